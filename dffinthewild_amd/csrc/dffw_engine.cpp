@@ -1,0 +1,978 @@
+// Host side of libdffw.so: the layer table (weight contract), BatchNorm folding + MFMA-fragment
+// weight packing, the static workspace arena and the whole-graph executor of DFF_net.forward
+// (reference Depth_Estimation_Test/Depth_Estimation_Network.py:74-127), behind the C ABI of
+// include/dffw.h.  All arithmetic of the forward runs in the gfx950 kernels of dffw_kernels.hip;
+// nothing here touches activation values.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/dffw.h"
+#include "dffw_internal.h"
+
+namespace dffw {
+
+// ---- errors ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return fail(DFFW_EHIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- layer table -------------------------------------------------------------------------------
+struct LayerDef {
+    std::string conv, bn;  // state-dict prefixes ("" = no BatchNorm)
+    int cin, cout;
+    int kd, kh, kw;
+    int sh, sw;            // stride over rows/cols (slice stride is always 1 in this network)
+    int pd, ph, pw;
+    int dh, dw;            // dilation over rows/cols
+    bool transposed;       // ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1)
+    bool live;
+    bool bias;
+};
+
+struct ParamInfo {
+    std::string name;
+    int64_t shape[5];
+    int ndim;
+    int flags;  // bit0 buffer, bit1 int64 counter, bit2 dead
+};
+
+class Table {
+  public:
+    std::vector<LayerDef> layers;
+    std::vector<ParamInfo> params;
+    std::map<std::string, int> by_name;
+
+    void conv(const std::string &key, int cin, int cout, int kd, int kh, int kw, int s, int pd, int ph, int pw, int dil,
+              bool bn, bool live = true) {
+        // `key` is the prefix of a reference convbn_3d pair when bn (conv = key.0, BatchNorm = key.1,
+        // DEN.py:286-289), else the conv's own prefix
+        LayerDef L{bn ? key + ".0" : key, bn ? key + ".1" : "", cin, cout, kd, kh, kw, s, s, pd, ph, pw, dil, dil, false, live, false};
+        add(L);
+    }
+    void deconv(const std::string &key, int cin, int cout) {
+        LayerDef L{key + ".0", key + ".1", cin, cout, 3, 3, 3, 2, 2, 1, 1, 1, 1, 1, true, true, false};
+        add(L);
+    }
+    void c3(const std::string &key, int cin, int cout, int s = 1, bool bn = true) { conv(key, cin, cout, 3, 3, 3, s, 1, 1, 1, 1, bn); }
+
+    void srd(const std::string &p, int c) {  // DEN.py:295-330
+        conv(p + ".Focus_Measure.conv.0", c, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
+        conv(p + ".Focus_Measure.conv.2", c, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
+        conv(p + ".N_ch_attention.0", c, c, 3, 1, 1, 1, 1, 0, 0, 1, false);
+        conv(p + ".N_ch_attention.2", c, c, 1, 1, 1, 1, 0, 0, 0, 1, false);
+    }
+    void efd(const std::string &p, int cin, int cout) {  // DEN.py:306-315
+        c3(p + ".stride_conv", cin, cout, 2);
+        c3(p + ".max_pooling.1", cin, cout, 1);
+    }
+    void hourglass(const std::string &p, int c) {  // DEN.py:240-264
+        c3(p + ".conv0.0", 2 * c, c);
+        c3(p + ".conv1.0", c, 2 * c, 2);
+        conv(p + ".pre_conv.0", 2 * c, 2 * c, 1, 1, 1, 1, 0, 0, 0, 1, true, /*live=*/false);
+        c3(p + ".conv2", 2 * c, 2 * c);
+        c3(p + ".conv3.0", 2 * c, 2 * c, 2);
+        c3(p + ".conv4.0", 2 * c, 2 * c);
+        deconv(p + ".conv5", 2 * c, 2 * c);
+        deconv(p + ".conv6", 2 * c, c);
+    }
+
+    static Table depth_net() {
+        Table t;
+        const std::string P = "DFF_net";
+        t.conv(P + ".FM_measure.Focus_extraction.0", 3, 8, 1, 9, 9, 1, 0, 8, 8, 2, true);  // DEN.py:135
+        t.srd(P + ".FM_measure.Focus_extraction.2", 8);
+        t.efd(P + ".FM_conv1.0", 8, 16);
+        t.srd(P + ".FM_conv1.1", 16);
+        t.efd(P + ".FM_conv2.0", 16, 32);
+        t.srd(P + ".FM_conv2.1", 32);
+        const std::string S = P + ".SPP_module";  // DEN.py:145-210
+        const char *scales[3] = {"8", "16", "32"};
+        const int widths[3] = {32, 64, 64};
+        for (int i = 0; i < 3; ++i) {
+            const std::string d = S + ".dres" + scales[i];
+            t.c3(d + "_0.0", 32, widths[i]);
+            t.c3(d + "_0.2", widths[i], widths[i]);
+            t.c3(d + "_1.0", widths[i], widths[i]);
+            t.c3(d + "_1.2", widths[i], widths[i]);
+        }
+        t.c3(S + ".conv1", 32, 64, 2, false);
+        t.c3(S + ".conv2.0", 64, 64);
+        t.c3(S + ".conv3", 64, 128, 2, false);
+        t.c3(S + ".conv4.0", 128, 128);
+        t.deconv(S + ".conv8", 128, 64);
+        t.deconv(S + ".conv9", 64, 32);
+        t.c3(S + ".combine1.0", 128, 64);
+        t.c3(S + ".combine2.0", 192, 128);
+        t.conv(S + ".redir1", 32, 32, 1, 1, 1, 1, 0, 0, 0, 1, true);
+        t.conv(S + ".redir2", 64, 64, 1, 1, 1, 1, 0, 0, 0, 1, true);
+        t.conv(S + ".redir3", 128, 128, 1, 1, 1, 1, 0, 0, 0, 1, true, /*live=*/false);
+        t.c3(P + ".confidence.0", 32, 32);
+        t.c3(P + ".confidence.2", 32, 1, 1, false);
+        t.c3(P + ".dres0.0", 32, 64);
+        t.c3(P + ".dres0.2", 64, 64);
+        t.deconv(P + ".deconv_1", 64, 32);
+        t.hourglass(P + ".dres2", 32);
+        t.deconv(P + ".deconv_2", 32, 16);
+        t.hourglass(P + ".dres3", 16);
+        t.deconv(P + ".deconv_3", 16, 8);
+        t.hourglass(P + ".dres4", 8);
+        t.conv(P + ".classif1.0", 32, 1, 1, 1, 1, 1, 0, 0, 0, 1, false);
+        t.conv(P + ".classif2.0", 16, 1, 1, 1, 1, 1, 0, 0, 0, 1, false);
+        t.conv(P + ".classif3.0", 8, 1, 1, 1, 1, 1, 0, 0, 0, 1, false);
+        return t;
+    }
+
+  private:
+    void add(const LayerDef &L) {
+        by_name[L.conv] = (int)layers.size();
+        layers.push_back(L);
+        const int dead = L.live ? 0 : 4;
+        ParamInfo w{L.conv + ".weight", {0, 0, 0, 0, 0}, 5, dead};
+        w.shape[0] = L.transposed ? L.cin : L.cout;
+        w.shape[1] = L.transposed ? L.cout : L.cin;
+        w.shape[2] = L.kd;
+        w.shape[3] = L.kh;
+        w.shape[4] = L.kw;
+        params.push_back(w);
+        if (L.bias) params.push_back(ParamInfo{L.conv + ".bias", {L.cout, 0, 0, 0, 0}, 1, dead});
+        if (!L.bn.empty()) {
+            params.push_back(ParamInfo{L.bn + ".weight", {L.cout, 0, 0, 0, 0}, 1, dead});
+            params.push_back(ParamInfo{L.bn + ".bias", {L.cout, 0, 0, 0, 0}, 1, dead});
+            params.push_back(ParamInfo{L.bn + ".running_mean", {L.cout, 0, 0, 0, 0}, 1, dead | 1});
+            params.push_back(ParamInfo{L.bn + ".running_var", {L.cout, 0, 0, 0, 0}, 1, dead | 1});
+            params.push_back(ParamInfo{L.bn + ".num_batches_tracked", {0, 0, 0, 0, 0}, 0, dead | 3});
+        }
+    }
+};
+
+static const Table &table_for(int net) {
+    static const Table depth = Table::depth_net();
+    (void)net;
+    return depth;
+}
+
+// ---- host number formats -----------------------------------------------------------------------
+static uint16_t host_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float host_bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static uint16_t host_f2h(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+static float host_h2f(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+static void host_split(int prec, float v, uint16_t &hi, uint16_t &lo) {
+    if (prec == P_BF16X3) {
+        hi = host_f2bf(v);
+        lo = host_f2bf(v - host_bf2f(hi));
+    } else if (prec == P_FP16) {
+        hi = host_f2h(v);
+        lo = 0;
+        (void)host_h2f;
+    } else {
+        hi = host_f2bf(v);
+        lo = 0;
+    }
+}
+
+// ---- packed conv layer -------------------------------------------------------------------------
+struct Tap {
+    int dz, dy, dx;  // input offset
+    int kz, ky, kx;  // which filter element
+};
+
+struct Variant {      // one launch: a regular conv, or one sub-pixel phase of a transposed conv
+    int KC = 0;
+    int ooy = 0, oox = 0;
+    TapEntry *tab = nullptr;  // device
+    uint16_t *wpk = nullptr;  // device
+};
+
+struct PackedConv {
+    LayerDef def;
+    int nt = 1;
+    float *bias = nullptr;  // device, nt*16 floats
+    std::vector<Variant> variants;
+};
+
+static void free_packed(PackedConv &pc) {
+    if (pc.bias) (void)hipFree(pc.bias);
+    for (auto &v : pc.variants) {
+        if (v.tab) (void)hipFree(v.tab);
+        if (v.wpk) (void)hipFree(v.wpk);
+    }
+    pc.variants.clear();
+    pc.bias = nullptr;
+}
+
+// weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
+static int pack_conv(const LayerDef &L, int prec, const float *weight, const float *bn, const float *conv_bias,
+                     PackedConv &pc) {
+    pc.def = L;
+    pc.nt = conv_nt_for(L.cout);
+    const int parts = prec_parts(prec);
+    const int cin_pad = (L.cin + 7) / 8 * 8;
+    const int c8n = cin_pad / 8;
+
+    // fold BatchNorm (eval mode, eps 1e-5): y = conv(x)*scale + shift
+    std::vector<double> scale(L.cout, 1.0), shift(L.cout, 0.0);
+    for (int c = 0; c < L.cout; ++c) {
+        if (bn) {
+            const double g = bn[c], b = bn[L.cout + c], m = bn[2 * L.cout + c], v = bn[3 * L.cout + c];
+            scale[c] = g / std::sqrt(v + 1e-5);
+            shift[c] = b - m * scale[c];
+        }
+        if (conv_bias) shift[c] += conv_bias[c] * scale[c];
+    }
+    std::vector<float> bias(pc.nt * 16, 0.f);
+    for (int c = 0; c < L.cout; ++c) bias[c] = (float)shift[c];
+    HIPCHK(hipMalloc((void **)&pc.bias, bias.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(pc.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    // tap lists
+    std::vector<std::vector<Tap>> tapsets;
+    std::vector<std::pair<int, int>> phase;
+    if (!L.transposed) {
+        std::vector<Tap> taps;
+        for (int kz = 0; kz < L.kd; ++kz)
+            for (int ky = 0; ky < L.kh; ++ky)
+                for (int kx = 0; kx < L.kw; ++kx)
+                    taps.push_back(Tap{kz - L.pd, ky * L.dh - L.ph, kx * L.dw - L.pw, kz, ky, kx});
+        tapsets.push_back(taps);
+        phase.push_back({0, 0});
+    } else {
+        // out[oz,oy,ox] = sum in[iz,iy,ix] * w[kz,ky,kx] with oz = iz-1+kz, oy = 2*iy-1+ky, ox = 2*ix-1+kx.
+        // For output parity p along a stride-2 axis (o = 2*g + p): p=0 uses k=1 at i=g; p=1 uses k=0 at
+        // i=g+1 and k=2 at i=g.  Never materialise the zero-inserted input.
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                std::vector<Tap> taps;
+                for (int kz = 0; kz < 3; ++kz)
+                    for (int ky = 0; ky < 3; ++ky) {
+                        if ((ky & 1) == py) continue;  // py=0 -> ky odd only; py=1 -> ky even only
+                        for (int kx = 0; kx < 3; ++kx) {
+                            if ((kx & 1) == px) continue;
+                            const int dy = (ky == 0) ? 1 : 0, dx = (kx == 0) ? 1 : 0;
+                            taps.push_back(Tap{1 - kz, dy, dx, kz, ky, kx});
+                        }
+                    }
+                tapsets.push_back(taps);
+                phase.push_back({py, px});
+            }
+    }
+
+    const int kvol = L.kd * L.kh * L.kw;
+    auto wval = [&](int cout, int cin, const Tap &t) -> double {
+        const int64_t kidx = ((int64_t)t.kz * L.kh + t.ky) * L.kw + t.kx;
+        const int64_t i = L.transposed ? ((int64_t)cin * L.cout + cout) * kvol + kidx : ((int64_t)cout * L.cin + cin) * kvol + kidx;
+        return (double)weight[i] * scale[cout];
+    };
+
+    for (size_t vi = 0; vi < tapsets.size(); ++vi) {
+        const auto &taps = tapsets[vi];
+        Variant v;
+        v.ooy = phase[vi].first;
+        v.oox = phase[vi].second;
+        const int K8 = (int)taps.size() * c8n;
+        v.KC = (K8 + 3) / 4;
+        std::vector<TapEntry> tab(v.KC * 4);
+        for (int k8 = 0; k8 < v.KC * 4; ++k8) {
+            if (k8 < K8) {
+                const Tap &t = taps[k8 / c8n];
+                tab[k8] = TapEntry{t.dz, t.dy, t.dx, (k8 % c8n) * 8};
+            } else {
+                tab[k8] = TapEntry{0, 0, 0, -1};
+            }
+        }
+        std::vector<uint16_t> wpk((size_t)v.KC * pc.nt * parts * 64 * 8, 0);
+        for (int kc = 0; kc < v.KC; ++kc)
+            for (int nt = 0; nt < pc.nt; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int cout = nt * 16 + (lane & 15);
+                        const int k = kc * 32 + (lane >> 4) * 8 + j;
+                        const int tapi = k / cin_pad, cin = k % cin_pad;
+                        float val = 0.f;
+                        if (cout < L.cout && tapi < (int)taps.size() && cin < L.cin) val = (float)wval(cout, cin, taps[tapi]);
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)kc * pc.nt + nt) * parts) * 512 + (size_t)lane * 8 + j;
+                        wpk[base] = hi;
+                        if (parts == 2) wpk[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&v.tab, tab.size() * sizeof(TapEntry)));
+        HIPCHK(hipMemcpy(v.tab, tab.data(), tab.size() * sizeof(TapEntry), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&v.wpk, wpk.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(v.wpk, wpk.data(), wpk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        pc.variants.push_back(v);
+    }
+    return DFFW_OK;
+}
+
+// ---- workspace arena ---------------------------------------------------------------------------
+// Offsets into the caller's workspace; first-fit with coalescing.  The graph is static for a given
+// (B,N,H,W), so a dry run of the same code computes the exact peak (dffw_workspace_bytes).
+class Arena {
+  public:
+    explicit Arena(int64_t cap = INT64_MAX) : cap_(cap) { free_.push_back({0, cap}); }
+    int64_t alloc(int64_t bytes) {
+        bytes = (bytes + 255) & ~(int64_t)255;
+        for (size_t i = 0; i < free_.size(); ++i) {
+            if (free_[i].second >= bytes) {
+                const int64_t off = free_[i].first;
+                free_[i].first += bytes;
+                free_[i].second -= bytes;
+                if (free_[i].second == 0) free_.erase(free_.begin() + i);
+                live_[off] = bytes;
+                peak_ = std::max(peak_, off + bytes);
+                return off;
+            }
+        }
+        return -1;
+    }
+    void release(int64_t off) {
+        auto it = live_.find(off);
+        if (it == live_.end()) return;
+        std::pair<int64_t, int64_t> blk{off, it->second};
+        live_.erase(it);
+        auto pos = std::lower_bound(free_.begin(), free_.end(), blk);
+        pos = free_.insert(pos, blk);
+        size_t i = pos - free_.begin();
+        if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
+            free_[i].second += free_[i + 1].second;
+            free_.erase(free_.begin() + i + 1);
+        }
+        if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
+            free_[i - 1].second += free_[i].second;
+            free_.erase(free_.begin() + i);
+        }
+    }
+    int64_t peak() const { return peak_; }
+
+  private:
+    int64_t cap_, peak_ = 0;
+    std::vector<std::pair<int64_t, int64_t>> free_;
+    std::map<int64_t, int64_t> live_;
+};
+
+}  // namespace dffw
+
+using namespace dffw;
+
+// ---- engine ------------------------------------------------------------------------------------
+struct dffw_engine {
+    int device = 0, net = 0, prec = 0;
+    std::map<std::string, PackedConv> convs;
+    ~dffw_engine() {
+        for (auto &kv : convs) free_packed(kv.second);
+    }
+};
+
+namespace dffw {
+
+struct ConvOpt {
+    const Act *in1 = nullptr;
+    const Act *res0 = nullptr, *res1 = nullptr;
+    int relu = 0;
+    Act *out_pre = nullptr;  // receives the pre-residual value (allocated here)
+    float *outf = nullptr;   // fp32 score output instead of an activation volume
+};
+
+struct Run {
+    dffw_engine *e;
+    hipStream_t s;
+    Arena arena;
+    bool dry;
+    char *ws;
+    int err = DFFW_OK;
+    const dffw_tap *taps = nullptr;
+    int n_taps = 0;
+
+    Run(dffw_engine *e_, hipStream_t s_, bool dry_, char *ws_, int64_t cap) : e(e_), s(s_), arena(cap), dry(dry_), ws(ws_) {}
+
+    bool ok() const { return err == DFFW_OK; }
+
+    void *raw(int64_t bytes) {
+        if (!ok()) return nullptr;
+        const int64_t off = arena.alloc(bytes);
+        if (off < 0) {
+            err = fail(DFFW_ENOMEM, "workspace too small (need more than the %lld bytes given)", (long long)bytes);
+            return nullptr;
+        }
+        return dry ? (void *)(uintptr_t)(off + 256) : (void *)(ws + off);
+    }
+    void drop_raw(void *p) {
+        if (!p) return;
+        arena.release(dry ? (int64_t)(uintptr_t)p - 256 : (int64_t)((char *)p - ws));
+    }
+    Act act(int B, int N, int H, int W, int C) {
+        Act a;
+        a.B = B; a.N = N; a.H = H; a.W = W; a.C = C;
+        a.p = (uint16_t *)raw(a.pixels() * prec_parts(e->prec) * C * (int64_t)sizeof(uint16_t));
+        return a;
+    }
+    void drop(Act &a) {
+        drop_raw(a.p);
+        a.p = nullptr;
+    }
+    void check(hipError_t h, const char *what) {
+        if (ok() && h != hipSuccess) err = fail(DFFW_EHIP, "%s: %s", what, hipGetErrorString(h));
+    }
+
+    Act conv(const std::string &name, const Act &in0, const ConvOpt &o = ConvOpt()) {
+        Act out;
+        if (!ok()) return out;
+        auto it = e->convs.find(name);
+        if (it == e->convs.end()) {
+            err = fail(DFFW_EINVAL, "no packed layer %s", name.c_str());
+            return out;
+        }
+        const PackedConv &pc = it->second;
+        const LayerDef &L = pc.def;
+        const int cin = in0.C + (o.in1 ? o.in1->C : 0);
+        const int cin_pad = (L.cin + 7) / 8 * 8;
+        if (cin != cin_pad) {
+            err = fail(DFFW_EINVAL, "layer %s expects %d input channels, got %d", name.c_str(), cin_pad, cin);
+            return out;
+        }
+        int Ho, Wo;
+        if (L.transposed) {
+            Ho = in0.H * 2;
+            Wo = in0.W * 2;
+        } else {
+            Ho = (in0.H + 2 * L.ph - L.dh * (L.kh - 1) - 1) / L.sh + 1;
+            Wo = (in0.W + 2 * L.pw - L.dw * (L.kw - 1) - 1) / L.sw + 1;
+        }
+        const int No = in0.N + 2 * L.pd - (L.kd - 1);
+        if (o.outf == nullptr) out = act(in0.B, No, Ho, Wo, L.cout);
+        else { out.B = in0.B; out.N = No; out.H = Ho; out.W = Wo; out.C = L.cout; }
+        if (o.out_pre) *o.out_pre = act(in0.B, No, Ho, Wo, L.cout);
+        if (!ok() || dry) return out;
+
+        ConvArgs a;
+        memset(&a, 0, sizeof a);
+        a.in0 = in0.p;
+        a.C0 = in0.C;
+        a.in1 = o.in1 ? o.in1->p : in0.p;
+        a.C1 = o.in1 ? o.in1->C : 0;
+        a.B = in0.B; a.Ni = in0.N; a.Hi = in0.H; a.Wi = in0.W;
+        a.No = No; a.Ho = Ho; a.Wo = Wo;
+        a.Cout = L.cout;
+        a.bias = pc.bias;
+        a.res0 = o.res0 ? o.res0->p : nullptr;
+        a.res1 = o.res1 ? o.res1->p : nullptr;
+        a.out = out.p;
+        a.out_pre = o.out_pre ? o.out_pre->p : nullptr;
+        a.outf = o.outf;
+        a.relu = o.relu;
+        for (const Variant &v : pc.variants) {
+            a.KC = v.KC;
+            a.tab = v.tab;
+            a.wpk = v.wpk;
+            if (L.transposed) {
+                a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
+                a.sy = a.sx = 1;
+                a.osy = a.osx = 2;
+                a.ooy = v.ooy; a.oox = v.oox;
+            } else {
+                a.Ng = No; a.Hg = Ho; a.Wg = Wo;
+                a.sy = L.sh; a.sx = L.sw;
+                a.osy = a.osx = 1;
+                a.ooy = a.oox = 0;
+            }
+            a.M = (int64_t)a.B * a.Ng * a.Hg * a.Wg;
+            check(launch_conv(e->prec, a, s), name.c_str());
+        }
+        return out;
+    }
+
+    Act pool(const Act &x, int mode, int k) {
+        Act out = act(x.B, x.N, x.H / k, x.W / k, x.C);
+        if (ok() && !dry) check(launch_pool(e->prec, mode, k, x.p, out.p, x.B, x.N, x.H, x.W, x.C, s), "pool");
+        return out;
+    }
+
+    void tap(const char *name, const Act &a) {
+        if (!ok() || dry) return;
+        for (int i = 0; i < n_taps; ++i)
+            if (!strcmp(taps[i].name, name)) {
+                const int64_t n = a.pixels() * a.C;
+                if (taps[i].numel != n) {
+                    err = fail(DFFW_EINVAL, "tap %s holds %lld elements, caller gave %lld", name, (long long)n, (long long)taps[i].numel);
+                    return;
+                }
+                check(launch_to_ncdhw(e->prec, a.p, taps[i].dst, a.B, a.C, a.N, a.H, a.W, s), name);
+            }
+    }
+    void tap_f32(const char *name, const float *p, int64_t n) {
+        if (!ok() || dry) return;
+        for (int i = 0; i < n_taps; ++i)
+            if (!strcmp(taps[i].name, name)) {
+                if (taps[i].numel != n) {
+                    err = fail(DFFW_EINVAL, "tap %s holds %lld elements, caller gave %lld", name, (long long)n, (long long)taps[i].numel);
+                    return;
+                }
+                check(hipMemcpyAsync(taps[i].dst, p, n * sizeof(float), hipMemcpyDeviceToDevice, s), name);
+            }
+    }
+};
+
+// SRD block (DEN.py:317-330): x -> feat = relu(x + BN(conv(relu(BN(conv x))))) ; feat + relu(conv1(relu(conv3x1x1 feat)))
+static Act srd(Run &r, const std::string &p, Act &x, bool drop_x) {
+    ConvOpt o1; o1.relu = 1;
+    Act t = r.conv(p + ".Focus_Measure.conv.0.0", x, o1);
+    ConvOpt o2; o2.relu = 1; o2.res0 = &x;
+    Act feat = r.conv(p + ".Focus_Measure.conv.2.0", t, o2);
+    r.drop(t);
+    if (drop_x) r.drop(x);
+    ConvOpt o3; o3.relu = 1;
+    Act a = r.conv(p + ".N_ch_attention.0", feat, o3);
+    ConvOpt o4; o4.relu = 2; o4.res0 = &feat;
+    Act out = r.conv(p + ".N_ch_attention.2", a, o4);
+    r.drop(a);
+    r.drop(feat);
+    return out;
+}
+
+// EFD block (DEN.py:306-315)
+static Act efd(Run &r, const std::string &p, const Act &x) {
+    Act a = r.conv(p + ".stride_conv.0", x);
+    Act m = r.pool(x, 0, 2);
+    ConvOpt o; o.relu = 1; o.res0 = &a;
+    Act out = r.conv(p + ".max_pooling.1.0", m, o);
+    r.drop(m);
+    r.drop(a);
+    return out;
+}
+
+// one scale of the pyramid: r0 = dresX_0(t) ; dresX_1(r0) + r0   (DEN.py:216-223)
+static Act pyramid_scale(Run &r, const std::string &S, const char *tag, Act &t) {
+    const std::string d = S + ".dres" + tag;
+    ConvOpt rl; rl.relu = 1;
+    Act a = r.conv(d + "_0.0.0", t, rl);
+    Act r0 = r.conv(d + "_0.2.0", a, rl);
+    r.drop(a);
+    Act b = r.conv(d + "_1.0.0", r0, rl);
+    ConvOpt o; o.res0 = &r0;
+    Act out = r.conv(d + "_1.2.0", b, o);
+    r.drop(b);
+    r.drop(r0);
+    return out;
+}
+
+// hourglassup.forward (DEN.py:212-238)
+static Act pyramid(Run &r, const std::string &S, const Act &v3) {
+    ConvOpt rl; rl.relu = 1;
+    Act p8 = r.pool(v3, 1, 2), p16 = r.pool(v3, 1, 4), p32 = r.pool(v3, 1, 8);
+    Act s8 = pyramid_scale(r, S, "8", p8);
+    r.drop(p8);
+    Act s16 = pyramid_scale(r, S, "16", p16);
+    r.drop(p16);
+    Act s32 = pyramid_scale(r, S, "32", p32);
+    r.drop(p32);
+    Act d1 = r.conv(S + ".conv1", s8);
+    ConvOpt c1 = rl; c1.in1 = &s16;
+    Act m1 = r.conv(S + ".combine1.0.0", d1, c1);
+    r.drop(d1); r.drop(s16);
+    Act c2 = r.conv(S + ".conv2.0.0", m1, rl);
+    r.drop(m1);
+    Act d2 = r.conv(S + ".conv3", c2);
+    ConvOpt cc2 = rl; cc2.in1 = &s32;
+    Act m2 = r.conv(S + ".combine2.0.0", d2, cc2);
+    r.drop(d2); r.drop(s32);
+    Act c4 = r.conv(S + ".conv4.0.0", m2, rl);
+    r.drop(m2);
+    Act rd2 = r.conv(S + ".redir2.0", c2);
+    r.drop(c2);
+    ConvOpt u8o = rl; u8o.res0 = &rd2;
+    Act u8 = r.conv(S + ".conv8.0", c4, u8o);
+    r.drop(c4); r.drop(rd2);
+    Act rd1 = r.conv(S + ".redir1.0", s8);
+    r.drop(s8);
+    ConvOpt u9o = rl; u9o.res0 = &rd1;
+    Act u9 = r.conv(S + ".conv9.0", u8, u9o);
+    r.drop(u8); r.drop(rd1);
+    return u9;
+}
+
+// hourglass.forward (DEN.py:265-284).  x = cat[xa, xb] on channels.  Returns conv6's output `out`
+// in *out_raw (if wanted) and out + skip in the return value; pre1 = conv0's output.
+static Act hourglass(Run &r, const std::string &p, const Act &xa, const Act &xb, const Act *presqu, const Act *postsqu,
+                     const Act &skip, Act *pre1_out, Act *out_raw) {
+    ConvOpt rl; rl.relu = 1;
+    ConvOpt c0 = rl; c0.in1 = &xb;
+    Act pre1 = r.conv(p + ".conv0.0.0", xa, c0);
+    Act o1 = r.conv(p + ".conv1.0.0", pre1, rl);
+    ConvOpt c2 = rl; c2.res0 = postsqu;
+    Act pre = r.conv(p + ".conv2.0", o1, c2);
+    r.drop(o1);
+    Act o3 = r.conv(p + ".conv3.0.0", pre, rl);
+    Act o4 = r.conv(p + ".conv4.0.0", o3, rl);
+    r.drop(o3);
+    ConvOpt c5 = rl; c5.res0 = presqu ? presqu : &pre;
+    Act o5 = r.conv(p + ".conv5.0", o4, c5);
+    r.drop(o4); r.drop(pre);
+    ConvOpt c6; c6.res0 = &skip; c6.out_pre = out_raw;
+    Act sum = r.conv(p + ".conv6.0", o5, c6);
+    r.drop(o5);
+    if (pre1_out) *pre1_out = pre1; else r.drop(pre1);
+    return sum;
+}
+
+static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst[4], int B, int N, int H, int W, float *const out[4]) {
+    const std::string P = "DFF_net";
+    const int prec = r.e->prec;
+    ConvOpt rl; rl.relu = 1;
+
+    // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80
+    Act in = r.act(B, N, H, W, 8);
+    if (r.ok() && !r.dry) r.check(launch_stack_in(prec, FS, in.p, B, N, H, W, r.s), "stack_in");
+    Act stem = r.conv(P + ".FM_measure.Focus_extraction.0.0", in, rl);
+    r.drop(in);
+    Act v1 = srd(r, P + ".FM_measure.Focus_extraction.2", stem, true);
+    r.tap("V1", v1);
+    Act e1 = efd(r, P + ".FM_conv1.0", v1);
+    Act v2 = srd(r, P + ".FM_conv1.1", e1, true);
+    r.tap("V2", v2);
+    Act e2 = efd(r, P + ".FM_conv2.0", v2);
+    Act v3 = srd(r, P + ".FM_conv2.1", e2, true);
+    r.tap("V3", v3);
+
+    // multi-scale aggregation (1st hourglass)                                      DEN.py:82
+    Act vol = pyramid(r, P + ".SPP_module", v3);
+    r.tap("FS_volume", vol);
+
+    // confidence head -> mid_out                                                   DEN.py:83-90
+    const int h8 = H / 8, w8 = W / 8;
+    float *conf = (float *)r.raw((int64_t)B * N * h8 * w8 * sizeof(float));
+    {
+        Act c = r.conv(P + ".confidence.0.0", vol, rl);
+        ConvOpt of; of.outf = conf;
+        r.conv(P + ".confidence.2", c, of);
+        r.drop(c);
+        r.tap_f32("conf", conf, (int64_t)B * N * h8 * w8);
+        if (r.ok() && !r.dry && out[0])
+            r.check(launch_regress(conf, B, N, h8, w8, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[0], r.s), "regress0");
+        r.drop_raw(conf);
+    }
+
+    // refinement                                                                   DEN.py:92-108
+    Act d0 = r.conv(P + ".dres0.0.0", vol, rl);
+    r.drop(vol);
+    Act d1 = r.conv(P + ".dres0.2.0", d0, rl);
+    r.drop(d0);
+    Act x1 = r.conv(P + ".deconv_1.0", d1);
+    r.drop(d1);
+
+    Act pre_a, out_a;
+    Act s1 = hourglass(r, P + ".dres2", x1, v3, nullptr, nullptr, x1, &pre_a, &out_a);
+    r.drop(x1); r.drop(v3);
+    const int h4 = H / 4, w4 = W / 4;
+    float *cost1 = (float *)r.raw((int64_t)B * N * h4 * w4 * sizeof(float));
+    { ConvOpt of; of.outf = cost1; r.conv(P + ".classif1.0", s1, of); }
+    r.tap_f32("cost1", cost1, (int64_t)B * N * h4 * w4);
+    if (r.ok() && !r.dry && out[1])
+        r.check(launch_regress(cost1, B, N, h4, w4, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[1], r.s), "regress1");
+    r.drop_raw(cost1);
+
+    Act x2 = r.conv(P + ".deconv_2.0", s1);
+    r.drop(s1);
+    Act pre_b, out_b;
+    Act s2 = hourglass(r, P + ".dres3", x2, v2, &pre_a, &out_a, x2, &pre_b, &out_b);
+    r.drop(x2); r.drop(v2); r.drop(pre_a); r.drop(out_a);
+    const int h2 = H / 2, w2 = W / 2;
+    float *cost2 = (float *)r.raw((int64_t)B * N * h2 * w2 * sizeof(float));
+    { ConvOpt of; of.outf = cost2; r.conv(P + ".classif2.0", s2, of); }
+    r.tap_f32("cost2", cost2, (int64_t)B * N * h2 * w2);
+    if (r.ok() && !r.dry && out[2])
+        r.check(launch_regress(cost2, B, N, h2, w2, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[2], r.s), "regress2");
+    r.drop_raw(cost2);
+
+    Act x3 = r.conv(P + ".deconv_3.0", s2);
+    r.drop(s2);
+    Act s3 = hourglass(r, P + ".dres4", x3, v1, &pre_b, &out_b, x3, nullptr, nullptr);
+    r.drop(x3); r.drop(v1); r.drop(pre_b); r.drop(out_b);
+    float *cost3 = (float *)r.raw((int64_t)B * N * H * W * sizeof(float));
+    { ConvOpt of; of.outf = cost3; r.conv(P + ".classif3.0", s3, of); }
+    r.drop(s3);
+    r.tap_f32("cost3", cost3, (int64_t)B * N * H * W);
+    if (r.ok() && !r.dry && out[3])
+        r.check(launch_regress(cost3, B, N, H, W, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[3], r.s), "regress3");
+    r.drop_raw(cost3);
+    return r.err;
+}
+
+static int check_dims(int B, int N, int H, int W) {
+    if (B < 1 || N < 1) return fail(DFFW_EINVAL, "B and N must be >= 1 (got B=%d N=%d)", B, N);
+    if (H < 32 || W < 32 || H % 32 || W % 32)
+        return fail(DFFW_EINVAL, "H and W must be positive multiples of 32 (got %dx%d); pad with -1 as the reference loaders do", H, W);
+    return DFFW_OK;
+}
+
+}  // namespace dffw
+
+// ---- C ABI -------------------------------------------------------------------------------------
+extern "C" {
+
+const char *dffw_version(void) { return "dffw 0.1 (gfx950)"; }
+const char *dffw_last_error(void) { return g_err.c_str(); }
+
+int dffw_param_count(int net) {
+    if (net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "unknown net %d", net);
+    return (int)table_for(net).params.size();
+}
+
+int dffw_param_info(int net, int index, const char **name, int64_t shape[5], int *ndim, int *flags) {
+    if (net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "unknown net %d", net);
+    const Table &t = table_for(net);
+    if (index < 0 || index >= (int)t.params.size()) return fail(DFFW_EINVAL, "param index %d out of range", index);
+    const ParamInfo &p = t.params[index];
+    if (name) *name = p.name.c_str();
+    if (shape) memcpy(shape, p.shape, sizeof p.shape);
+    if (ndim) *ndim = p.ndim;
+    if (flags) *flags = p.flags;
+    return DFFW_OK;
+}
+
+int dffw_engine_create(int device, int net, const dffw_tensor *tensors, int n_tensors, int precision, dffw_engine **out) {
+    if (!out) return fail(DFFW_EINVAL, "out is null");
+    *out = nullptr;
+    if (net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "unknown net %d", net);
+    if (precision < 0 || precision > 2) return fail(DFFW_EINVAL, "unknown precision %d", precision);
+    if (!tensors || n_tensors <= 0) return fail(DFFW_EINVAL, "no tensors given");
+    HIPCHK(hipSetDevice(device));
+    std::map<std::string, const dffw_tensor *> by;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name) return fail(DFFW_EINVAL, "tensor %d has no name", i);
+        std::string nm = tensors[i].name;
+        if (nm.rfind("module.", 0) == 0) nm = nm.substr(7);
+        by[nm] = &tensors[i];
+    }
+    auto need = [&](const std::string &nm, int64_t numel, const float **p) -> int {
+        auto it = by.find(nm);
+        if (it == by.end()) return fail(DFFW_EMISSING, "state dict has no entry '%s'", nm.c_str());
+        if (it->second->numel != numel)
+            return fail(DFFW_EINVAL, "'%s' has %lld elements, expected %lld", nm.c_str(), (long long)it->second->numel, (long long)numel);
+        if (!it->second->data) return fail(DFFW_EINVAL, "'%s' has null data", nm.c_str());
+        *p = it->second->data;
+        return DFFW_OK;
+    };
+    std::unique_ptr<dffw_engine> e(new dffw_engine);
+    e->device = device;
+    e->net = net;
+    e->prec = precision;
+    const Table &t = table_for(net);
+    for (const LayerDef &L : t.layers) {
+        if (!L.live) continue;
+        const float *w = nullptr, *cb = nullptr;
+        int rc = need(L.conv + ".weight", (int64_t)L.cin * L.cout * L.kd * L.kh * L.kw, &w);
+        if (rc) return rc;
+        if (L.bias && (rc = need(L.conv + ".bias", L.cout, &cb))) return rc;
+        std::vector<float> bn;
+        if (!L.bn.empty()) {
+            const char *sfx[4] = {".weight", ".bias", ".running_mean", ".running_var"};
+            bn.resize(4 * (size_t)L.cout);
+            for (int k = 0; k < 4; ++k) {
+                const float *p = nullptr;
+                if ((rc = need(L.bn + sfx[k], L.cout, &p))) return rc;
+                memcpy(bn.data() + (size_t)k * L.cout, p, L.cout * sizeof(float));
+            }
+        }
+        PackedConv &pc = e->convs[L.conv];
+        rc = pack_conv(L, precision, w, bn.empty() ? nullptr : bn.data(), cb, pc);
+        if (rc) return rc;
+    }
+    *out = e.release();
+    return DFFW_OK;
+}
+
+void dffw_engine_destroy(dffw_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    delete e;
+}
+
+int dffw_engine_precision(const dffw_engine *e) { return e ? e->prec : fail(DFFW_EINVAL, "null engine"); }
+
+int64_t dffw_workspace_bytes(const dffw_engine *e, int B, int N, int H, int W) {
+    if (!e) return fail(DFFW_EINVAL, "null engine");
+    int rc = check_dims(B, N, H, W);
+    if (rc) return rc;
+    Run r(const_cast<dffw_engine *>(e), nullptr, true, nullptr, INT64_MAX / 2);
+    const int64_t st[4] = {0, 0, 0, 0};
+    float *outs[4] = {nullptr, nullptr, nullptr, nullptr};
+    rc = run_depth(r, nullptr, nullptr, st, B, N, H, W, outs);
+    if (rc) return rc;
+    return r.arena.peak();
+}
+
+int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists, const int64_t fd_strides[4], int B, int N,
+                      int H, int W, float *const out[4], void *workspace, int64_t workspace_bytes, void *hip_stream,
+                      const dffw_tap *taps, int n_taps) {
+    if (!e || !FS || !focus_dists || !fd_strides || !out) return fail(DFFW_EINVAL, "null argument");
+    int rc = check_dims(B, N, H, W);
+    if (rc) return rc;
+    if (!workspace) return fail(DFFW_ENOMEM, "workspace is null");
+    HIPCHK(hipSetDevice(e->device));
+    Run r(e, (hipStream_t)hip_stream, false, (char *)workspace, workspace_bytes);
+    r.taps = taps;
+    r.n_taps = taps ? n_taps : 0;
+    return run_depth(r, FS, focus_dists, fd_strides, B, N, H, W, out);
+}
+
+int dffw_forward(dffw_engine *e, const float *FS, const float *focus_dists, const int64_t fd_strides[4], int B, int N, int H,
+                 int W, float *const out[4], void *workspace, int64_t workspace_bytes, void *hip_stream) {
+    return dffw_forward_taps(e, FS, focus_dists, fd_strides, B, N, H, W, out, workspace, workspace_bytes, hip_stream, nullptr, 0);
+}
+
+// ---- single-operator entry points --------------------------------------------------------------
+int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, int N, int H, int W, const float *weight,
+                   int Cout, const int kernel[3], const int stride[3], const int pad[3], const int dilation[3], int transposed,
+                   const float *bn, const float *conv_bias, const float *residual, int relu, float *y, void *hip_stream) {
+    if (!x || !weight || !y || !kernel || !stride || !pad || !dilation) return fail(DFFW_EINVAL, "null argument");
+    if (precision < 0 || precision > 2) return fail(DFFW_EINVAL, "unknown precision %d", precision);
+    if (stride[0] != 1 || dilation[0] != 1) return fail(DFFW_EINVAL, "slice stride/dilation must be 1");
+    if (stride[1] != stride[2] || dilation[1] != dilation[2]) return fail(DFFW_EINVAL, "row/col stride and dilation must match");
+    if (Cout != 1 && Cout % 4) return fail(DFFW_EINVAL, "Cout must be 1 or a multiple of 4");
+    if (Cout > 128) return fail(DFFW_EINVAL, "Cout > 128 unsupported");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    LayerDef L{"op", "", Cin, Cout, kernel[0], kernel[1], kernel[2], stride[1], stride[2], pad[0], pad[1], pad[2],
+               dilation[1], dilation[2], transposed != 0, true, false};
+    if (transposed && !(kernel[0] == 3 && kernel[1] == 3 && kernel[2] == 3 && stride[1] == 2 && pad[0] == 1 && pad[1] == 1 && pad[2] == 1))
+        return fail(DFFW_EINVAL, "transposed conv supports only k3 s(1,2,2) p1 op(0,1,1)");
+    dffw_engine eng;
+    eng.device = device;
+    eng.prec = precision;
+    int rc = pack_conv(L, precision, weight, bn, conv_bias, eng.convs["op"]);
+    if (rc) return rc;
+    const int parts = prec_parts(precision);
+    const int cpad = (Cin + 7) / 8 * 8;
+    Act in;
+    in.B = B; in.N = N; in.H = H; in.W = W; in.C = cpad;
+    const int64_t in_bytes = in.pixels() * parts * cpad * 2;
+    HIPCHK(hipMalloc((void **)&in.p, in_bytes));
+    HIPCHK(hipMemsetAsync(in.p, 0, in_bytes, s));
+    // place the Cin real channels into the first channels of the padded volume
+    {
+        // from_ncdhw writes C=Cin densely; when Cin is not a multiple of 8 go through a temp
+        if (cpad == Cin) {
+            HIPCHK(launch_from_ncdhw(precision, x, in.p, B, Cin, N, H, W, s));
+        } else {
+            float *xp = nullptr;
+            const int64_t plane = (int64_t)N * H * W;
+            HIPCHK(hipMalloc((void **)&xp, (size_t)B * cpad * plane * sizeof(float)));
+            HIPCHK(hipMemsetAsync(xp, 0, (size_t)B * cpad * plane * sizeof(float), s));
+            for (int b = 0; b < B; ++b)
+                HIPCHK(hipMemcpyAsync(xp + (int64_t)b * cpad * plane, x + (int64_t)b * Cin * plane, (size_t)Cin * plane * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s));
+            HIPCHK(launch_from_ncdhw(precision, xp, in.p, B, cpad, N, H, W, s));
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipFree(xp));
+        }
+    }
+    int Ho, Wo;
+    if (transposed) { Ho = 2 * H; Wo = 2 * W; }
+    else {
+        Ho = (H + 2 * pad[1] - dilation[1] * (kernel[1] - 1) - 1) / stride[1] + 1;
+        Wo = (W + 2 * pad[2] - dilation[2] * (kernel[2] - 1) - 1) / stride[2] + 1;
+    }
+    const int No = N + 2 * pad[0] - (kernel[0] - 1);
+    const int64_t opix = (int64_t)B * No * Ho * Wo;
+    // run through the same Run::conv path the graph uses, on a private workspace
+    const int64_t ws_bytes = 2 * (opix * parts * std::max(Cout, 4) * 2 + 4096) + opix * 4 + 4096;
+    char *ws = nullptr;
+    HIPCHK(hipMalloc((void **)&ws, ws_bytes));
+    Run r(&eng, s, false, ws, ws_bytes);
+    Act res;
+    ConvOpt o;
+    o.relu = relu;
+    float *scoref = nullptr;
+    if (Cout == 1) {
+        scoref = (float *)r.raw(opix * sizeof(float));
+        o.outf = scoref;
+    } else if (residual) {
+        res = r.act(B, No, Ho, Wo, Cout);
+        HIPCHK(launch_from_ncdhw(precision, residual, res.p, B, Cout, No, Ho, Wo, s));
+        o.res0 = &res;
+    }
+    Act out = r.conv("op", in, o);
+    rc = r.err;
+    if (rc == DFFW_OK) {
+        if (Cout == 1) rc = hipMemcpyAsync(y, scoref, opix * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? DFFW_OK : fail(DFFW_EHIP, "copy");
+        else rc = launch_to_ncdhw(precision, out.p, y, B, Cout, No, Ho, Wo, s) == hipSuccess ? DFFW_OK : fail(DFFW_EHIP, "to_ncdhw");
+    }
+    hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(ws);
+    (void)hipFree(in.p);
+    if (rc == DFFW_OK && se != hipSuccess) rc = fail(DFFW_EHIP, "sync: %s", hipGetErrorString(se));
+    return rc;
+}
+
+int dffw_op_pool(int device, int precision, int mode, int k, const float *x, int B, int C, int N, int H, int W, float *y,
+                 void *hip_stream) {
+    if (!x || !y) return fail(DFFW_EINVAL, "null argument");
+    if (precision < 0 || precision > 2) return fail(DFFW_EINVAL, "unknown precision %d", precision);
+    if (C % 8 || k < 1 || H % k || W % k) return fail(DFFW_EINVAL, "pool needs C %% 8 == 0 and H,W divisible by k");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int parts = prec_parts(precision);
+    uint16_t *a = nullptr, *b = nullptr;
+    const int64_t nin = (int64_t)B * N * H * W * parts * C, nout = (int64_t)B * N * (H / k) * (W / k) * parts * C;
+    HIPCHK(hipMalloc((void **)&a, nin * 2));
+    HIPCHK(hipMalloc((void **)&b, nout * 2));
+    int rc = DFFW_OK;
+    hipError_t h = launch_from_ncdhw(precision, x, a, B, C, N, H, W, s);
+    if (h == hipSuccess) h = launch_pool(precision, mode, k, a, b, B, N, H, W, C, s);
+    if (h == hipSuccess) h = launch_to_ncdhw(precision, b, y, B, C, N, H / k, W / k, s);
+    if (h == hipSuccess) h = hipStreamSynchronize(s);
+    if (h != hipSuccess) rc = fail(DFFW_EHIP, "pool: %s", hipGetErrorString(h));
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return rc;
+}
+
+int dffw_op_regress(int device, const float *score, int B, int N, int h, int w, int H, int W, const float *focus_dists,
+                    const int64_t fd_strides[4], float *depth, void *hip_stream) {
+    if (!score || !focus_dists || !fd_strides || !depth) return fail(DFFW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(launch_regress(score, B, N, h, w, H, W, focus_dists, fd_strides[0], fd_strides[1], fd_strides[2], fd_strides[3], depth, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return DFFW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Internal declarations shared by the graph executor (dffw_engine.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dffw {
+
+// ---- activation storage ---------------------------------------------------------------------
+// Every intermediate volume lives in HBM channels-last, one "pixel" (b, slice, y, x) at a time:
+//     act[pixel][part][channel]   16-bit elements, part in {hi, lo} for split-bf16, {hi} otherwise
+// so the C channels that form the contraction axis of the next conv are contiguous (16-byte
+// MFMA operand loads) and one pixel of an 8-channel split-bf16 volume is a single 32-byte line.
+struct Act {
+    uint16_t *p = nullptr;
+    int B = 0, N = 0, H = 0, W = 0, C = 0;
+    int64_t pixels() const { return (int64_t)B * N * H * W; }
+};
+
+enum Prec { P_BF16X3 = 0, P_FP16 = 1, P_BF16 = 2 };
+inline int prec_parts(int prec) { return prec == P_BF16X3 ? 2 : 1; }
+
+// One entry per group of 8 contraction indices (8 consecutive input channels of one filter tap).
+struct TapEntry {
+    int dz, dy, dx;  // input offset of the tap relative to the (strided) output coordinate
+    int coff;        // first channel of the group inside the (virtually concatenated) input
+};
+static_assert(sizeof(TapEntry) == 16, "TapEntry must be 16 bytes");
+
+#define DFFW_TAP_INVALID (1 << 20)
+
+struct ConvArgs {
+    const uint16_t *in0, *in1;  // in1: second half of a virtual channel concat (C1 = 0: none)
+    int C0, C1;
+    int B, Ni, Hi, Wi;          // input volume
+    int Ng, Hg, Wg;             // logical grid whose points are the GEMM columns (B*Ng*Hg*Wg of them)
+    int sy, sx;                 // input row/col = grid row/col * s + tap offset
+    int No, Ho, Wo;             // output volume
+    int osy, osx, ooy, oox;     // output row/col = grid row/col * os + oo (sub-pixel phases of convT)
+    int Cout, KC;               // KC = number of 32-deep contraction chunks
+    const TapEntry *tab;        // [KC*4]
+    const uint16_t *wpk;        // weights in MFMA fragment order [KC][NT][part][64 lanes][8]
+    const float *bias;          // [NT*16] folded BatchNorm shift (zero padded)
+    const uint16_t *res0, *res1;// residual volumes in the output's geometry, or null
+    uint16_t *out;              // output volume, or null
+    uint16_t *out_pre;          // optional second output: value before the residual add
+    float *outf;                // fp32 score volume (B,No,Ho,Wo) for Cout == 1 layers, or null
+    int relu;                   // 0: none   1: relu(acc+res)   2: relu(acc)+res
+    int64_t M;                  // B*Ng*Hg*Wg
+};
+
+// launchers (dffw_kernels.hip)
+int conv_nt_for(int cout);  // 16-channel output tiles the conv kernel picked for `cout` iterates over
+hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s);
+hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int N, int H, int W, hipStream_t s);
+hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s);
+hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C, int N, int H, int W, hipStream_t s);
+hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *out, int B, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd,
+                          int64_t fsb, int64_t fsn, int64_t fsh, int64_t fsw, float *depth, hipStream_t s);
+
+}  // namespace dffw

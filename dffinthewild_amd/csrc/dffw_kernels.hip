@@ -1,0 +1,454 @@
+// gfx950 (MI355X, CDNA4) kernels of the depth-from-focus engine.  wave = 64 lanes everywhere.
+//
+//  conv_igemm    implicit-GEMM convolution on the matrix cores (v_mfma_f32_16x16x32_{bf16,f16}):
+//                D[cout][pixel] += W[cout][k] * X[k][pixel], k = (filter tap, input channel).
+//                Covers every conv of DFF_net (1x9x9 dilated, 1x3x3, 3x1x1, 1x1x1, 3x3x3 at stride
+//                1 and (1,2,2), and the 4 sub-pixel phases of the transposed 3x3x3) through a tap
+//                table; BatchNorm shift, up to two residual adds and ReLU are fused in the epilogue.
+//  pool          (1,k,k) max / average pooling on channels-last volumes.
+//  stack_in      focal stack (B,3,N,H,W) fp32 planar -> channels-last 8-channel volume.
+//  regress       bilinear resize + softplus normalisation + focus-distance expectation.
+#include "dffw_internal.h"
+
+namespace dffw {
+
+typedef __attribute__((ext_vector_type(8))) short short8;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- 16-bit number formats ---------------------------------------------------------------------
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even (finite inputs)
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f2h(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float h2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+template <int PREC>
+struct Fmt {
+    static constexpr int PARTS = (PREC == P_BF16X3) ? 2 : 1;
+    // value of channel c of a pixel whose storage starts at p (layout [part][C])
+    static __device__ __forceinline__ float load(const uint16_t *p, int C, int c) {
+        if constexpr (PREC == P_BF16X3) return bf2f(p[c]) + bf2f(p[C + c]);
+        else if constexpr (PREC == P_FP16) return h2f(p[c]);
+        else return bf2f(p[c]);
+    }
+    static __device__ __forceinline__ void split(float v, uint16_t &hi, uint16_t &lo) {
+        if constexpr (PREC == P_BF16X3) {
+            hi = f2bf(v);
+            lo = f2bf(v - bf2f(hi));
+        } else if constexpr (PREC == P_FP16) {
+            hi = f2h(v);
+            lo = 0;
+        } else {
+            hi = f2bf(v);
+            lo = 0;
+        }
+    }
+    static __device__ __forceinline__ float join(uint16_t hi, uint16_t lo) {
+        if constexpr (PREC == P_BF16X3) return bf2f(hi) + bf2f(lo);
+        else if constexpr (PREC == P_FP16) return h2f(hi);
+        else return bf2f(hi);
+    }
+    static __device__ __forceinline__ void store(uint16_t *p, int C, int c, float v) {
+        uint16_t hi, lo;
+        split(v, hi, lo);
+        p[c] = hi;
+        if constexpr (PARTS == 2) p[C + c] = lo;
+    }
+};
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mma(short8 a, short8 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ---- implicit-GEMM convolution -----------------------------------------------------------------
+// Workgroup = 4 waves; each wave owns MT*16 consecutive grid points (GEMM columns) and all
+// NT*16 output channels (GEMM rows).  Operand fragments for v_mfma_f32_16x16x32: lane l supplies
+// row/column (l & 15) and the 8 contraction indices of group (l >> 4); the result registers hold
+// D[cout = (l>>4)*4 + i][pixel = l & 15], i.e. 4 consecutive channels of one pixel per lane, which
+// is exactly an 8-byte channels-last store.
+template <int PREC, int NT, int MT>
+__global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int64_t pos0 = ((int64_t)blockIdx.x * 4 + wave) * (MT * 16);
+    if (pos0 >= a.M) return;
+
+    const int ps0 = PARTS * a.C0, ps1 = PARTS * a.C1;  // pixel stride in elements
+    const int64_t samp0 = (int64_t)a.Ni * a.Hi * a.Wi * ps0;
+    const int64_t samp1 = (int64_t)a.Ni * a.Hi * a.Wi * ps1;
+
+    int pn[MT], py[MT], px[MT], pbase[MT];
+    bool pv[MT];
+    int64_t opix[MT];
+    const uint16_t *s0[MT];
+    const uint16_t *s1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t p = pos0 + mt * 16 + r;
+        pv[mt] = p < a.M;
+        const int64_t pp = pv[mt] ? p : 0;
+        const int x = (int)(pp % a.Wg);
+        int64_t t = pp / a.Wg;
+        const int y = (int)(t % a.Hg);
+        t /= a.Hg;
+        const int n = (int)(t % a.Ng);
+        const int b = (int)(t / a.Ng);
+        pn[mt] = n;
+        py[mt] = y * a.sy;
+        px[mt] = x * a.sx;
+        pbase[mt] = (n * a.Hi + py[mt]) * a.Wi + px[mt];
+        s0[mt] = a.in0 + b * samp0;
+        s1[mt] = a.in1 + b * samp1;
+        opix[mt] = (((int64_t)b * a.No + n) * a.Ho + (y * a.osy + a.ooy)) * a.Wo + (x * a.osx + a.oox);
+    }
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const short8 *wbase = reinterpret_cast<const short8 *>(a.wpk) + lane;
+    const short8 zero8 = short8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int kc = 0; kc < a.KC; ++kc) {
+        const TapEntry te = a.tab[kc * 4 + g];
+        const bool tvalid = te.coff >= 0;
+        const bool second = te.coff >= a.C0;
+        const int cc = tvalid ? (second ? te.coff - a.C0 : te.coff) : 0;
+        const int ps = second ? ps1 : ps0;
+        const int csrc = second ? a.C1 : a.C0;
+        const int delta = (te.dz * a.Hi + te.dy) * a.Wi + te.dx;
+
+        short8 wf[NT][PARTS];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt)
+                wf[nt][pt] = wbase[((int64_t)kc * NT * PARTS + nt * PARTS + pt) * 64];
+
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int iz = pn[mt] + te.dz, iy = py[mt] + te.dy, ix = px[mt] + te.dx;
+            const bool ok = pv[mt] && tvalid && (unsigned)iz < (unsigned)a.Ni && (unsigned)iy < (unsigned)a.Hi &&
+                            (unsigned)ix < (unsigned)a.Wi;
+            const uint16_t *src = (second ? s1[mt] : s0[mt]) + ((int64_t)(pbase[mt] + delta) * ps + cc);
+            short8 xh = zero8, xl = zero8;
+            if (ok) {
+                xh = *reinterpret_cast<const short8 *>(src);
+                if constexpr (PARTS == 2) xl = *reinterpret_cast<const short8 *>(src + csrc);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (PARTS == 2) {
+                    acc[nt][mt] = mma<F16>(wf[nt][1], xh, acc[nt][mt]);  // w_lo * x_hi
+                    acc[nt][mt] = mma<F16>(wf[nt][0], xl, acc[nt][mt]);  // w_hi * x_lo
+                }
+                acc[nt][mt] = mma<F16>(wf[nt][0], xh, acc[nt][mt]);      // w_hi * x_hi
+            }
+        }
+    }
+
+    // ---- epilogue: BatchNorm shift, residuals, ReLU, split to storage format ---------------------
+    const int Cout = a.Cout;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (!pv[mt]) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c0 = nt * 16 + g * 4;
+            if (c0 >= Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][i] + a.bias[c0 + i];
+            if (a.outf) {  // 1-channel score volume, fp32, layout (B,No,Ho,Wo)
+                if (c0 == 0) a.outf[opix[mt]] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
+                continue;
+            }
+            const int64_t eo = opix[mt] * (PARTS * Cout) + c0;
+            if (a.out_pre) {
+                short4v h, l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint16_t hi, lo;
+                    Fmt<PREC>::split(v[i], hi, lo);
+                    h[i] = (short)hi;
+                    l[i] = (short)lo;
+                }
+                *reinterpret_cast<short4v *>(a.out_pre + eo) = h;
+                if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out_pre + eo + Cout) = l;
+            }
+            if (a.relu == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            if (a.res0) {
+                const short4v h = *reinterpret_cast<const short4v *>(a.res0 + eo);
+                short4v l = short4v{0, 0, 0, 0};
+                if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res0 + eo + Cout);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
+            }
+            if (a.res1) {
+                const short4v h = *reinterpret_cast<const short4v *>(a.res1 + eo);
+                short4v l = short4v{0, 0, 0, 0};
+                if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res1 + eo + Cout);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
+            }
+            if (a.relu == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            short4v h, l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint16_t hi, lo;
+                Fmt<PREC>::split(v[i], hi, lo);
+                h[i] = (short)hi;
+                l[i] = (short)lo;
+            }
+            *reinterpret_cast<short4v *>(a.out + eo) = h;
+            if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out + eo + Cout) = l;
+        }
+    }
+}
+
+template <int PREC, int NT, int MT>
+static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
+    const int64_t per_wg = 4 * MT * 16;
+    const int64_t grid = (a.M + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL((conv_igemm<PREC, NT, MT>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int PREC>
+static hipError_t launch_conv_p(const ConvArgs &a, hipStream_t s) {
+    const int nt = (a.Cout + 15) / 16;
+    if (nt <= 1) return launch_conv_t<PREC, 1, 4>(a, s);
+    if (nt <= 2) return launch_conv_t<PREC, 2, 4>(a, s);
+    if (nt <= 4) return launch_conv_t<PREC, 4, 4>(a, s);
+    if (nt <= 8) return launch_conv_t<PREC, 8, 2>(a, s);
+    return hipErrorInvalidValue;
+}
+
+// number of 16-channel output tiles the kernel chosen for `cout` iterates over (weights are packed for it)
+int conv_nt_for(int cout) {
+    const int nt = (cout + 15) / 16;
+    return nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : 8;
+}
+
+hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s) {
+    switch (prec) {
+        case P_BF16X3: return launch_conv_p<P_BF16X3>(a, s);
+        case P_FP16: return launch_conv_p<P_FP16>(a, s);
+        case P_BF16: return launch_conv_p<P_BF16>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- layout conversion -------------------------------------------------------------------------
+// focal stack (B,3,N,H,W) fp32 -> [pixel][part][8] with channels 3..7 zero (the stem conv contracts
+// over 8-channel groups; the packed stem weights are zero there).
+template <int PREC>
+__global__ __launch_bounds__(256) void stack_in_kernel(const float *__restrict__ FS, uint16_t *__restrict__ out, int B,
+                                                       int N, int H, int W) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int64_t plane = (int64_t)N * H * W;
+    const int64_t total = (int64_t)B * plane;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / plane, q = i - b * plane;
+        const float *src = FS + b * 3 * plane + q;
+        short8 h = short8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint16_t hi, lo;
+            Fmt<PREC>::split(src[c * plane], hi, lo);
+            h[c] = (short)hi;
+            l[c] = (short)lo;
+        }
+        short8 *dst = reinterpret_cast<short8 *>(out + i * (PARTS * 8));
+        dst[0] = h;
+        if constexpr (PARTS == 2) dst[1] = l;
+    }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void from_ncdhw_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int B,
+                                                         int C, int64_t plane) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int64_t total = (int64_t)B * plane * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int64_t b = pix / plane, q = pix - b * plane;
+        Fmt<PREC>::store(out + pix * (PARTS * C), C, c, x[(b * C + c) * plane + q]);
+    }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void to_ncdhw_kernel(const uint16_t *__restrict__ x, float *__restrict__ out, int B,
+                                                       int C, int64_t plane) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int64_t total = (int64_t)B * plane * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i % plane;
+        const int64_t t = i / plane;
+        const int c = (int)(t % C);
+        const int64_t b = t / C;
+        out[i] = Fmt<PREC>::load(x + (b * plane + q) * (PARTS * C), C, c);
+    }
+}
+
+static inline unsigned grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+#define DFFW_PREC_SWITCH(prec, CALL)                    \
+    switch (prec) {                                     \
+        case P_BF16X3: { constexpr int PR = P_BF16X3; CALL; break; } \
+        case P_FP16: { constexpr int PR = P_FP16; CALL; break; }     \
+        case P_BF16: { constexpr int PR = P_BF16; CALL; break; }     \
+        default: return hipErrorInvalidValue;           \
+    }
+
+hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int N, int H, int W, hipStream_t s) {
+    const int64_t total = (int64_t)B * N * H * W;
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((stack_in_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, FS, out, B, N, H, W));
+    return hipGetLastError();
+}
+
+hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s) {
+    const int64_t plane = (int64_t)N * H * W;
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((from_ncdhw_kernel<PR>), dim3(grid_for(B * plane * C)), dim3(256), 0, s, x, out, B, C, plane));
+    return hipGetLastError();
+}
+
+hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C, int N, int H, int W, hipStream_t s) {
+    const int64_t plane = (int64_t)N * H * W;
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((to_ncdhw_kernel<PR>), dim3(grid_for(B * plane * C)), dim3(256), 0, s, x, out, B, C, plane));
+    return hipGetLastError();
+}
+
+// ---- pooling -----------------------------------------------------------------------------------
+// One thread per (output pixel, 8-channel group): 16-byte loads per part, fp32 reduce, re-split.
+template <int PREC>
+__global__ __launch_bounds__(256) void pool_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ out, int B, int N,
+                                                   int H, int W, int C, int k, int mode) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int Ho = H / k, Wo = W / k, C8 = C / 8;
+    const int64_t total = (int64_t)B * N * Ho * Wo * C8;
+    const float inv = 1.0f / (float)(k * k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        int64_t t = i / C8;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int64_t bn = t / Ho;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = mode == 0 ? -INFINITY : 0.f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                const int64_t pix = (bn * H + (oy * k + dy)) * W + (ox * k + dx);
+                const uint16_t *p = x + pix * (PARTS * C) + c8 * 8;
+                const short8 h = *reinterpret_cast<const short8 *>(p);
+                short8 l = short8{0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (PARTS == 2) l = *reinterpret_cast<const short8 *>(p + C);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = Fmt<PREC>::join((uint16_t)h[j], (uint16_t)l[j]);
+                    v[j] = mode == 0 ? fmaxf(v[j], f) : v[j] + f;
+                }
+            }
+        short8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint16_t hi, lo;
+            Fmt<PREC>::split(mode == 0 ? v[j] : v[j] * inv, hi, lo);
+            h[j] = (short)hi;
+            l[j] = (short)lo;
+        }
+        uint16_t *q = out + ((bn * Ho + oy) * Wo + ox) * (int64_t)(PARTS * C) + c8 * 8;
+        *reinterpret_cast<short8 *>(q) = h;
+        if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(q + C) = l;
+    }
+}
+
+hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *out, int B, int N, int H, int W, int C,
+                       hipStream_t s) {
+    if (C % 8 || H % k || W % k) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * N * (H / k) * (W / k) * (C / 8);
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((pool_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, x, out, B, N, H, W, C, k, mode));
+    return hipGetLastError();
+}
+
+// ---- depth regression --------------------------------------------------------------------------
+// One thread per output pixel; the N <= ~15 per-slice scores of a pixel are consumed in a register
+// loop (for fixed slice n consecutive lanes read consecutive x: coalesced), so the soft-argmin
+// over focus slices needs no cross-lane traffic at all.
+//   s_n   = bilinear(score[b,n], y, x)             (align_corners=False, PyTorch's index rule)
+//   p_n   = softplus(s_n) + 1e-6                   (beta 1, threshold 20)
+//   depth = sum_n fd_n p_n / sum_n p_n             (DEN.py:88-90)
+__global__ __launch_bounds__(256) void regress_kernel(const float *__restrict__ score, int B, int N, int h, int w, int H,
+                                                      int W, const float *__restrict__ fd, int64_t fsb, int64_t fsn,
+                                                      int64_t fsh, int64_t fsw, float *__restrict__ depth) {
+    const int64_t total = (int64_t)B * H * W;
+    const float sch = (float)h / (float)H, scw = (float)w / (float)W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W);
+        const int64_t t = i / W;
+        const int Y = (int)(t % H);
+        const int64_t b = t / H;
+        float sy = ((float)Y + 0.5f) * sch - 0.5f;
+        float sx = ((float)X + 0.5f) * scw - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float *sp = score + b * N * (int64_t)h * w;
+        const float *fp = fd + b * fsb + Y * fsh + X * fsw;
+        float num = 0.f, den = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float *pl = sp + (int64_t)n * h * w;
+            const float v = hy * (hx * pl[y0 * w + x0] + lx * pl[y0 * w + x1]) +
+                            ly * (hx * pl[y1 * w + x0] + lx * pl[y1 * w + x1]);
+            const float p = (v > 20.f ? v : log1pf(expf(v))) + 1e-6f;
+            den += p;
+            num += fp[n * fsn] * p;
+        }
+        depth[i] = num / den;
+    }
+}
+
+hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd, int64_t fsb,
+                          int64_t fsn, int64_t fsh, int64_t fsw, float *depth, hipStream_t s) {
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(regress_kernel, dim3(grid_for(total)), dim3(256), 0, s, score, B, N, h, w, H, W, fd, fsb, fsn, fsh,
+                       fsw, depth);
+    return hipGetLastError();
+}
+
+}  // namespace dffw

@@ -1,0 +1,238 @@
+"""ctypes binding of ``libdffw.so`` (C ABI: ``include/dffw.h``).
+
+This is the only place Python touches the native library.  There is no CPU or PyTorch fallback:
+if the shared object is missing the import of this module raises, and every forward runs the
+hand-written gfx950 kernels.  PyTorch is used for device memory (inputs, outputs, the workspace
+come from its caching allocator) and for the current HIP stream, nothing else.
+"""
+import ctypes
+import os
+import threading
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdffw.so")
+
+PRECISIONS = {"bf16x3": 0, "fp16": 1, "bf16": 2}
+NET_DEPTH = 0
+
+
+class DffwError(RuntimeError):
+    pass
+
+
+class _Tensor(ctypes.Structure):
+    _fields_ = [("name", c_char_p), ("data", POINTER(c_float)), ("numel", c_int64)]
+
+
+class _Tap(ctypes.Structure):
+    _fields_ = [("name", c_char_p), ("dst", c_void_p), ("numel", c_int64)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise DffwError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C dffinthewild_amd/csrc). "
+            "dffinthewild_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dffw_version.restype = c_char_p
+    lib.dffw_last_error.restype = c_char_p
+    lib.dffw_param_count.argtypes = [c_int]
+    lib.dffw_param_info.argtypes = [c_int, c_int, POINTER(c_char_p), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
+    lib.dffw_engine_create.argtypes = [c_int, c_int, POINTER(_Tensor), c_int, c_int, POINTER(c_void_p)]
+    lib.dffw_engine_destroy.argtypes = [c_void_p]
+    lib.dffw_engine_destroy.restype = None
+    lib.dffw_engine_precision.argtypes = [c_void_p]
+    lib.dffw_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+    lib.dffw_workspace_bytes.restype = c_int64
+    fwd = [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_int, c_int, c_int, c_int,
+           POINTER(c_void_p), c_void_p, c_int64, c_void_p]
+    lib.dffw_forward.argtypes = fwd
+    lib.dffw_forward_taps.argtypes = fwd + [POINTER(_Tap), c_int]
+    lib.dffw_op_conv3d.argtypes = [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int,
+                                   POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int,
+                                   POINTER(c_float), POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p]
+    lib.dffw_op_pool.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.dffw_op_regress.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                    POINTER(c_int64), c_void_p, c_void_p]
+    return lib
+
+
+lib = _load()
+
+# every symbol include/dffw.h declares (tests check the library exports each one)
+ABI_SYMBOLS = (
+    "dffw_version", "dffw_last_error", "dffw_param_count", "dffw_param_info", "dffw_engine_create",
+    "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
+    "dffw_forward_taps", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
+)
+
+
+def _check(rc, what):
+    if rc < 0:
+        msg = lib.dffw_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise DffwError(f"{what} failed ({rc}): {msg}")
+    return rc
+
+
+def param_table(net=NET_DEPTH):
+    """The library's view of the weight contract: list of (key, shape, flags)."""
+    n = _check(lib.dffw_param_count(net), "dffw_param_count")
+    out = []
+    for i in range(n):
+        name, shape, ndim, flags = c_char_p(), (c_int64 * 5)(), c_int(), c_int()
+        _check(lib.dffw_param_info(net, i, byref(name), shape, byref(ndim), byref(flags)), "dffw_param_info")
+        out.append((name.value.decode(), tuple(shape[:ndim.value]), flags.value))
+    return out
+
+
+def _stream_ptr(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32(t):
+    return ctypes.cast(t.data_ptr(), POINTER(c_float))
+
+
+class Engine:
+    """Owns one ``dffw_engine`` (packed weights on one GPU).  Thread-compatible: calls on engines
+    of different devices may run concurrently (ctypes releases the GIL)."""
+
+    def __init__(self, state_dict, device, precision="bf16x3", net=NET_DEPTH):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise DffwError("the HIP engine needs a GPU device (no CPU fallback)")
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.precision = precision
+        keep, arr = [], (_Tensor * len(state_dict))()
+        i = 0
+        for key, t in state_dict.items():
+            if not torch.is_floating_point(t):
+                continue  # num_batches_tracked counters carry no arithmetic
+            h = t.detach().to("cpu", torch.float32).contiguous()
+            keep.append(h)
+            arr[i] = _Tensor(key.encode(), _f32(h), h.numel())
+            i += 1
+        self._h = c_void_p()
+        _check(lib.dffw_engine_create(self.index, net, arr, i, PRECISIONS[precision], byref(self._h)), "dffw_engine_create")
+        self._ws = {}
+        self._lock = threading.Lock()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.dffw_engine_destroy(h)
+            self._h = None
+
+    def workspace_bytes(self, B, N, H, W):
+        return _check(lib.dffw_workspace_bytes(self._h, B, N, H, W), "dffw_workspace_bytes")
+
+    def _workspace(self, B, N, H, W):
+        key = (B, N, H, W)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.workspace_bytes(B, N, H, W)
+            self._ws.clear()  # one resident workspace: shapes change rarely (test.py runs one dataset per process)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, FS, focus_dists, taps=None):
+        """FS (B,3,N,H,W) float32 on this engine's device; focus_dists broadcastable to (B,N,H,W).
+        Returns (mid_out, pred1, pred2, pred3); with ``taps`` (list of names) also a dict of
+        intermediate volumes in the reference's layout."""
+        B, C, N, H, W = FS.shape
+        FS = FS.contiguous()
+        fd = focus_dists.expand(B, N, H, W)
+        strides = (c_int64 * 4)(*fd.stride())
+        outs = [torch.empty((B, H, W), dtype=torch.float32, device=FS.device) for _ in range(4)]
+        optrs = (c_void_p * 4)(*[o.data_ptr() for o in outs])
+        with self._lock, torch.cuda.device(self.index):
+            ws = self._workspace(B, N, H, W)
+            args = [self._h, c_void_p(FS.data_ptr()), c_void_p(fd.data_ptr()), strides, B, N, H, W, optrs,
+                    c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index)]
+            if not taps:
+                _check(lib.dffw_forward(*args), "dffw_forward")
+                return tuple(outs)
+            shapes = _tap_shapes(B, N, H, W)
+            bufs = {nm: torch.empty(shapes[nm], dtype=torch.float32, device=FS.device) for nm in taps}
+            tarr = (_Tap * len(bufs))(*[_Tap(nm.encode(), c_void_p(t.data_ptr()), t.numel()) for nm, t in bufs.items()])
+            _check(lib.dffw_forward_taps(*args, tarr, len(bufs)), "dffw_forward_taps")
+            return tuple(outs), bufs
+
+
+def _tap_shapes(B, N, H, W):
+    return {
+        "V1": (B, 8, N, H, W), "V2": (B, 16, N, H // 2, W // 2), "V3": (B, 32, N, H // 4, W // 4),
+        "FS_volume": (B, 32, N, H // 8, W // 8), "conf": (B, N, H // 8, W // 8),
+        "cost1": (B, N, H // 4, W // 4), "cost2": (B, N, H // 2, W // 2), "cost3": (B, N, H, W),
+    }
+
+
+# ---- single-operator wrappers (used by the kernel parity tests) ----------------------------------
+def _i3(v):
+    v = (v, v, v) if isinstance(v, int) else tuple(v)
+    return (c_int * 3)(*v)
+
+
+def op_conv3d(x, weight, *, stride=1, pad=0, dilation=1, transposed=False, bn=None, bias=None,
+              residual=None, relu=0, precision="bf16x3"):
+    """y = [relu](BN(conv(x)) [+ residual]) through the MFMA implicit-GEMM kernel.  ``x`` (B,C,N,H,W)
+    float32 on the GPU; ``weight`` CPU/GPU float32 in PyTorch layout; ``bn`` = (gamma, beta, mean, var)."""
+    B, Cin, N, H, W = x.shape
+    w = weight.detach().to("cpu", torch.float32).contiguous()
+    Cout = w.shape[1] if transposed else w.shape[0]
+    k = tuple(w.shape[2:])
+    s, p, d = _i3(stride), _i3(pad), _i3(dilation)
+    if transposed:
+        No, Ho, Wo = N, 2 * H, 2 * W
+    else:
+        No = N + 2 * p[0] - (k[0] - 1)
+        Ho = (H + 2 * p[1] - d[1] * (k[1] - 1) - 1) // s[1] + 1
+        Wo = (W + 2 * p[2] - d[2] * (k[2] - 1) - 1) // s[2] + 1
+    bnh = None
+    if bn is not None:
+        bnh = torch.cat([t.detach().to("cpu", torch.float32).reshape(-1) for t in bn]).contiguous()
+    bh = bias.detach().to("cpu", torch.float32).contiguous() if bias is not None else None
+    y = torch.empty((B, No, Ho, Wo) if Cout == 1 else (B, Cout, No, Ho, Wo), dtype=torch.float32, device=x.device)
+    x = x.contiguous()
+    res = residual.contiguous() if residual is not None else None
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(dev):
+        _check(lib.dffw_op_conv3d(dev, PRECISIONS[precision], c_void_p(x.data_ptr()), B, Cin, N, H, W, _f32(w), Cout,
+                                  (c_int * 3)(*k), s, p, d, int(transposed),
+                                  _f32(bnh) if bnh is not None else None, _f32(bh) if bh is not None else None,
+                                  c_void_p(res.data_ptr()) if res is not None else None, relu,
+                                  c_void_p(y.data_ptr()), _stream_ptr(dev)), "dffw_op_conv3d")
+    return y
+
+
+def op_pool(x, k, mode="max", precision="bf16x3"):
+    B, C, N, H, W = x.shape
+    y = torch.empty((B, C, N, H // k, W // k), dtype=torch.float32, device=x.device)
+    x = x.contiguous()
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(dev):
+        _check(lib.dffw_op_pool(dev, PRECISIONS[precision], 0 if mode == "max" else 1, k, c_void_p(x.data_ptr()),
+                                B, C, N, H, W, c_void_p(y.data_ptr()), _stream_ptr(dev)), "dffw_op_pool")
+    return y
+
+
+def op_regress(score, focus_dists, H, W):
+    B, N, h, w = score.shape
+    score = score.contiguous()
+    fd = focus_dists.expand(B, N, H, W)
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=score.device)
+    dev = score.device.index if score.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(dev):
+        _check(lib.dffw_op_regress(dev, c_void_p(score.data_ptr()), B, N, h, w, H, W, c_void_p(fd.data_ptr()),
+                                   (c_int64 * 4)(*fd.stride()), c_void_p(depth.data_ptr()), _stream_ptr(dev)),
+               "dffw_op_regress")
+    return depth

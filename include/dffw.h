@@ -1,0 +1,126 @@
+/* dffw.h — C ABI of the MI355X (gfx950) depth-from-focus engine, libdffw.so.
+ *
+ * The reference (wcy199705/DfFintheWild) has no FFI/plugin layer: its boundary is the Python
+ * nn.Module call `Network()(FS, focus_dists)` (Depth_Estimation_Test/test.py:30,118,
+ * Depth_Estimation_Test/Depth_Estimation_Network.py:7-13) whose arithmetic runs inside PyTorch
+ * operators.  This header is what a binding for that call binds instead: plain pointers and
+ * sizes, no torch types.  dffinthewild_amd/engine.py is the ctypes stub.
+ *
+ * Conventions: every function returns 0 on success or a negative DFFW_E* code; the message is
+ * available from dffw_last_error() (thread-local).  No C++ exception crosses this boundary.
+ * "device" pointers are HIP device memory on the engine's device; "host" pointers are ordinary
+ * memory.  All launches are enqueue-only on the caller's HIP stream (no implicit sync), so
+ * timing around a call behaves like the reference's asynchronous model() call (test.py:117-119).
+ */
+#ifndef DFFW_H
+#define DFFW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFFW_OK 0
+#define DFFW_EINVAL (-1)  /* bad argument / shape contract violated */
+#define DFFW_EHIP (-2)    /* a HIP runtime call failed */
+#define DFFW_ENOMEM (-3)  /* workspace too small */
+#define DFFW_EMISSING (-4)/* a required state-dict tensor was not supplied */
+
+/* Arithmetic of the conv contractions (accumulation is always fp32 in the MFMA). */
+#define DFFW_PREC_BF16X3 0 /* split-bf16: x = hi+lo, 3 MFMA products hi*hi+hi*lo+lo*hi (default; ~1e-5 rel-L2) */
+#define DFFW_PREC_FP16 1   /* single fp16 product (~1e-3 rel-L2, weight dependent) */
+#define DFFW_PREC_BF16 2   /* single bf16 product (~5e-3..1e-2 rel-L2; does not meet the 1e-3 target) */
+
+/* Which network of the reference an engine implements. */
+#define DFFW_NET_DEPTH 0 /* Depth_Estimation_Network.Network  (DEN.py:7-13)  */
+
+typedef struct dffw_engine dffw_engine;
+
+/* One state-dict entry handed to the engine: the reference's key (an optional leading "module."
+ * is accepted, test.py:32,78 vs train_code_Defocus.py:66), host fp32 data in PyTorch layout
+ * (Conv3d (Cout,Cin,kd,kh,kw); ConvTranspose3d (Cin,Cout,kd,kh,kw); BatchNorm vectors). */
+typedef struct dffw_tensor {
+    const char *name;
+    const float *data;
+    int64_t numel;
+} dffw_tensor;
+
+/* Optional debug tap: after the forward, the named intermediate volume is written to `dst`
+ * (device, fp32, reference layout (B,C,N,h,w), or (B,N,h,w) for the 1-channel score volumes).
+ * Names: V1 V2 V3 FS_volume conf cost1 cost2 cost3. */
+typedef struct dffw_tap {
+    const char *name;
+    float *dst;
+    int64_t numel;
+} dffw_tap;
+
+const char *dffw_version(void);
+const char *dffw_last_error(void);
+
+/* The weight contract (replaces nn.Module.state_dict() of DEN.py:7-57): number of state-dict
+ * entries of network `net`, and entry `index` in the reference's registration order.
+ * flags bit0: buffer (BatchNorm running stats) rather than parameter; bit1: int64
+ * num_batches_tracked scalar; bit2: dead (present in checkpoints, never read by forward). */
+int dffw_param_count(int net);
+int dffw_param_info(int net, int index, const char **name, int64_t shape[5], int *ndim, int *flags);
+
+/* Replaces `Network(); model.load_state_dict(...); model.cuda()` (test.py:30,78,80): folds
+ * BatchNorm into the convs, packs weights into MFMA fragment order for `precision` and uploads
+ * them to `device`.  The engine owns only that packed copy. */
+int dffw_engine_create(int device, int net, const dffw_tensor *tensors, int n_tensors,
+                       int precision, dffw_engine **out);
+void dffw_engine_destroy(dffw_engine *e);
+int dffw_engine_precision(const dffw_engine *e);
+
+/* Bytes of scratch dffw_forward needs for one (B,N,H,W) call; the caller allocates it (torch's
+ * caching allocator in the Python binding) so nothing is hipMalloc'ed per call. */
+int64_t dffw_workspace_bytes(const dffw_engine *e, int B, int N, int H, int W);
+
+/* Replaces `mid, p1, p2, p3 = model(FS, focus_dists)` (test.py:118; DFF_net.forward DEN.py:74-127).
+ *   FS            device fp32, contiguous (B,3,N,H,W) — channel BEFORE slice (test_Dataloader.py:39)
+ *   focus_dists   device fp32, element strides fd_strides[4] over (B,N,H,W); stride 0 = broadcast
+ *                 ((B,N,1,1) of End_to_End/Test_dataloader.py:52-54, or dense (B,N,H,W))
+ *   out[4]        device fp32 (B,H,W) each: mid_out, pred1, pred2, pred3 (DEN.py:127); entries may
+ *                 be NULL to skip storing that map
+ *   H, W          multiples of 32 (else DFFW_EINVAL, as the reference fails in torch.cat / pooling)
+ */
+int dffw_forward(dffw_engine *e, const float *FS, const float *focus_dists,
+                 const int64_t fd_strides[4], int B, int N, int H, int W, float *const out[4],
+                 void *workspace, int64_t workspace_bytes, void *hip_stream);
+
+/* Same, additionally exporting intermediate volumes for parity debugging. */
+int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists,
+                      const int64_t fd_strides[4], int B, int N, int H, int W, float *const out[4],
+                      void *workspace, int64_t workspace_bytes, void *hip_stream,
+                      const dffw_tap *taps, int n_taps);
+
+/* ---- single-operator entry points (parity tests of each kernel family; they allocate their own
+ * temporaries with hipMalloc and synchronise the stream before returning) -------------------- */
+
+/* y = [relu]( BN(conv(x)) [+ residual] ) in the engine's arithmetic.  Replaces nn.Conv3d /
+ * nn.ConvTranspose3d (+ nn.BatchNorm3d, DEN.py:286-289).  x, residual, y: device fp32 in the
+ * reference layout (B,C,N,H,W).  weight: host fp32, PyTorch layout.  bn: host fp32 4*Cout
+ * values gamma|beta|mean|var, or NULL.  conv_bias: host fp32 Cout or NULL.  For transposed != 0
+ * the geometry is fixed to the reference's only form: k3, stride (1,2,2), pad 1, output_padding
+ * (0,1,1).  relu: 0 none, 1 relu(acc+res), 2 relu(acc)+res. */
+int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, int N, int H, int W,
+                   const float *weight, int Cout, const int kernel[3], const int stride[3],
+                   const int pad[3], const int dilation[3], int transposed, const float *bn,
+                   const float *conv_bias, const float *residual, int relu, float *y,
+                   void *hip_stream);
+
+/* mode 0: max-pool (1,k,k) stride (1,k,k) (DEN.py:310); mode 1: average-pool (DEN.py:149-153). */
+int dffw_op_pool(int device, int precision, int mode, int k, const float *x, int B, int C, int N,
+                 int H, int W, float *y, void *hip_stream);
+
+/* The regression block of DEN.py:86-90: bilinear resize (align_corners=False) of score (B,N,h,w) to
+ * (H,W), softplus+1e-6, normalise over N, sum_N focus_dists*p -> depth (B,H,W).  All device fp32. */
+int dffw_op_regress(int device, const float *score, int B, int N, int h, int w, int H, int W,
+                    const float *focus_dists, const int64_t fd_strides[4], float *depth,
+                    void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFFW_H */

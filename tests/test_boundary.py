@@ -1,0 +1,99 @@
+"""CPU: the drop-in boundary — weight contract, call contract and the C ABI surface.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+from dffinthewild_amd import graph, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng(lib_built):
+    from dffinthewild_amd import engine
+    return engine
+
+
+def test_library_exports_every_declared_symbol(eng):
+    header = open(os.path.join(ROOT, "include", "dffw.h")).read()
+    declared = set(re.findall(r"\b(dffw_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(eng.ABI_SYMBOLS)
+    raw = ctypes.CDLL(eng.LIB_PATH)
+    for sym in declared:
+        assert hasattr(raw, sym), sym
+    assert b"gfx950" in eng.lib.dffw_version()
+
+
+def test_native_param_table_matches_python_table(eng):
+    native = eng.param_table()
+    rows = list(graph.param_entries(graph.dff_net_convs()))
+    assert len(native) == len(rows) == 384
+    for (nk, nshape, flags), (k, shape, role, is_buf) in zip(native, rows):
+        assert nk == k and tuple(nshape) == tuple(shape)
+        assert bool(flags & 1) == is_buf
+        assert bool(flags & 2) == (role == graph.ROLE_BN_NBT)
+    dead = [k for k, _, f in native if f & 4]
+    assert len(dead) == 24 and all(("pre_conv" in k or "redir3" in k) for k in dead)
+
+
+def test_state_dict_contract(eng):
+    from dffinthewild_amd import Network
+    m = Network()
+    sd = m.state_dict()
+    assert len(sd) == 384
+    assert sd["DFF_net.FM_measure.Focus_extraction.0.0.weight"].shape == (8, 3, 1, 9, 9)
+    assert sd["DFF_net.deconv_1.0.weight"].shape == (64, 32, 3, 3, 3)       # ConvTranspose3d (Cin,Cout,...)
+    assert sd["DFF_net.SPP_module.combine2.0.0.weight"].shape == (128, 192, 3, 3, 3)
+    assert sd["DFF_net.dres4.conv6.1.num_batches_tracked"].dtype == torch.long
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == 4_038_832
+    # synthetic state (and a DataParallel-prefixed copy) loads strictly
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    new = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries).items()}
+    m.load_state_dict(new)
+    m.load_state_dict({"module." + k: v for k, v in new.items()})
+    assert torch.equal(m.state_dict()["DFF_net.classif3.0.weight"], new["DFF_net.classif3.0.weight"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in new.items() if "classif3" not in k})
+
+
+def test_reference_call_sequence_on_cpu_fails_loudly(eng):
+    """test.py:30-32,78,85 sequence works up to the model call; the call itself needs the GPU."""
+    from dffinthewild_amd.Depth_Estimation_Network import Network
+    model = Network()
+    model = model.cpu()
+    model = nn.DataParallel(model)
+    model.module.load_state_dict(model.module.state_dict())
+    model.eval()
+    FS = torch.zeros(1, 3, 4, 32, 32)
+    fd = torch.zeros(1, 4, 32, 32)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.module(FS, fd)
+
+
+def test_shape_contract_errors(eng):
+    from dffinthewild_amd import Network
+    m = Network().eval()
+    fd = torch.zeros(1, 4, 1, 1)
+    with pytest.raises(ValueError, match="multiples of 32"):
+        m(torch.zeros(1, 3, 4, 48, 48), fd)
+    with pytest.raises(ValueError, match="3 colour channels"):
+        m(torch.zeros(1, 4, 3, 32, 32), torch.zeros(1, 3, 1, 1))       # (B,N,3,H,W) is NOT the layout
+    with pytest.raises(ValueError, match="broadcast"):
+        m(torch.zeros(1, 3, 4, 32, 32), torch.zeros(1, 5, 1, 1))
+    with pytest.raises(RuntimeError, match="eval"):
+        Network()(torch.zeros(1, 3, 4, 32, 32), fd)
+    with pytest.raises(ValueError):
+        Network(precision="fp8")
+
+
+def test_c_abi_argument_errors_without_gpu(eng):
+    lib = eng.lib
+    assert lib.dffw_param_count(7) < 0 and b"unknown net" in lib.dffw_last_error()
+    h = ctypes.c_void_p()
+    assert lib.dffw_engine_create(0, 0, None, 0, 0, ctypes.byref(h)) == -1
+    assert lib.dffw_workspace_bytes(None, 1, 1, 32, 32) < 0

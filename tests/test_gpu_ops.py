@@ -1,0 +1,126 @@
+"""GPU: each kernel family of libdffw.so, called through the C ABI, against the same PyTorch
+operator the reference invokes (computed on the CPU in fp32).  Tolerances are relative L2:
+split-bf16 5e-5 (expected ~1e-5), fp16 3e-3, bf16 2e-2."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"bf16x3": 5e-5, "fp16": 3e-3, "bf16": 2e-2}
+
+
+def rel(a, b):
+    a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def eng(lib_built):
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from dffinthewild_amd import engine
+    return engine
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def bn_params(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (0.5 + torch.rand(c, generator=g), torch.rand(c, generator=g) - 0.5,
+            torch.rand(c, generator=g) - 0.5, 0.5 + torch.rand(c, generator=g))
+
+
+def ref_bn(y, bn):
+    return F.batch_norm(y, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+
+
+# (name, Cin, Cout, kernel, stride, pad, dilation, N, H, W)  — every conv family of DFF_net
+CONV_CASES = [
+    ("stem_1x9x9_dil2", 3, 8, (1, 9, 9), (1, 1, 1), (0, 8, 8), (1, 2, 2), 3, 32, 40),
+    ("slice_1x3x3", 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), 4, 16, 24),
+    ("attn_3x1x1", 16, 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), 5, 8, 16),
+    ("point_1x1x1", 32, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), 3, 8, 8),
+    ("c3_16_8", 16, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 4, 16, 16),
+    ("c3_32_16", 32, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 3, 8, 24),
+    ("c3_64_32", 64, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 2, 8, 8),
+    ("c3_192_128", 192, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 2, 8, 8),
+    ("c3_s2_8_16", 8, 16, (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 1, 1), 3, 16, 32),
+    ("c3_s2_64_128", 64, 128, (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 1, 1), 2, 16, 16),
+    ("c3_one_slice", 8, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 1, 8, 8),
+    ("score_c3_32_1", 32, 1, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 3, 8, 8),
+    ("score_1x1x1_8_1", 8, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), 3, 16, 16),
+]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: c[0])
+def test_conv_families(eng, case, prec):
+    name, cin, cout, k, s, p, d, N, H, W = case
+    B = 2
+    x = rnd(B, cin, N, H, W, seed=1)
+    w = rnd(cout, cin, *k, seed=2, scale=(2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5 * 1.7)
+    bn = bn_params(cout, 3) if cout > 1 else None
+    ref = F.conv3d(x, w, None, s, p, d)
+    if bn:
+        ref = ref_bn(ref, bn)
+        ref = F.relu(ref)
+    got = eng.op_conv3d(x.cuda(), w, stride=s, pad=p, dilation=d, bn=bn, relu=1 if bn else 0, precision=prec)
+    if cout == 1:
+        ref = ref.squeeze(1)
+    assert got.shape == ref.shape
+    assert rel(got, ref) <= TOL[prec], (name, prec, rel(got, ref))
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16"])
+@pytest.mark.parametrize("cin,cout,N,H,W", [(16, 8, 3, 8, 8), (64, 32, 2, 8, 16), (128, 64, 2, 4, 4), (32, 32, 1, 8, 8)])
+def test_transposed_conv_phases(eng, cin, cout, N, H, W, prec):
+    """ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1) as 4 sub-pixel phases (DEN.py:41-42), + BN + residual + ReLU."""
+    B = 2
+    x = rnd(B, cin, N, H, W, seed=4)
+    w = rnd(cin, cout, 3, 3, 3, seed=5, scale=(2.0 / (cin * 27)) ** 0.5 * 3)
+    bn = bn_params(cout, 6)
+    res = rnd(B, cout, N, 2 * H, 2 * W, seed=7)
+    ref = F.relu(ref_bn(F.conv_transpose3d(x, w, None, (1, 2, 2), 1, (0, 1, 1)), bn) + res)
+    got = eng.op_conv3d(x.cuda(), w, transposed=True, stride=(1, 2, 2), pad=1, bn=bn, residual=res.cuda(), relu=1, precision=prec)
+    assert rel(got, ref) <= TOL[prec], rel(got, ref)
+
+
+def test_conv_epilogue_variants(eng):
+    """relu=2 is relu(acc)+res (the SRD attention add, DEN.py:329); relu=0 with residual is the
+    un-activated skip sum (DEN.py:96)."""
+    B, cin, cout, N, H, W = 1, 16, 16, 3, 8, 8
+    x, w, res = rnd(B, cin, N, H, W, seed=8), rnd(cout, cin, 1, 1, 1, seed=9), rnd(B, cout, N, H, W, seed=10)
+    y = F.conv3d(x, w)
+    assert rel(eng.op_conv3d(x.cuda(), w, residual=res.cuda(), relu=2), F.relu(y) + res) <= 5e-5
+    assert rel(eng.op_conv3d(x.cuda(), w, residual=res.cuda(), relu=0), y + res) <= 5e-5
+    assert rel(eng.op_conv3d(x.cuda(), w, residual=res.cuda(), relu=1), F.relu(y + res)) <= 5e-5
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16"])
+def test_pools(eng, prec):
+    x = rnd(2, 32, 3, 16, 32, seed=11)
+    assert rel(eng.op_pool(x.cuda(), 2, "max", prec), F.max_pool3d(x, (1, 2, 2), (1, 2, 2))) <= TOL[prec]
+    for k in (2, 4, 8):
+        assert rel(eng.op_pool(x.cuda(), k, "avg", prec), F.avg_pool3d(x, (1, k, k), (1, k, k))) <= TOL[prec]
+
+
+@pytest.mark.parametrize("N,h,w,scale", [(10, 8, 8, 8), (5, 8, 12, 4), (15, 16, 16, 2), (4, 32, 32, 1), (1, 8, 8, 8)])
+@pytest.mark.parametrize("layout", ["dense", "bcast"])
+def test_regression_head(eng, N, h, w, scale, layout):
+    """bilinear(align_corners=False) + softplus + normalise + expectation (DEN.py:86-90) in fp32."""
+    B, H, W = 2, h * scale, w * scale
+    score = rnd(B, N, h, w, seed=12, scale=30.0)
+    score[0, :, 0, 0] = -40.0            # all-negative pixel: the 1e-6 floor decides
+    score[1, 0, 1, 1] = 45.0             # softplus linear branch (threshold 20)
+    fd = torch.linspace(0.1, 1.5, N).reshape(1, N, 1, 1).repeat(B, 1, 1, 1)
+    fd = fd * torch.tensor([1.0, 2.0]).reshape(B, 1, 1, 1)
+    fd_in = fd.expand(B, N, H, W).contiguous() if layout == "dense" else fd
+    up = F.interpolate(score, size=[H, W], mode="bilinear", align_corners=False) if scale > 1 else score
+    p = F.softplus(up) + 1e-6
+    ref = torch.sum(fd_in * (p / p.sum(1, keepdim=True)), 1)
+    got = eng.op_regress(score.cuda(), fd_in.cuda(), H, W)
+    assert rel(got, ref) <= 2e-6, rel(got, ref)
+    assert float((got.cpu() - ref).abs().max()) <= 5e-6
