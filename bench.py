@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: focal-stacks/sec of the depth-from-focus forward on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16x3|fp16|bf16]
+
+A "step" is one pass of the hot path (DFF_net.forward, reference DEN.py:74-127, through
+libdffw.so) over one batch of synthetic 10-slice 3x256x256 focal stacks per GPU — BASELINE.json's
+config "DefocusNet-shape 10-slice 256x256 stacks, batch=32, 1xMI355X" (config 3; config 4 is the
+same per-GPU batch on 8 GPUs).  Inputs are resident in HBM before the timed region.  For N > 1 the
+driver launches one rank per GPU with torch.distributed.run; every rank processes its own 32
+stacks (weak scaling, no data-path collective) and the per-rank depth maps are collected with one
+RCCL all-gather inside the timed step.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (by summed time) of one profiled forward: algorithmic FLOPs per
+                launch / HIP-event duration per launch against the dense MFMA peak of the
+                instruction type issued (2.5 PFLOP/s bf16/f16; split-bf16 issues 3 MFMAs per
+                algorithmic product, so its ceiling is 1/3 of that)
+  cpu_baseline  the oracle (oracle/cpu_ref.py = the reference's PyTorch-CPU arithmetic, restated)
+                timed on this box's host cores on a bounded sample
+  parity        rel-L2 / RMSE of this run's pred3 for stack 0 against the oracle
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dffinthewild_amd import dist as ddist  # noqa: E402
+from dffinthewild_amd import graph, synth  # noqa: E402
+
+GFLOP_PER_STACK = 61.317          # 10x256x256, 2*MAC over the 70 convs
+PEAK_MFMA_TFLOPS = 2500.0         # dense bf16/f16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(precision, device):
+    from dffinthewild_amd.Depth_Estimation_Network import Network
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, seed=0, profile="smooth").items()}
+    model = Network(precision=precision)
+    model.load_state_dict(sd)
+    return model.to(device).eval(), sd
+
+
+def roofline_from_profile(model, FS, fd, device):
+    eng = model._engine_on(device)
+    eng.profile(True)
+    with torch.no_grad():
+        model(FS, fd)
+    torch.cuda.synchronize(device)
+    rows = eng.profile_collect()
+    eng.profile(False)
+    agg = {}
+    for kernel, layer, flops, nbytes, ms in rows:
+        a = agg.setdefault(kernel, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+        a["launches"] += 1
+        a["flops"] += flops
+        a["bytes"] += nbytes
+        a["ms"] += ms
+    total_ms = sum(a["ms"] for a in agg.values())
+    conv = {k: a for k, a in agg.items() if "conv_igemm" in k}
+    dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    conv_flops = sum(a["flops"] for a in conv.values())
+    conv_ms = sum(a["ms"] for a in conv.values())
+    roof = {
+        "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+        "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+        "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
+        "algorithmic_gb_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
+        "share_of_forward_time": round(dom["ms"] / total_ms, 3),
+        "all_conv_kernels": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                             "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                             "share_of_forward_time": round(conv_ms / total_ms, 3)},
+        "profiled_forward_ms": round(total_ms, 3), "n_launches": len(rows),
+    }
+    per_kernel = {k: {"launches": a["launches"], "ms": round(a["ms"], 3),
+                      "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["flops"] else None,
+                      "gbs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)} for k, a in sorted(agg.items())}
+    return roof, per_kernel, rows
+
+
+def cpu_baseline(sd, seconds):
+    """Oracle forward (B=1, 10x256x256) on all host cores this process may use."""
+    from oracle import cpu_ref
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    FS = torch.from_numpy(synth.focal_stack(1, 10, 256, 256, seed=1000))
+    fd = torch.from_numpy(synth.focus_dists(1, 10, 256, 256))
+    with torch.no_grad():
+        ref = cpu_ref.dff_forward(sd, FS, fd)          # warm-up, also the parity reference for stack 0
+        times = []
+        t_end = time.time() + seconds
+        while len(times) < 3 or (time.time() < t_end and len(times) < 20):
+            t0 = time.perf_counter()
+            cpu_ref.dff_forward(sd, FS, fd)
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    model_name = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    base = {"value": round(1.0 / best, 4), "unit": "stacks/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} forwards of one 10x3x256x256 stack (batch 1) after 1 warm-up, best of; "
+                      f"mean {sum(times)/len(times):.3f} s; oracle/cpu_ref.py on PyTorch-CPU fp32",
+            "cpu": model_name}
+    return base, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="stacks per GPU per step")
+    ap.add_argument("--slices", type=int, default=10)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--precision", default=os.environ.get("DFFW_PRECISION", "bf16x3"))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-layers", default=None, help="write the per-launch profile table to this file")
+    args = ap.parse_args()
+
+    rank, local_rank, world = ddist.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        ddist.init_process_group("nccl")
+
+    B, N, S = args.batch, args.slices, args.size
+    model, sd = build_model(args.precision, device)
+    FS = torch.from_numpy(synth.focal_stack(B, N, S, S, seed=1000 + rank)).to(device)
+    fd = torch.from_numpy(synth.focus_dists(B, N, S, S)).to(device)       # dense tile, as test_Dataloader.py:24
+
+    def step():
+        with torch.no_grad():
+            outs = model(FS, fd)
+            gathered = ddist.all_gather_depth(outs[3]) if world > 1 else outs[3]
+        return outs, gathered
+
+    for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs, gathered = step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stacks = world * B * args.steps
+    value = stacks / elapsed
+
+    result = None
+    if rank == 0:
+        scale = (N * S * S) / (10 * 256 * 256)
+        result = {
+            "metric": "focal-stacks/sec (10x3x256x256)", "value": round(value, 2), "unit": "stacks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA operands hi+lo, fp32 accumulate, fp32-accurate)",
+                      "fp16": "f16 (MFMA, fp32 accumulate)", "bf16": "bf16 (MFMA, fp32 accumulate)"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": f"DFF_net forward, {N}-slice 3x{S}x{S} focal stacks, batch {B} per GPU "
+                                   f"(BASELINE.json config 3{'/4' if world > 1 else ''}), dense focus_dists, "
+                                   f"synthetic weights seed 0",
+                       "batch_per_gpu": B, "global_batch": B * world, "slices": N, "height": S, "width": S,
+                       "parallelism": f"batch-sharded x{world}, RCCL all-gather of pred3" if world > 1 else "single GPU",
+                       "precision": args.precision},
+            "forward_tflops_algorithmic": round(value * GFLOP_PER_STACK * scale / 1e3, 2),
+        }
+    if rank == 0 and not args.no_roofline:
+        roof, per_kernel, rows = roofline_from_profile(model, FS, fd, device)
+        result["roofline"] = roof
+        result["kernels"] = per_kernel
+        if args.dump_layers:
+            with open(args.dump_layers, "w") as f:
+                f.write("kernel\tlayer\tgflop\talg_MB\tms\ttflops\talg_GBs\n")
+                for k, l, fl, by, ms in rows:
+                    f.write(f"{k}\t{l}\t{fl/1e9:.3f}\t{by/1e6:.2f}\t{ms:.4f}\t{fl/(ms*1e-3)/1e12 if ms else 0:.2f}\t{by/(ms*1e-3)/1e9 if ms else 0:.1f}\n")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and (N, S) == (10, 256):
+        from oracle import cpu_ref
+        base, ref = cpu_baseline(sd, args.cpu_seconds)
+        result["cpu_baseline"] = base
+        got = outs[3][0].float().cpu()
+        result["parity"] = {"rel_l2": float(f"{cpu_ref.rel_l2(got, ref[3][0]):.3e}"),
+                            "rmse": float(f"{cpu_ref.rmse(got, ref[3][0]):.3e}"),
+                            "checked": "pred3 of stack 0 of the timed batch vs oracle, gate 1e-3"}
+        result["gpu_over_cpu"] = round(value / base["value"], 1)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -216,6 +216,7 @@ struct Tap {
 
 struct Variant {      // one launch: a regular conv, or one sub-pixel phase of a transposed conv
     int KC = 0;
+    int ntaps = 0;
     int ooy = 0, oox = 0;
     TapEntry *tab = nullptr;  // device
     uint16_t *wpk = nullptr;  // device
@@ -306,6 +307,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         Variant v;
         v.ooy = phase[vi].first;
         v.oox = phase[vi].second;
+        v.ntaps = (int)taps.size();
         const int K8 = (int)taps.size() * c8n;
         v.KC = (K8 + 3) / 4;
         std::vector<TapEntry> tab(v.KC * 4);
@@ -393,10 +395,26 @@ class Arena {
 using namespace dffw;
 
 // ---- engine ------------------------------------------------------------------------------------
+struct ProfRec {
+    std::string kernel, layer;
+    double flops = 0, bytes = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
 struct dffw_engine {
     int device = 0, net = 0, prec = 0;
     std::map<std::string, PackedConv> convs;
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    void clear_recs() {
+        for (auto &r : recs) {
+            if (r.e0) (void)hipEventDestroy(r.e0);
+            if (r.e1) (void)hipEventDestroy(r.e1);
+        }
+        recs.clear();
+    }
     ~dffw_engine() {
+        clear_recs();
         for (auto &kv : convs) free_packed(kv.second);
     }
 };
@@ -451,6 +469,24 @@ struct Run {
     void check(hipError_t h, const char *what) {
         if (ok() && h != hipSuccess) err = fail(DFFW_EHIP, "%s: %s", what, hipGetErrorString(h));
     }
+    // bracket one launch with HIP events on the launch stream (profiling mode only)
+    void prof_begin(const char *kernel, const std::string &layer, double flops, double bytes) {
+        if (!e->profiling || dry || !ok()) return;
+        ProfRec pr;
+        pr.kernel = kernel;
+        pr.layer = layer;
+        pr.flops = flops;
+        pr.bytes = bytes;
+        check(hipEventCreate(&pr.e0), "hipEventCreate");
+        check(hipEventCreate(&pr.e1), "hipEventCreate");
+        if (ok()) check(hipEventRecord(pr.e0, s), "hipEventRecord");
+        e->recs.push_back(pr);
+    }
+    void prof_end() {
+        if (!e->profiling || dry || !ok() || e->recs.empty()) return;
+        check(hipEventRecord(e->recs.back().e1, s), "hipEventRecord");
+    }
+    double elem_bytes() const { return 2.0 * prec_parts(e->prec); }
 
     Act conv(const std::string &name, const Act &in0, const ConvOpt &o = ConvOpt()) {
         Act out;
@@ -514,14 +550,32 @@ struct Run {
                 a.ooy = a.oox = 0;
             }
             a.M = (int64_t)a.B * a.Ng * a.Hg * a.Wg;
+            if (e->profiling) {
+                char kn[64];
+                conv_kernel_name(e->prec, L.cout, kn, sizeof kn);
+                const double nv = (double)pc.variants.size();
+                const double opx = (double)a.M;  // output pixels written by this launch
+                double bytes = (double)in0.pixels() * L.cin * elem_bytes() / nv   // input volume read once per layer
+                               + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
+                               + opx * L.cout * elem_bytes() * ((o.res0 ? 1 : 0) + (o.res1 ? 1 : 0))
+                               + (double)v.ntaps * L.cin * L.cout * elem_bytes();
+                prof_begin(kn, name, 2.0 * (double)a.M * v.ntaps * L.cin * L.cout, bytes);
+            }
             check(launch_conv(e->prec, a, s), name.c_str());
+            prof_end();
         }
         return out;
     }
 
     Act pool(const Act &x, int mode, int k) {
         Act out = act(x.B, x.N, x.H / k, x.W / k, x.C);
-        if (ok() && !dry) check(launch_pool(e->prec, mode, k, x.p, out.p, x.B, x.N, x.H, x.W, x.C, s), "pool");
+        if (ok() && !dry) {
+            char kn[48];
+            snprintf(kn, sizeof kn, "dffw::pool_kernel<%d>", e->prec);
+            prof_begin(kn, mode == 0 ? "maxpool" : "avgpool", 0.0, (double)(x.pixels() + out.pixels()) * x.C * elem_bytes());
+            check(launch_pool(e->prec, mode, k, x.p, out.p, x.B, x.N, x.H, x.W, x.C, s), "pool");
+            prof_end();
+        }
         return out;
     }
 
@@ -652,6 +706,14 @@ static Act hourglass(Run &r, const std::string &p, const Act &xa, const Act &xb,
     return sum;
 }
 
+static void regress(Run &r, const char *tag, const float *score, int B, int N, int h, int w, int H, int W, const float *fd,
+                    const int64_t fst[4], float *out) {
+    if (!r.ok() || r.dry || !out) return;
+    r.prof_begin("dffw::regress_kernel", tag, 0.0, (double)B * N * h * w * 4.0 + (double)B * H * W * 4.0);
+    r.check(launch_regress(score, B, N, h, w, H, W, fd, fst[0], fst[1], fst[2], fst[3], out, r.s), tag);
+    r.prof_end();
+}
+
 static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst[4], int B, int N, int H, int W, float *const out[4]) {
     const std::string P = "DFF_net";
     const int prec = r.e->prec;
@@ -659,7 +721,13 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
 
     // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80
     Act in = r.act(B, N, H, W, 8);
-    if (r.ok() && !r.dry) r.check(launch_stack_in(prec, FS, in.p, B, N, H, W, r.s), "stack_in");
+    if (r.ok() && !r.dry) {
+        char kn[48];
+        snprintf(kn, sizeof kn, "dffw::stack_in_kernel<%d>", prec);
+        r.prof_begin(kn, "stack_in", 0.0, (double)B * N * H * W * (3 * 4.0 + 8 * r.elem_bytes()));
+        r.check(launch_stack_in(prec, FS, in.p, B, N, H, W, r.s), "stack_in");
+        r.prof_end();
+    }
     Act stem = r.conv(P + ".FM_measure.Focus_extraction.0.0", in, rl);
     r.drop(in);
     Act v1 = srd(r, P + ".FM_measure.Focus_extraction.2", stem, true);
@@ -684,8 +752,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
         r.conv(P + ".confidence.2", c, of);
         r.drop(c);
         r.tap_f32("conf", conf, (int64_t)B * N * h8 * w8);
-        if (r.ok() && !r.dry && out[0])
-            r.check(launch_regress(conf, B, N, h8, w8, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[0], r.s), "regress0");
+        regress(r, "regress.mid_out", conf, B, N, h8, w8, H, W, fd, fst, out[0]);
         r.drop_raw(conf);
     }
 
@@ -704,8 +771,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     float *cost1 = (float *)r.raw((int64_t)B * N * h4 * w4 * sizeof(float));
     { ConvOpt of; of.outf = cost1; r.conv(P + ".classif1.0", s1, of); }
     r.tap_f32("cost1", cost1, (int64_t)B * N * h4 * w4);
-    if (r.ok() && !r.dry && out[1])
-        r.check(launch_regress(cost1, B, N, h4, w4, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[1], r.s), "regress1");
+    regress(r, "regress.pred1", cost1, B, N, h4, w4, H, W, fd, fst, out[1]);
     r.drop_raw(cost1);
 
     Act x2 = r.conv(P + ".deconv_2.0", s1);
@@ -717,8 +783,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     float *cost2 = (float *)r.raw((int64_t)B * N * h2 * w2 * sizeof(float));
     { ConvOpt of; of.outf = cost2; r.conv(P + ".classif2.0", s2, of); }
     r.tap_f32("cost2", cost2, (int64_t)B * N * h2 * w2);
-    if (r.ok() && !r.dry && out[2])
-        r.check(launch_regress(cost2, B, N, h2, w2, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[2], r.s), "regress2");
+    regress(r, "regress.pred2", cost2, B, N, h2, w2, H, W, fd, fst, out[2]);
     r.drop_raw(cost2);
 
     Act x3 = r.conv(P + ".deconv_3.0", s2);
@@ -729,8 +794,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     { ConvOpt of; of.outf = cost3; r.conv(P + ".classif3.0", s3, of); }
     r.drop(s3);
     r.tap_f32("cost3", cost3, (int64_t)B * N * H * W);
-    if (r.ok() && !r.dry && out[3])
-        r.check(launch_regress(cost3, B, N, H, W, H, W, fd, fst[0], fst[1], fst[2], fst[3], out[3], r.s), "regress3");
+    regress(r, "regress.pred3", cost3, B, N, H, W, H, W, fd, fst, out[3]);
     r.drop_raw(cost3);
     return r.err;
 }
@@ -847,6 +911,7 @@ int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists,
     if (rc) return rc;
     if (!workspace) return fail(DFFW_ENOMEM, "workspace is null");
     HIPCHK(hipSetDevice(e->device));
+    if (e->profiling) e->clear_recs();
     Run r(e, (hipStream_t)hip_stream, false, (char *)workspace, workspace_bytes);
     r.taps = taps;
     r.n_taps = taps ? n_taps : 0;
@@ -856,6 +921,33 @@ int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists,
 int dffw_forward(dffw_engine *e, const float *FS, const float *focus_dists, const int64_t fd_strides[4], int B, int N, int H,
                  int W, float *const out[4], void *workspace, int64_t workspace_bytes, void *hip_stream) {
     return dffw_forward_taps(e, FS, focus_dists, fd_strides, B, N, H, W, out, workspace, workspace_bytes, hip_stream, nullptr, 0);
+}
+
+int dffw_profile_enable(dffw_engine *e, int on) {
+    if (!e) return fail(DFFW_EINVAL, "null engine");
+    e->profiling = on != 0;
+    if (!on) e->clear_recs();
+    return DFFW_OK;
+}
+
+int dffw_profile_collect(dffw_engine *e, dffw_prof_entry *out, int capacity) {
+    if (!e) return fail(DFFW_EINVAL, "null engine");
+    const int n = (int)e->recs.size();
+    if (!out) return n;
+    for (int i = 0; i < n && i < capacity; ++i) {
+        ProfRec &r = e->recs[i];
+        float ms = 0.f;
+        if (r.e0 && r.e1) {
+            HIPCHK(hipEventSynchronize(r.e1));
+            HIPCHK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        }
+        out[i].kernel = r.kernel.c_str();
+        out[i].layer = r.layer.c_str();
+        out[i].flops = r.flops;
+        out[i].bytes = r.bytes;
+        out[i].ms = ms;
+    }
+    return n;
 }
 
 // ---- single-operator entry points --------------------------------------------------------------

@@ -51,6 +51,7 @@ struct ConvArgs {
 // launchers (dffw_kernels.hip)
 int conv_nt_for(int cout);  // 16-channel output tiles the conv kernel picked for `cout` iterates over
 hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s);
+void conv_kernel_name(int prec, int cout, char *buf, int n);  // name of the instantiation launch_conv picks
 hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int N, int H, int W, hipStream_t s);
 hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C, int N, int H, int W, hipStream_t s);

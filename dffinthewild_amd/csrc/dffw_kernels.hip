@@ -8,6 +8,8 @@
 //  pool          (1,k,k) max / average pooling on channels-last volumes.
 //  stack_in      focal stack (B,3,N,H,W) fp32 planar -> channels-last 8-channel volume.
 //  regress       bilinear resize + softplus normalisation + focus-distance expectation.
+#include <cstdio>
+
 #include "dffw_internal.h"
 
 namespace dffw {
@@ -252,6 +254,11 @@ static hipError_t launch_conv_p(const ConvArgs &a, hipStream_t s) {
 int conv_nt_for(int cout) {
     const int nt = (cout + 15) / 16;
     return nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : 8;
+}
+
+void conv_kernel_name(int prec, int cout, char *buf, int n) {
+    const int nt = conv_nt_for(cout);
+    snprintf(buf, n, "dffw::conv_igemm<%d, %d, %d>", prec, nt, nt == 8 ? 2 : 4);
 }
 
 hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s) {

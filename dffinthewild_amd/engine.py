@@ -31,6 +31,11 @@ class _Tap(ctypes.Structure):
     _fields_ = [("name", c_char_p), ("dst", c_void_p), ("numel", c_int64)]
 
 
+class _Prof(ctypes.Structure):
+    _fields_ = [("kernel", c_char_p), ("layer", c_char_p), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
+                ("ms", c_float)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise DffwError(
@@ -52,6 +57,8 @@ def _load():
            POINTER(c_void_p), c_void_p, c_int64, c_void_p]
     lib.dffw_forward.argtypes = fwd
     lib.dffw_forward_taps.argtypes = fwd + [POINTER(_Tap), c_int]
+    lib.dffw_profile_enable.argtypes = [c_void_p, c_int]
+    lib.dffw_profile_collect.argtypes = [c_void_p, POINTER(_Prof), c_int]
     lib.dffw_op_conv3d.argtypes = [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int,
                                    POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int,
                                    POINTER(c_float), POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p]
@@ -67,7 +74,7 @@ lib = _load()
 ABI_SYMBOLS = (
     "dffw_version", "dffw_last_error", "dffw_param_count", "dffw_param_info", "dffw_engine_create",
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
-    "dffw_forward_taps", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
+    "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
 )
 
 
@@ -125,11 +132,22 @@ class Engine:
         self._ws = {}
         self._lock = threading.Lock()
 
-    def __del__(self):
+    def __del__(self, _destroy=lib.dffw_engine_destroy):
         h = getattr(self, "_h", None)
         if h:
-            lib.dffw_engine_destroy(h)
+            _destroy(h)
             self._h = None
+
+    def profile(self, on=True):
+        """Bracket every kernel launch of the following forwards with HIP events (bench.py)."""
+        _check(lib.dffw_profile_enable(self._h, int(on)), "dffw_profile_enable")
+
+    def profile_collect(self):
+        """[(kernel, layer, flops, bytes, ms)] for the launches of the last profiled forward."""
+        n = _check(lib.dffw_profile_collect(self._h, None, 0), "dffw_profile_collect")
+        arr = (_Prof * n)()
+        _check(lib.dffw_profile_collect(self._h, arr, n), "dffw_profile_collect")
+        return [(e.kernel.decode(), e.layer.decode(), e.flops, e.bytes, e.ms) for e in arr]
 
     def workspace_bytes(self, B, N, H, W):
         return _check(lib.dffw_workspace_bytes(self._h, B, N, H, W), "dffw_workspace_bytes")

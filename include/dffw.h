@@ -95,6 +95,20 @@ int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists,
                       void *workspace, int64_t workspace_bytes, void *hip_stream,
                       const dffw_tap *taps, int n_taps);
 
+/* ---- per-launch timing (bench.py's roofline figures) -------------------------------------------
+ * With profiling enabled every kernel launch of the next forward is bracketed by HIP events on the
+ * caller's stream; dffw_profile_collect waits for them and returns one entry per launch.  Strings
+ * stay valid until the next forward or the engine's destruction. */
+typedef struct dffw_prof_entry {
+    const char *kernel; /* kernel name as rocprofv3 --kernel-trace prints it, e.g. "dffw::conv_igemm<0, 1, 4>" */
+    const char *layer;  /* state-dict prefix of the conv (e.g. "DFF_net.dres4.conv0.0.0") or the op name */
+    double flops;       /* algorithmic FLOPs of the launch: 2*MAC of the layer's definition (DEN.py), no packing padding */
+    double bytes;       /* algorithmic HBM bytes: activations read once + written once (+ residuals) in storage format */
+    float ms;           /* elapsed time between the two events */
+} dffw_prof_entry;
+int dffw_profile_enable(dffw_engine *e, int on);
+int dffw_profile_collect(dffw_engine *e, dffw_prof_entry *out, int capacity); /* returns the number of entries */
+
 /* ---- single-operator entry points (parity tests of each kernel family; they allocate their own
  * temporaries with hipMalloc and synchronise the stream before returning) -------------------- */
 
