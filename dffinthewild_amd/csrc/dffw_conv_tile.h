@@ -1,0 +1,60 @@
+// LDS-tiled implicit-GEMM convolution (conv_tile): shared declarations for host and device.
+#pragma once
+#include "dffw_internal.h"
+
+namespace dffw {
+
+// geometry classes of DFF_net's convs that conv_tile covers
+enum Geo {
+    G3S1 = 0,  // 3x3x3, stride 1, pad 1                      (31 layers, 59 % of FLOPs)
+    G3S2 = 1,  // 3x3x3, stride (1,2,2), pad 1                (10 layers)
+    G3T = 2,   // transposed 3x3x3 s(1,2,2) p1 op(0,1,1): 4 sub-pixel passes over one input tile (11 layers)
+    G2S1 = 3,  // 1x3x3 per-slice conv, pad (0,1,1)           (6 layers)
+    G2D = 4,   // the stem: 1x9x9, dilation (1,2,2), pad (0,8,8), on the paired-pixel (W+2)-wide input (see stack_in)
+    GEO_COUNT = 5
+};
+
+struct GeoInfo {
+    int minz, maxz, miny, maxy, minx, maxx;  // tap offset range along slices / rows / cols
+    int s;                         // input stride over rows/cols
+    int os;                        // output stride (2 for the transposed conv)
+    int npass;
+};
+
+inline GeoInfo geo_info(int geo) {
+    switch (geo) {
+        case G3S1: return GeoInfo{-1, 1, -1, 1, -1, 1, 1, 1, 1};
+        case G3S2: return GeoInfo{-1, 1, -1, 1, -1, 1, 2, 1, 1};
+        case G3T: return GeoInfo{-1, 1, 0, 1, 0, 1, 1, 2, 4};
+        case G2D: return GeoInfo{0, 0, -8, 8, -6, 10, 1, 1, 1};
+        default: return GeoInfo{0, 0, -1, 1, -1, 1, 1, 1, 1};
+    }
+}
+
+// one instantiated kernel configuration
+struct TileCfg {
+    int id;
+    int geo, nt, cg;     // selection key: geometry class, 16-channel output tiles, channels staged per LDS fill
+    int tz, ty, tx;      // output tile (grid points) per workgroup
+    // derived LDS image constants (host needs them to precompute tap offsets)
+    int fz, fy, fx, fxl;
+};
+
+struct TileArgs {
+    int npass, nstage;
+    int KC[4];                // 32-deep contraction chunks per stage, per pass
+    const int *tab[4];        // [KC*4] per 8-channel group: LDS byte offset of its tap (+ channel octet * 16)
+    const uint16_t *wpk[4];   // [stage][KC][NT][part][64][8]
+    int ooy[4], oox[4];       // output sub-pixel phase of each pass
+    int tiles_z, tiles_y, tiles_x;
+    int total_tiles;
+};
+
+// returns nullptr when no instantiation covers (geo, nt, cg)
+const TileCfg *tile_cfg_find(int geo, int nt, int cg);
+int tile_cfg_count();
+const TileCfg *tile_cfg_at(int i);
+hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
+void conv_tile_kernel_name(int prec, const TileCfg *cfg, char *buf, int n);
+
+}  // namespace dffw

@@ -1,0 +1,375 @@
+// conv_tile: LDS-tiled implicit-GEMM convolution for gfx950 (MI355X).
+//
+// One workgroup (4 waves) produces a TZ x TY x TX block of output grid points of one focal-stack
+// sample, for ALL output channels.  Per channel group ("stage") of CG input channels it
+//   1. stages the input footprint of the block (block + filter halo, zero-filled outside the
+//      volume) into LDS by LDS-DMA (global_load_lds_dwordx4, every load of the stage in flight at once,
+//      no VGPR round trip), hi and lo halves of split-bf16 in separate planes;
+//   2. runs the contraction over (tap, channel) in 32-deep chunks on the matrix cores: the
+//      activation operand of v_mfma_f32_16x16x32 is a single ds_read_b128 at
+//      (grid-point base + tap offset), so each byte fetched from HBM/L2 is reused by all 27 taps
+//      out of LDS instead of being re-gathered from the vector L1;
+//      the weight operand comes pre-packed in fragment order from L2 (one 16-byte load per lane,
+//      register double-buffered one chunk ahead).
+// The transposed conv runs its 4 sub-pixel output phases as 4 passes over the same LDS image.
+// Stride-2 convs store the footprint with even/odd columns de-interleaved so that the 16 lanes of
+// an operand read stay on consecutive LDS addresses (bank-conflict free).
+// Epilogue as in conv_igemm: BatchNorm shift, residual adds, ReLU, split to the storage format,
+// 8-byte channels-last stores.  Workgroup -> tile mapping is XCD-aware: each of the 8 XCDs walks a
+// contiguous range of tiles so neighbouring tiles' halos hit in that XCD's L2.
+#include <cstdio>
+
+#include "dffw_conv_tile.h"
+#include "dffw_device.h"
+
+namespace dffw {
+
+template <int GEO>
+struct GeoT;
+template <>
+struct GeoT<G3S1> { static constexpr int MINZ = -1, MAXZ = 1, MINY = -1, MAXY = 1, S = 1, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
+template <>
+struct GeoT<G3S2> { static constexpr int MINZ = -1, MAXZ = 1, MINY = -1, MAXY = 1, S = 2, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
+template <>
+struct GeoT<G3T> { static constexpr int MINZ = -1, MAXZ = 1, MINY = 0, MAXY = 1, S = 1, OS = 2, NPASS = 4, MINX = MINY, MAXX = MAXY; };
+template <>
+struct GeoT<G2S1> { static constexpr int MINZ = 0, MAXZ = 0, MINY = -1, MAXY = 1, S = 1, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
+template <>
+struct GeoT<G2D> { static constexpr int MINZ = 0, MAXZ = 0, MINY = -8, MAXY = 8, S = 1, OS = 1, NPASS = 1, MINX = -6, MAXX = 10; };
+
+template <int GEO, int TZ_, int TY_, int TX_, int CG_>
+struct TileT {
+    using G = GeoT<GEO>;
+    static constexpr int TZ = TZ_, TY = TY_, TX = TX_, CG = CG_;
+    static constexpr int FZ = TZ + G::MAXZ - G::MINZ;
+    static constexpr int FY = (TY - 1) * G::S + (G::MAXY - G::MINY) + 1;
+    static constexpr int FX = (TX - 1) * G::S + (G::MAXX - G::MINX) + 1;
+    static constexpr int FXL = (G::S == 2) ? (FX + 1) / 2 * 2 : FX;
+    static constexpr int FPIX = FZ * FY * FXL;
+    static constexpr int MT = TZ * TY * TX / 16;
+    static_assert(TZ * TY * TX % 64 == 0, "tile must split evenly over 4 waves of 16-point operand tiles");
+};
+
+constexpr int NWAVES = 4;
+constexpr int NTHREADS = NWAVES * 64;
+
+template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG>
+__global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const TileArgs t) {
+    using T = TileT<GEO, TZ, TY, TX, CG>;
+    using G = GeoT<GEO>;
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int MTW = T::MT / NWAVES;  // operand tiles (16 grid points) per wave
+    constexpr int CG8 = CG / 8;
+
+    // LDS image: PARTS planes (hi, lo) of [footprint pixel][CG channels], 16-bit.  With CG = 8 a pixel is
+    // one 16-byte slot; with CG = 16 the lane groups 0/1 (2/3) of an operand read take the two channel
+    // octets of the SAME tap, so for the hardware's ds_read_b128 service groups the 16 lanes always fall
+    // on 16 distinct 16-byte bank groups: conflict-free without padding or swizzle, and the operand
+    // address is linear: (pixel of the grid point + pixel offset of the tap) * PIXB + octet*16.
+    // The image is filled by LDS-DMA (global_load_lds_dwordx4; destination = wave-uniform base +
+    // lane*16, i.e. linear in chunk order [part][pixel][octet]).
+    constexpr int PIXB = CG * 2;                          // bytes per pixel per plane
+    constexpr int PLANEB = T::FPIX * PIXB;
+    constexpr int NCH = PARTS * T::FPIX * CG8;            // 16-byte chunks in the image
+    constexpr int LDSB = (NCH * 16 + 1023) / 1024 * 1024;
+    constexpr int NIT = (NCH + NTHREADS - 1) / NTHREADS;
+    static_assert(PLANEB < 65536, "lo-plane offset must fit the ds_read immediate");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+
+    if ((a.dbg & 8) && blockIdx.x < 1024 && ((blockIdx.x >> 8) & 1)) {   // experiment: skew the 2nd resident WG of each CU
+        for (int i = 0; i < (a.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    // ---- XCD-aware tile id: XCD x (= blockIdx % 8) walks a contiguous range of tiles ----------------
+    int tile;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int txi = tile % t.tiles_x;
+    int tt = tile / t.tiles_x;
+    const int tyi = tt % t.tiles_y;
+    tt /= t.tiles_y;
+    const int tzi = tt % t.tiles_z;
+    const int b = tt / t.tiles_z;
+    const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;  // first grid point of the tile
+    const int iz0 = gz0 + G::MINZ, iy0 = gy0 * G::S + G::MINY, ix0 = gx0 * G::S + G::MINX;  // footprint origin
+
+    // ---- per-lane LDS byte offset of each of this wave's operand tiles ------------------------------
+    int pofs[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int p = (wave * MTW + j) * 16 + r;
+        const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+        pofs[j] = ((tz * T::FY + ty * G::S) * T::FXL + tx) * PIXB;
+    }
+
+    const int ps0 = PARTS * a.C0, ps1 = PARTS * a.C1;
+    const uint16_t *src0 = a.in0 + (int64_t)b * a.Ni * a.Hi * a.Wi * ps0;
+    const uint16_t *src1 = a.in1 + (int64_t)b * a.Ni * a.Hi * a.Wi * ps1;
+
+    for (int pass = 0; pass < G::NPASS; ++pass) {
+        f32x4 acc[NT][MTW];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) acc[nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const int KC = t.KC[pass];
+        const int *tab = t.tab[pass] + g;
+
+        for (int st = 0; st < t.nstage; ++st) {
+            if ((pass == 0 || t.nstage > 1) && !(a.dbg & 1)) {
+                // ---- stage the footprint of channel group `st` into LDS by LDS-DMA ------------------
+                __syncthreads();  // everyone is done reading the previous image
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int cbase = (it * NWAVES + wave) * 64;      // wave-uniform first chunk
+                    if (cbase >= NCH) break;
+                    const int ci = cbase + lane;
+                    const int c8 = ci % CG8;
+                    const int p = (ci / CG8) % T::FPIX;
+                    const int part = ci / (CG8 * T::FPIX);
+                    const int lx = p % T::FXL;
+                    const int fy = (p / T::FXL) % T::FY;
+                    const int fz = p / (T::FXL * T::FY);
+                    const int fx = (G::S == 2) ? (lx < T::FXL / 2 ? 2 * lx : 2 * (lx - T::FXL / 2) + 1) : lx;
+                    const int iz = iz0 + fz, iy = iy0 + fy, ix = ix0 + fx;
+                    const int c = st * CG + c8 * 8;
+                    const bool second = c >= a.C0;
+                    const int cc = second ? c - a.C0 : c;
+                    const int csrc = second ? a.C1 : a.C0;
+                    const uint16_t *sp = second ? src1 : src0;
+                    const bool ok = ci < NCH && fx < T::FX && (unsigned)iz < (unsigned)a.Ni && (unsigned)iy < (unsigned)a.Hi &&
+                                    (unsigned)ix < (unsigned)a.Wi;
+                    const uint16_t *gp = ok ? sp + ((int64_t)((iz * a.Hi + iy) * a.Wi + ix) * (PARTS * csrc) + part * csrc + cc) : a.zero;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                                     (__attribute__((address_space(3))) void *)(smem + cbase * 16), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+
+            // ---- contraction over (tap, channel-in-group) ------------------------------------------
+            // Software pipeline: the wave's MTW operand tiles are split into two groups; while the matrix
+            // cores work on one group's operands the ds_reads of the other group (same chunk or the next
+            // one) are in flight.  Within a group the three split-bf16 products are issued product-major so
+            // consecutive MFMAs never share an accumulator.
+            const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
+            constexpr int GA = MTW / 2, GB = MTW - GA;
+            short8 wcur[NT][PARTS], wnxt[NT][PARTS];
+            short8 xa[GA][PARTS], xb[GB][PARTS];
+            int tcur, tnxt = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wp[(nt * PARTS + pt) * 64];
+            tcur = tab[0];
+#pragma unroll
+            for (int j = 0; j < GA; ++j)
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) xa[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tcur + pt * PLANEB);
+            for (int kc = 0; kc < ((a.dbg & 2) ? 1 : KC); ++kc) {
+                const bool more = kc + 1 < KC;
+                if (more) {
+                    const short8 *wn = wp + (int64_t)(kc + 1) * (NT * PARTS * 64);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt) wnxt[nt][pt] = wn[(nt * PARTS + pt) * 64];
+                    tnxt = tab[(kc + 1) * 4];
+                }
+                // operands of group B for this chunk: in flight during group A's MFMAs
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+#pragma unroll
+                    for (int pt = 0; pt < PARTS; ++pt) xb[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[GA + j] + tcur + pt * PLANEB);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PARTS == 2) {
+#pragma unroll
+                    for (int j = 0; j < GA; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][1], xa[j][0], acc[nt][j]);
+#pragma unroll
+                    for (int j = 0; j < GA; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][0], xa[j][1], acc[nt][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < GA; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][0], xa[j][0], acc[nt][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                // operands of group A for the next chunk: in flight during group B's MFMAs
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < GA; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt) xa[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tnxt + pt * PLANEB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PARTS == 2) {
+#pragma unroll
+                    for (int j = 0; j < GB; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][1], xb[j][0], acc[nt][GA + j]);
+#pragma unroll
+                    for (int j = 0; j < GB; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][0], xb[j][1], acc[nt][GA + j]);
+                }
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][0], xb[j][0], acc[nt][GA + j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wnxt[nt][pt];
+                tcur = tnxt;
+            }
+        }
+
+        // ---- epilogue of this pass ---------------------------------------------------------------
+        const int Cout = a.Cout;
+        const int ooy = t.ooy[pass], oox = t.oox[pass];
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int p = (wave * MTW + j) * 16 + r;
+            const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+            const int gz = gz0 + tz, gy = gy0 + ty, gx = gx0 + tx;
+            if (gz >= a.Ng || gy >= a.Hg || gx >= a.Wg) continue;
+            if ((a.dbg & 4) && acc[0][j][0] != 12345.f) continue;
+            const int64_t opix = (((int64_t)b * a.No + gz) * a.Ho + (gy * G::OS + ooy)) * a.Wo + (gx * G::OS + oox);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c0 = nt * 16 + g * 4;
+                if (c0 >= Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[nt][j][i] + a.bias[c0 + i];
+                if (a.outf) {
+                    if (c0 == 0) a.outf[opix] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
+                    continue;
+                }
+                const int64_t eo = opix * (PARTS * Cout) + c0;
+                if (a.out_pre) {
+                    short4v h, l;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint16_t hi, lo;
+                        Fmt<PREC>::split(v[i], hi, lo);
+                        h[i] = (short)hi;
+                        l[i] = (short)lo;
+                    }
+                    *reinterpret_cast<short4v *>(a.out_pre + eo) = h;
+                    if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out_pre + eo + Cout) = l;
+                }
+                if (a.relu == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                if (a.res0) {
+                    const short4v h = *reinterpret_cast<const short4v *>(a.res0 + eo);
+                    short4v l = short4v{0, 0, 0, 0};
+                    if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res0 + eo + Cout);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
+                }
+                if (a.res1) {
+                    const short4v h = *reinterpret_cast<const short4v *>(a.res1 + eo);
+                    short4v l = short4v{0, 0, 0, 0};
+                    if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res1 + eo + Cout);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
+                }
+                if (a.relu == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                short4v h, l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint16_t hi, lo;
+                    Fmt<PREC>::split(v[i], hi, lo);
+                    h[i] = (short)hi;
+                    l[i] = (short)lo;
+                }
+                *reinterpret_cast<short4v *>(a.out + eo) = h;
+                if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out + eo + Cout) = l;
+            }
+        }
+    }
+}
+
+// ---- configuration table -----------------------------------------------------------------------
+//        id  geo   NT  TZ TY  TX  CG
+#define DFFW_TILE_CONFIGS(X)      \
+    X(0, G3S1, 1, 5, 4, 16, 16)   \
+    X(1, G3S1, 1, 5, 8, 16, 8)    \
+    X(2, G3S1, 2, 5, 4, 16, 16)   \
+    X(3, G3S1, 4, 5, 4, 16, 16)   \
+    X(4, G3S1, 8, 4, 4, 8, 16)    \
+    X(5, G3S2, 1, 5, 4, 16, 8)    \
+    X(6, G3S2, 2, 5, 4, 16, 8)    \
+    X(7, G3S2, 4, 5, 4, 16, 8)    \
+    X(8, G3S2, 8, 4, 4, 8, 8)     \
+    X(9, G3T, 1, 5, 4, 16, 16)    \
+    X(10, G3T, 2, 5, 4, 16, 16)   \
+    X(11, G3T, 4, 5, 4, 16, 16)   \
+    X(12, G2S1, 1, 5, 8, 16, 8)   \
+    X(13, G2S1, 1, 5, 8, 16, 16)  \
+    X(14, G2S1, 2, 5, 8, 16, 16)  \
+    X(15, G2D, 1, 2, 8, 16, 8)
+
+#define X_CFG(ID, GEO, NT, TZ, TY, TX, CG)                                                             \
+    TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
+            TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL},
+static const TileCfg g_cfgs[] = {DFFW_TILE_CONFIGS(X_CFG)};
+#undef X_CFG
+
+int tile_cfg_count() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
+const TileCfg *tile_cfg_at(int i) { return (i >= 0 && i < tile_cfg_count()) ? &g_cfgs[i] : nullptr; }
+const TileCfg *tile_cfg_find(int geo, int nt, int cg) {
+    for (const TileCfg &c : g_cfgs)
+        if (c.geo == geo && c.nt == nt && c.cg == cg) return &c;
+    return nullptr;
+}
+
+void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg);
+}
+
+template <int PREC>
+static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
+    switch (cfg->id) {
+#define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG)                                                                       \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG>), dim3((unsigned)t.total_tiles), dim3(NTHREADS), 0, s, a, t); \
+        break;
+        DFFW_TILE_CONFIGS(X_LAUNCH)
+#undef X_LAUNCH
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
+    switch (prec) {
+        case P_BF16X3: return launch_conv_tile_p<P_BF16X3>(cfg, a, t, s);
+        case P_FP16: return launch_conv_tile_p<P_FP16>(cfg, a, t, s);
+        case P_BF16: return launch_conv_tile_p<P_BF16>(cfg, a, t, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace dffw

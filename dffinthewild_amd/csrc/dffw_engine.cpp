@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -14,6 +15,7 @@
 #include <vector>
 
 #include "../../include/dffw.h"
+#include "dffw_conv_tile.h"
 #include "dffw_internal.h"
 
 namespace dffw {
@@ -222,11 +224,23 @@ struct Variant {      // one launch: a regular conv, or one sub-pixel phase of a
     uint16_t *wpk = nullptr;  // device
 };
 
+struct TilePack {            // weights/taps in conv_tile's order (per pass: [stage][KC][NT][part][64][8])
+    const TileCfg *cfg = nullptr;
+    int nstage = 0;
+    int npass = 0;
+    int KC[4] = {0, 0, 0, 0};
+    int ntaps[4] = {0, 0, 0, 0};
+    int ooy[4] = {0, 0, 0, 0}, oox[4] = {0, 0, 0, 0};
+    int *tab[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint16_t *wpk[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
 struct PackedConv {
     LayerDef def;
     int nt = 1;
     float *bias = nullptr;  // device, nt*16 floats
     std::vector<Variant> variants;
+    TilePack tile;
 };
 
 static void free_packed(PackedConv &pc) {
@@ -237,6 +251,13 @@ static void free_packed(PackedConv &pc) {
     }
     pc.variants.clear();
     pc.bias = nullptr;
+    for (int i = 0; i < 4; ++i) {
+        if (pc.tile.tab[i]) (void)hipFree(pc.tile.tab[i]);
+        if (pc.tile.wpk[i]) (void)hipFree(pc.tile.wpk[i]);
+        pc.tile.tab[i] = nullptr;
+        pc.tile.wpk[i] = nullptr;
+    }
+    pc.tile.cfg = nullptr;
 }
 
 // weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
@@ -263,6 +284,9 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     HIPCHK(hipMalloc((void **)&pc.bias, bias.size() * sizeof(float)));
     HIPCHK(hipMemcpy(pc.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
 
+    // The stem reads the paired-pixel (W+2)-wide volume written by stack_in: pixel p lives in the first half
+    // of record p+2, so every x-offset of its taps is shifted by +2.
+    const bool stem = (L.kd == 1 && L.kh == 9 && L.kw == 9 && L.dh == 2 && L.pd == 0 && L.ph == 8 && L.sh == 1 && L.cin == 3);
     // tap lists
     std::vector<std::vector<Tap>> tapsets;
     std::vector<std::pair<int, int>> phase;
@@ -271,7 +295,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         for (int kz = 0; kz < L.kd; ++kz)
             for (int ky = 0; ky < L.kh; ++ky)
                 for (int kx = 0; kx < L.kw; ++kx)
-                    taps.push_back(Tap{kz - L.pd, ky * L.dh - L.ph, kx * L.dw - L.pw, kz, ky, kx});
+                    taps.push_back(Tap{kz - L.pd, ky * L.dh - L.ph, kx * L.dw - L.pw + (stem ? 2 : 0), kz, ky, kx});
         tapsets.push_back(taps);
         phase.push_back({0, 0});
     } else {
@@ -341,6 +365,83 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMemcpy(v.wpk, wpk.data(), wpk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         pc.variants.push_back(v);
     }
+
+    // ---- second packing for the LDS-tiled kernel, when a configuration covers this geometry ----------
+    int geo = -1;
+    if (L.transposed) geo = G3T;
+    else if (L.kd == 3 && L.kh == 3 && L.kw == 3 && L.dh == 1 && L.pd == 1 && L.ph == 1 && L.sh == 1) geo = G3S1;
+    else if (L.kd == 3 && L.kh == 3 && L.kw == 3 && L.dh == 1 && L.pd == 1 && L.ph == 1 && L.sh == 2) geo = G3S2;
+    else if (L.kd == 1 && L.kh == 3 && L.kw == 3 && L.dh == 1 && L.pd == 0 && L.ph == 1 && L.sh == 1) geo = G2S1;
+    int cin_t = L.cin;  // channels the tiled kernel contracts over
+    if (stem) {
+        // paired-pixel input (stack_in): record q = RGB(q-2) | RGB(q).  Taps (ky, jx) for jx in {0,2,4,6,8}
+        // read record x+2*jx-6 and carry the weights of x-taps jx (channels 0..2) and jx+1 (channels
+        // 4..6; zero for the non-existent tap 9).
+        geo = G2D;
+        cin_t = 8;
+        tapsets.assign(1, std::vector<Tap>());
+        for (int ky = 0; ky < 9; ++ky)
+            for (int jx = 0; jx < 9; jx += 2) tapsets[0].push_back(Tap{0, 2 * ky - 8, 2 * jx - 6, 0, ky, jx});
+    }
+    auto wval_t = [&](int cout, int cin, const Tap &t) -> double {
+        if (!stem) return wval(cout, cin, t);
+        if ((cin & 3) == 3) return 0.0;
+        Tap u = t;
+        if (cin >= 4) {
+            if (t.kx + 1 > 8) return 0.0;
+            u.kx = t.kx + 1;
+        }
+        return wval(cout, cin & 3, u);
+    };
+    if (geo >= 0 && cin_t % 8 == 0) {
+        const int cg = (geo == G3S2) ? 8 : (cin_t % 16 == 0 ? 16 : 8);
+        const TileCfg *cfg = tile_cfg_find(geo, pc.nt, cg);
+        if (cfg && cin_t % cg == 0) {
+            const GeoInfo gi = geo_info(geo);
+            TilePack &tp = pc.tile;
+            tp.cfg = cfg;
+            tp.nstage = cin_t / cg;
+            tp.npass = (int)tapsets.size();
+            const int cg8 = cg / 8;
+            for (int ps = 0; ps < tp.npass; ++ps) {
+                const auto &taps = tapsets[ps];
+                const int K8 = (int)taps.size() * cg8;
+                const int KC = (K8 + 3) / 4;
+                tp.KC[ps] = KC;
+                tp.ntaps[ps] = (int)taps.size();
+                tp.ooy[ps] = phase[ps].first;
+                tp.oox[ps] = phase[ps].second;
+                std::vector<int> tab(KC * 4, 0);
+                for (int k8 = 0; k8 < K8; ++k8) {
+                    const Tap &tpp = taps[k8 / cg8];
+                    const int dzz = tpp.dz - gi.minz, dyy = tpp.dy - gi.miny, dxx = tpp.dx - gi.minx;
+                    const int lx = (gi.s == 2) ? ((dxx & 1) * (cfg->fxl / 2) + (dxx >> 1)) : dxx;
+                    tab[k8] = ((dzz * cfg->fy + dyy) * cfg->fxl + lx) * (cg * 2) + (k8 % cg8) * 16;
+                }
+                std::vector<uint16_t> wpk((size_t)tp.nstage * KC * pc.nt * parts * 512, 0);
+                for (int st = 0; st < tp.nstage; ++st)
+                    for (int kc = 0; kc < KC; ++kc)
+                        for (int nt = 0; nt < pc.nt; ++nt)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int cout = nt * 16 + (lane & 15);
+                                    const int k = kc * 32 + (lane >> 4) * 8 + j;
+                                    const int tapi = k / cg, cin = st * cg + k % cg;
+                                    float val = 0.f;
+                                    if (cout < L.cout && tapi < (int)taps.size()) val = (float)wval_t(cout, cin, taps[tapi]);
+                                    uint16_t hi, lo;
+                                    host_split(prec, val, hi, lo);
+                                    const size_t base = ((((size_t)st * KC + kc) * pc.nt + nt) * parts) * 512 + (size_t)lane * 8 + j;
+                                    wpk[base] = hi;
+                                    if (parts == 2) wpk[base + 512] = lo;
+                                }
+                HIPCHK(hipMalloc((void **)&tp.tab[ps], tab.size() * sizeof(int)));
+                HIPCHK(hipMemcpy(tp.tab[ps], tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+                HIPCHK(hipMalloc((void **)&tp.wpk[ps], wpk.size() * sizeof(uint16_t)));
+                HIPCHK(hipMemcpy(tp.wpk[ps], wpk.data(), wpk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            }
+        }
+    }
     return DFFW_OK;
 }
 
@@ -406,6 +507,13 @@ struct dffw_engine {
     std::map<std::string, PackedConv> convs;
     bool profiling = false;
     std::vector<ProfRec> recs;
+    uint16_t *zero_page = nullptr;  // 256 zero bytes: what out-of-volume LDS-DMA lanes read
+    int ensure_zero_page() {
+        if (zero_page) return DFFW_OK;
+        HIPCHK(hipMalloc((void **)&zero_page, 256));
+        HIPCHK(hipMemset(zero_page, 0, 256));
+        return DFFW_OK;
+    }
     void clear_recs() {
         for (auto &r : recs) {
             if (r.e0) (void)hipEventDestroy(r.e0);
@@ -415,11 +523,17 @@ struct dffw_engine {
     }
     ~dffw_engine() {
         clear_recs();
+        if (zero_page) (void)hipFree(zero_page);
         for (auto &kv : convs) free_packed(kv.second);
     }
 };
 
 namespace dffw {
+
+static bool getenv_flag(const char *name) {
+    const char *v = getenv(name);
+    return v && *v && *v != '0';
+}
 
 struct ConvOpt {
     const Act *in1 = nullptr;
@@ -509,8 +623,9 @@ struct Run {
             Ho = in0.H * 2;
             Wo = in0.W * 2;
         } else {
+            const int win = (L.kh == 9 && L.cin == 3) ? in0.W - 2 : in0.W;  // stem input is the (W+2)-wide paired volume
             Ho = (in0.H + 2 * L.ph - L.dh * (L.kh - 1) - 1) / L.sh + 1;
-            Wo = (in0.W + 2 * L.pw - L.dw * (L.kw - 1) - 1) / L.sw + 1;
+            Wo = (win + 2 * L.pw - L.dw * (L.kw - 1) - 1) / L.sw + 1;
         }
         const int No = in0.N + 2 * L.pd - (L.kd - 1);
         if (o.outf == nullptr) out = act(in0.B, No, Ho, Wo, L.cout);
@@ -534,6 +649,52 @@ struct Run {
         a.out_pre = o.out_pre ? o.out_pre->p : nullptr;
         a.outf = o.outf;
         a.relu = o.relu;
+        if (e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
+        a.zero = e->zero_page;
+        { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? atoi(d) : 0; }
+        const TilePack &tp = pc.tile;
+        const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
+        const bool use_tile = tp.cfg && !getenv_flag("DFFW_NO_TILE") && gW * 2 >= tp.cfg->tx && gH * 2 >= tp.cfg->ty &&
+                              in0.C % 8 == 0 && (!o.in1 || o.in1->C % 8 == 0);
+        if (use_tile) {
+            const TileCfg *cfg = tp.cfg;
+            a.Ng = L.transposed ? in0.N : No;
+            a.Hg = gH;
+            a.Wg = gW;
+            a.sy = a.sx = L.transposed ? 1 : L.sh;
+            a.osy = a.osx = L.transposed ? 2 : 1;
+            a.M = (int64_t)a.B * a.Ng * a.Hg * a.Wg;
+            TileArgs t;
+            memset(&t, 0, sizeof t);
+            t.npass = tp.npass;
+            t.nstage = tp.nstage;
+            double flops = 0;
+            for (int ps = 0; ps < tp.npass; ++ps) {
+                t.KC[ps] = tp.KC[ps];
+                t.tab[ps] = tp.tab[ps];
+                t.wpk[ps] = tp.wpk[ps];
+                t.ooy[ps] = tp.ooy[ps];
+                t.oox[ps] = tp.oox[ps];
+                flops += 2.0 * (double)a.M * (L.transposed ? tp.ntaps[ps] : L.kd * L.kh * L.kw) * L.cin * L.cout;
+            }
+            t.tiles_z = (a.Ng + cfg->tz - 1) / cfg->tz;
+            t.tiles_y = (a.Hg + cfg->ty - 1) / cfg->ty;
+            t.tiles_x = (a.Wg + cfg->tx - 1) / cfg->tx;
+            t.total_tiles = a.B * t.tiles_z * t.tiles_y * t.tiles_x;
+            if (e->profiling) {
+                char kn[96];
+                conv_tile_kernel_name(e->prec, cfg, kn, sizeof kn);
+                const double opx = (double)out.B * No * Ho * Wo;
+                const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
+                                     + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
+                                     + opx * L.cout * elem_bytes() * ((o.res0 ? 1 : 0) + (o.res1 ? 1 : 0))
+                                     + (double)L.kd * L.kh * L.kw * L.cin * L.cout * elem_bytes();
+                prof_begin(kn, name, flops, bytes);
+            }
+            check(launch_conv_tile(e->prec, cfg, a, t, s), name.c_str());
+            prof_end();
+            return out;
+        }
         for (const Variant &v : pc.variants) {
             a.KC = v.KC;
             a.tab = v.tab;
@@ -720,11 +881,11 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     ConvOpt rl; rl.relu = 1;
 
     // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80
-    Act in = r.act(B, N, H, W, 8);
+    Act in = r.act(B, N, H, W + 2, 8);   // paired-pixel records, see stack_in_kernel
     if (r.ok() && !r.dry) {
         char kn[48];
         snprintf(kn, sizeof kn, "dffw::stack_in_kernel<%d>", prec);
-        r.prof_begin(kn, "stack_in", 0.0, (double)B * N * H * W * (3 * 4.0 + 8 * r.elem_bytes()));
+        r.prof_begin(kn, "stack_in", 0.0, (double)B * N * H * W * 3 * 4.0 + (double)B * N * H * (W + 2) * 8 * r.elem_bytes());
         r.check(launch_stack_in(prec, FS, in.p, B, N, H, W, r.s), "stack_in");
         r.prof_end();
     }
@@ -973,28 +1134,28 @@ int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, in
     if (rc) return rc;
     const int parts = prec_parts(precision);
     const int cpad = (Cin + 7) / 8 * 8;
+    const bool stem = (!transposed && kernel[0] == 1 && kernel[1] == 9 && kernel[2] == 9 && dilation[1] == 2 && pad[0] == 0 && pad[1] == 8 &&
+                       stride[1] == 1 && Cin == 3);
     Act in;
-    in.B = B; in.N = N; in.H = H; in.W = W; in.C = cpad;
+    in.B = B; in.N = N; in.H = H; in.W = stem ? W + 2 : W; in.C = cpad;
     const int64_t in_bytes = in.pixels() * parts * cpad * 2;
     HIPCHK(hipMalloc((void **)&in.p, in_bytes));
     HIPCHK(hipMemsetAsync(in.p, 0, in_bytes, s));
-    // place the Cin real channels into the first channels of the padded volume
-    {
-        // from_ncdhw writes C=Cin densely; when Cin is not a multiple of 8 go through a temp
-        if (cpad == Cin) {
-            HIPCHK(launch_from_ncdhw(precision, x, in.p, B, Cin, N, H, W, s));
-        } else {
-            float *xp = nullptr;
-            const int64_t plane = (int64_t)N * H * W;
-            HIPCHK(hipMalloc((void **)&xp, (size_t)B * cpad * plane * sizeof(float)));
-            HIPCHK(hipMemsetAsync(xp, 0, (size_t)B * cpad * plane * sizeof(float), s));
-            for (int b = 0; b < B; ++b)
-                HIPCHK(hipMemcpyAsync(xp + (int64_t)b * cpad * plane, x + (int64_t)b * Cin * plane, (size_t)Cin * plane * sizeof(float),
-                                      hipMemcpyDeviceToDevice, s));
-            HIPCHK(launch_from_ncdhw(precision, xp, in.p, B, cpad, N, H, W, s));
-            HIPCHK(hipStreamSynchronize(s));
-            HIPCHK(hipFree(xp));
-        }
+    if (stem) {
+        HIPCHK(launch_stack_in(precision, x, in.p, B, N, H, W, s));   // the stem's paired-pixel input format
+    } else if (cpad == Cin) {
+        HIPCHK(launch_from_ncdhw(precision, x, in.p, B, Cin, N, H, W, s));
+    } else {   // place the Cin real channels into the first channels of a zero-padded volume
+        float *xp = nullptr;
+        const int64_t plane = (int64_t)N * H * W;
+        HIPCHK(hipMalloc((void **)&xp, (size_t)B * cpad * plane * sizeof(float)));
+        HIPCHK(hipMemsetAsync(xp, 0, (size_t)B * cpad * plane * sizeof(float), s));
+        for (int b = 0; b < B; ++b)
+            HIPCHK(hipMemcpyAsync(xp + (int64_t)b * cpad * plane, x + (int64_t)b * Cin * plane, (size_t)Cin * plane * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+        HIPCHK(launch_from_ncdhw(precision, xp, in.p, B, cpad, N, H, W, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(xp));
     }
     int Ho, Wo;
     if (transposed) { Ho = 2 * H; Wo = 2 * W; }

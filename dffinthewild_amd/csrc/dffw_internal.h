@@ -45,6 +45,8 @@ struct ConvArgs {
     uint16_t *out_pre;          // optional second output: value before the residual add
     float *outf;                // fp32 score volume (B,No,Ho,Wo) for Cout == 1 layers, or null
     int relu;                   // 0: none   1: relu(acc+res)   2: relu(acc)+res
+    int dbg;                    // ablation switches for profiling (0 in production): 1 no fill, 2 no MFMA loop, 4 no stores
+    const uint16_t *zero;       // >= 16 zero bytes in device memory (source of out-of-volume LDS-DMA lanes)
     int64_t M;                  // B*Ng*Hg*Wg
 };
 

@@ -10,70 +10,10 @@
 //  regress       bilinear resize + softplus normalisation + focus-distance expectation.
 #include <cstdio>
 
+#include "dffw_device.h"
 #include "dffw_internal.h"
 
 namespace dffw {
-
-typedef __attribute__((ext_vector_type(8))) short short8;
-typedef __attribute__((ext_vector_type(4))) short short4v;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-// ---- 16-bit number formats ---------------------------------------------------------------------
-__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even (finite inputs)
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ uint16_t f2h(float f) {
-    _Float16 h = (_Float16)f;
-    return __builtin_bit_cast(uint16_t, h);
-}
-__device__ __forceinline__ float h2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
-
-template <int PREC>
-struct Fmt {
-    static constexpr int PARTS = (PREC == P_BF16X3) ? 2 : 1;
-    // value of channel c of a pixel whose storage starts at p (layout [part][C])
-    static __device__ __forceinline__ float load(const uint16_t *p, int C, int c) {
-        if constexpr (PREC == P_BF16X3) return bf2f(p[c]) + bf2f(p[C + c]);
-        else if constexpr (PREC == P_FP16) return h2f(p[c]);
-        else return bf2f(p[c]);
-    }
-    static __device__ __forceinline__ void split(float v, uint16_t &hi, uint16_t &lo) {
-        if constexpr (PREC == P_BF16X3) {
-            hi = f2bf(v);
-            lo = f2bf(v - bf2f(hi));
-        } else if constexpr (PREC == P_FP16) {
-            hi = f2h(v);
-            lo = 0;
-        } else {
-            hi = f2bf(v);
-            lo = 0;
-        }
-    }
-    static __device__ __forceinline__ float join(uint16_t hi, uint16_t lo) {
-        if constexpr (PREC == P_BF16X3) return bf2f(hi) + bf2f(lo);
-        else if constexpr (PREC == P_FP16) return h2f(hi);
-        else return bf2f(hi);
-    }
-    static __device__ __forceinline__ void store(uint16_t *p, int C, int c, float v) {
-        uint16_t hi, lo;
-        split(v, hi, lo);
-        p[c] = hi;
-        if constexpr (PARTS == 2) p[C + c] = lo;
-    }
-};
-
-template <bool F16>
-__device__ __forceinline__ f32x4 mma(short8 a, short8 b, f32x4 c) {
-    if constexpr (F16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 // ---- implicit-GEMM convolution -----------------------------------------------------------------
 // Workgroup = 4 waves; each wave owns MT*16 consecutive grid points (GEMM columns) and all
@@ -271,24 +211,34 @@ hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s) {
 }
 
 // ---- layout conversion -------------------------------------------------------------------------
-// focal stack (B,3,N,H,W) fp32 -> [pixel][part][8] with channels 3..7 zero (the stem conv contracts
-// over 8-channel groups; the packed stem weights are zero there).
+// focal stack (B,3,N,H,W) fp32 -> paired-pixel volume (B,N,H,W+2) of 8-channel records: record q of a
+// row holds RGB of pixel q-2 in channels 0..2 and RGB of pixel q in channels 4..6 (zero outside
+// [0,W); channels 3 and 7 zero).  The stem conv is dilated by 2, so its x-taps j and j+1 read pixels
+// x+2j-8 and x+2j-6: with this pairing both sit in ONE 16-byte record (q = x+2j-6) and the 9x9x3
+// stencil becomes 9x5 taps of a full 8-channel contraction group (360 instead of 648 deep).
 template <int PREC>
 __global__ __launch_bounds__(256) void stack_in_kernel(const float *__restrict__ FS, uint16_t *__restrict__ out, int B,
                                                        int N, int H, int W) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int W2 = W + 2;
     const int64_t plane = (int64_t)N * H * W;
-    const int64_t total = (int64_t)B * plane;
+    const int64_t total = (int64_t)B * N * H * W2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / plane, q = i - b * plane;
-        const float *src = FS + b * 3 * plane + q;
+        const int q = (int)(i % W2);
+        const int64_t row = i / W2;              // (b*N + n)*H + y
+        const int64_t b = row / ((int64_t)N * H);
+        const int64_t nh = row - b * (int64_t)N * H;
+        const float *src = FS + b * 3 * plane + nh * W;
         short8 h = short8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             uint16_t hi, lo;
-            Fmt<PREC>::split(src[c * plane], hi, lo);
+            Fmt<PREC>::split(q >= 2 ? src[c * plane + q - 2] : 0.f, hi, lo);
             h[c] = (short)hi;
             l[c] = (short)lo;
+            Fmt<PREC>::split(q < W ? src[c * plane + q] : 0.f, hi, lo);
+            h[4 + c] = (short)hi;
+            l[4 + c] = (short)lo;
         }
         short8 *dst = reinterpret_cast<short8 *>(out + i * (PARTS * 8));
         dst[0] = h;
@@ -339,7 +289,7 @@ static inline unsigned grid_for(int64_t total) {
     }
 
 hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int N, int H, int W, hipStream_t s) {
-    const int64_t total = (int64_t)B * N * H * W;
+    const int64_t total = (int64_t)B * N * H * (W + 2);
     DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((stack_in_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, FS, out, B, N, H, W));
     return hipGetLastError();
 }
