@@ -239,74 +239,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
             }
         }
 
-        // ---- epilogue of this pass ---------------------------------------------------------------
-        const int Cout = a.Cout;
+        // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) -------------------------------
         const int ooy = t.ooy[pass], oox = t.oox[pass];
 #pragma unroll
         for (int j = 0; j < MTW; ++j) {
             const int p = (wave * MTW + j) * 16 + r;
             const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
             const int gz = gz0 + tz, gy = gy0 + ty, gx = gx0 + tx;
-            if (gz >= a.Ng || gy >= a.Hg || gx >= a.Wg) continue;
-            if ((a.dbg & 4) && acc[0][j][0] != 12345.f) continue;
+            bool pvalid = gz < a.Ng && gy < a.Hg && gx < a.Wg;
+            if ((a.dbg & 4) && acc[0][j][0] != 12345.f) pvalid = false;
             const int64_t opix = (((int64_t)b * a.No + gz) * a.Ho + (gy * G::OS + ooy)) * a.Wo + (gx * G::OS + oox);
+            float cls = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int c0 = nt * 16 + g * 4;
-                if (c0 >= Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[nt][j][i] + a.bias[c0 + i];
-                if (a.outf) {
-                    if (c0 == 0) a.outf[opix] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
-                    continue;
-                }
-                const int64_t eo = opix * (PARTS * Cout) + c0;
-                if (a.out_pre) {
-                    short4v h, l;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint16_t hi, lo;
-                        Fmt<PREC>::split(v[i], hi, lo);
-                        h[i] = (short)hi;
-                        l[i] = (short)lo;
-                    }
-                    *reinterpret_cast<short4v *>(a.out_pre + eo) = h;
-                    if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out_pre + eo + Cout) = l;
-                }
-                if (a.relu == 2) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                }
-                if (a.res0) {
-                    const short4v h = *reinterpret_cast<const short4v *>(a.res0 + eo);
-                    short4v l = short4v{0, 0, 0, 0};
-                    if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res0 + eo + Cout);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
-                }
-                if (a.res1) {
-                    const short4v h = *reinterpret_cast<const short4v *>(a.res1 + eo);
-                    short4v l = short4v{0, 0, 0, 0};
-                    if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res1 + eo + Cout);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
-                }
-                if (a.relu == 1) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                }
-                short4v h, l;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint16_t hi, lo;
-                    Fmt<PREC>::split(v[i], hi, lo);
-                    h[i] = (short)hi;
-                    l[i] = (short)lo;
-                }
-                *reinterpret_cast<short4v *>(a.out + eo) = h;
-                if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out + eo + Cout) = l;
-            }
+            for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC>(a, acc[nt][j], nt, g, opix, pvalid, cls);
+            epilogue_cls(a, cls, g, opix, pvalid);
         }
     }
 }

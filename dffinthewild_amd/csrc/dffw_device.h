@@ -68,4 +68,119 @@ __device__ __forceinline__ f32x4 mma(short8 a, short8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- conv epilogue shared by conv_igemm and conv_tile ---------------------------------------------------
+// One call handles, for every lane of the wave, the 4 output channels c0 = nt*16 + g*4 .. +3 of the
+// lane's grid point (the v_mfma_f32_16x16x32 result layout): BatchNorm shift, optional copy of the
+// pre-residual value, up to two residual adds, ReLU, optional 1x1x1 classifier partial dot, store.
+// MUST be called by all 64 lanes (no divergence around it): in split-bf16 storage the hi and lo
+// halves of lane rows g and g^1 are exchanged with v_permlane16_swap so that every lane moves one
+// 16-byte piece (8 channels of one half) per access instead of two 8-byte pieces, i.e. a wave store
+// covers 16 pixels x 64 contiguous bytes.  `pvalid`: the lane's grid point exists.
+__device__ __forceinline__ void swap16(uint32_t &a, uint32_t &b) {
+    // a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3} (rows = 16-lane groups)
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+template <int PREC>
+__device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &accq, int nt, int g, int64_t opix, bool pvalid,
+                                              float &cls_partial) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int Cout = a.Cout;
+    const int c0 = nt * 16 + g * 4;
+    const bool cvalid = c0 < Cout;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = accq[i] + a.bias[c0 + i];   // bias is zero-padded to the kernel's NT*16 channels
+    if (a.outf) {  // 1-channel fp32 score volume (B,No,Ho,Wo)
+        if (pvalid && c0 == 0) a.outf[opix] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
+        return;
+    }
+    if constexpr (PARTS == 2) {
+        const int oct = nt * 2 + (g >> 1);                 // which 8-channel group this lane moves
+        const bool wvalid = pvalid && oct * 8 < Cout;
+        const int64_t eo = opix * (2 * Cout) + (g & 1) * Cout + oct * 8;
+        auto wide_store = [&](uint16_t *base) {
+            uint16_t hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Fmt<PREC>::split(v[i], hi[i], lo[i]);
+            uint32_t h01 = hi[0] | ((uint32_t)hi[1] << 16), h23 = hi[2] | ((uint32_t)hi[3] << 16);
+            uint32_t l01 = lo[0] | ((uint32_t)lo[1] << 16), l23 = lo[2] | ((uint32_t)lo[3] << 16);
+            swap16(h01, l01);
+            swap16(h23, l23);
+            if (wvalid) *reinterpret_cast<uint4 *>(base + eo) = make_uint4(h01, h23, l01, l23);
+        };
+        auto wide_add = [&](const uint16_t *base) {
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (wvalid) q = *reinterpret_cast<const uint4 *>(base + eo);
+            swap16(q.x, q.z);
+            swap16(q.y, q.w);
+            v[0] += Fmt<PREC>::join((uint16_t)(q.x & 0xFFFF), (uint16_t)(q.z & 0xFFFF));
+            v[1] += Fmt<PREC>::join((uint16_t)(q.x >> 16), (uint16_t)(q.z >> 16));
+            v[2] += Fmt<PREC>::join((uint16_t)(q.y & 0xFFFF), (uint16_t)(q.w & 0xFFFF));
+            v[3] += Fmt<PREC>::join((uint16_t)(q.y >> 16), (uint16_t)(q.w >> 16));
+        };
+        if (a.out_pre) wide_store(a.out_pre);
+        if (a.relu == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (a.res0) wide_add(a.res0);
+        if (a.res1) wide_add(a.res1);
+        if (a.relu == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (a.cls_w && cvalid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cls_partial = fmaf(a.cls_w[c0 + i], v[i], cls_partial);
+        }
+        if (a.out) wide_store(a.out);
+    } else {
+        const bool ok = pvalid && cvalid;
+        const int64_t eo = opix * Cout + c0;
+        auto store4 = [&](uint16_t *base) {
+            short4v h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint16_t hi, lo;
+                Fmt<PREC>::split(v[i], hi, lo);
+                h[i] = (short)hi;
+            }
+            if (ok) *reinterpret_cast<short4v *>(base + eo) = h;
+        };
+        auto add4 = [&](const uint16_t *base) {
+            short4v h = short4v{0, 0, 0, 0};
+            if (ok) h = *reinterpret_cast<const short4v *>(base + eo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], 0);
+        };
+        if (a.out_pre) store4(a.out_pre);
+        if (a.relu == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (a.res0) add4(a.res0);
+        if (a.res1) add4(a.res1);
+        if (a.relu == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (a.cls_w && cvalid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cls_partial = fmaf(a.cls_w[c0 + i], v[i], cls_partial);
+        }
+        if (a.out) store4(a.out);
+    }
+}
+
+// finish the fused 1x1x1 classifier: sum the partial dots of the 4 lane rows, row 0 writes the score
+__device__ __forceinline__ void epilogue_cls(const ConvArgs &a, float partial, int g, int64_t opix, bool pvalid) {
+    if (!a.cls_w) return;
+    partial += __shfl_xor(partial, 16);
+    partial += __shfl_xor(partial, 32);
+    if (g == 0 && pvalid) a.cls_out[opix] = partial;
+}
+
 }  // namespace dffw

@@ -241,6 +241,7 @@ struct PackedConv {
     float *bias = nullptr;  // device, nt*16 floats
     std::vector<Variant> variants;
     TilePack tile;
+    float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
 };
 
 static void free_packed(PackedConv &pc) {
@@ -258,6 +259,8 @@ static void free_packed(PackedConv &pc) {
         pc.tile.wpk[i] = nullptr;
     }
     pc.tile.cfg = nullptr;
+    if (pc.w32) (void)hipFree(pc.w32);
+    pc.w32 = nullptr;
 }
 
 // weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
@@ -364,6 +367,15 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&v.wpk, wpk.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(v.wpk, wpk.data(), wpk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         pc.variants.push_back(v);
+    }
+
+    if (!L.transposed && L.kh == 1 && L.kw == 1 && L.cout <= 32 && L.cin <= 32) {
+        std::vector<float> w32((size_t)L.kd * L.cin * L.cout);
+        for (int kz = 0; kz < L.kd; ++kz)
+            for (int ci = 0; ci < L.cin; ++ci)
+                for (int co = 0; co < L.cout; ++co) w32[((size_t)kz * L.cin + ci) * L.cout + co] = (float)wval(co, ci, Tap{0, 0, 0, kz, 0, 0});
+        HIPCHK(hipMalloc((void **)&pc.w32, w32.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(pc.w32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
     // ---- second packing for the LDS-tiled kernel, when a configuration covers this geometry ----------
@@ -541,6 +553,9 @@ struct ConvOpt {
     int relu = 0;
     Act *out_pre = nullptr;  // receives the pre-residual value (allocated here)
     float *outf = nullptr;   // fp32 score output instead of an activation volume
+    const char *cls = nullptr;  // name of a 1x1x1 C->1 layer to apply to the final value inside the epilogue
+    float *cls_out = nullptr;   // its fp32 score volume
+    bool discard = false;       // the activation output itself is not needed (only cls_out / out_pre)
 };
 
 struct Run {
@@ -628,8 +643,17 @@ struct Run {
             Wo = (win + 2 * L.pw - L.dw * (L.kw - 1) - 1) / L.sw + 1;
         }
         const int No = in0.N + 2 * L.pd - (L.kd - 1);
-        if (o.outf == nullptr) out = act(in0.B, No, Ho, Wo, L.cout);
+        if (o.outf == nullptr && !o.discard) out = act(in0.B, No, Ho, Wo, L.cout);
         else { out.B = in0.B; out.N = No; out.H = Ho; out.W = Wo; out.C = L.cout; }
+        const float *cls_w = nullptr;
+        if (o.cls) {
+            auto ic = e->convs.find(o.cls);
+            if (ic == e->convs.end() || !ic->second.w32 || ic->second.def.cin != L.cout || ic->second.def.cout != 1) {
+                err = fail(DFFW_EINVAL, "cannot fuse classifier %s into %s", o.cls, name.c_str());
+                return out;
+            }
+            cls_w = ic->second.w32;
+        }
         if (o.out_pre) *o.out_pre = act(in0.B, No, Ho, Wo, L.cout);
         if (!ok() || dry) return out;
 
@@ -648,6 +672,8 @@ struct Run {
         a.out = out.p;
         a.out_pre = o.out_pre ? o.out_pre->p : nullptr;
         a.outf = o.outf;
+        a.cls_w = cls_w;
+        a.cls_out = o.cls_out;
         a.relu = o.relu;
         if (e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
@@ -773,11 +799,28 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x) {
     Act feat = r.conv(p + ".Focus_Measure.conv.2.0", t, o2);
     r.drop(t);
     if (drop_x) r.drop(x);
-    ConvOpt o3; o3.relu = 1;
-    Act a = r.conv(p + ".N_ch_attention.0", feat, o3);
-    ConvOpt o4; o4.relu = 2; o4.res0 = &feat;
-    Act out = r.conv(p + ".N_ch_attention.2", a, o4);
-    r.drop(a);
+    Act out;
+    auto i3 = r.e->convs.find(p + ".N_ch_attention.0");
+    auto i1 = r.e->convs.find(p + ".N_ch_attention.2");
+    if (srd_attention_supported(feat.C) && i3 != r.e->convs.end() && i1 != r.e->convs.end() && i3->second.w32 && i1->second.w32 &&
+        !getenv_flag("DFFW_NO_FUSED_ATTENTION")) {
+        out = r.act(feat.B, feat.N, feat.H, feat.W, feat.C);
+        if (r.ok() && !r.dry) {
+            char kn[64];
+            snprintf(kn, sizeof kn, "dffw::srd_attention_kernel<%d, %d>", r.e->prec, feat.C);
+            const double px = (double)feat.pixels();
+            r.prof_begin(kn, p + ".N_ch_attention", 2.0 * px * 4 * feat.C * feat.C, 2.0 * px * feat.C * r.elem_bytes());
+            r.check(launch_srd_attention(r.e->prec, feat.p, out.p, i3->second.w32, i1->second.w32, feat.B, feat.N, feat.H, feat.W,
+                                         feat.C, r.s), "srd_attention");
+            r.prof_end();
+        }
+    } else {
+        ConvOpt o3; o3.relu = 1;
+        Act a = r.conv(p + ".N_ch_attention.0", feat, o3);
+        ConvOpt o4; o4.relu = 2; o4.res0 = &feat;
+        out = r.conv(p + ".N_ch_attention.2", a, o4);
+        r.drop(a);
+    }
     r.drop(feat);
     return out;
 }
@@ -846,7 +889,7 @@ static Act pyramid(Run &r, const std::string &S, const Act &v3) {
 // hourglass.forward (DEN.py:265-284).  x = cat[xa, xb] on channels.  Returns conv6's output `out`
 // in *out_raw (if wanted) and out + skip in the return value; pre1 = conv0's output.
 static Act hourglass(Run &r, const std::string &p, const Act &xa, const Act &xb, const Act *presqu, const Act *postsqu,
-                     const Act &skip, Act *pre1_out, Act *out_raw) {
+                     const Act &skip, Act *pre1_out, Act *out_raw, const std::string &cls, float *cls_out, bool discard_sum) {
     ConvOpt rl; rl.relu = 1;
     ConvOpt c0 = rl; c0.in1 = &xb;
     Act pre1 = r.conv(p + ".conv0.0.0", xa, c0);
@@ -860,7 +903,8 @@ static Act hourglass(Run &r, const std::string &p, const Act &xa, const Act &xb,
     ConvOpt c5 = rl; c5.res0 = presqu ? presqu : &pre;
     Act o5 = r.conv(p + ".conv5.0", o4, c5);
     r.drop(o4); r.drop(pre);
-    ConvOpt c6; c6.res0 = &skip; c6.out_pre = out_raw;
+    // conv6 + skip (DEN.py:96,102,107) with the 1x1x1 classifier (DEN.py:97,103,108) folded into the epilogue
+    ConvOpt c6; c6.res0 = &skip; c6.out_pre = out_raw; c6.cls = cls.c_str(); c6.cls_out = cls_out; c6.discard = discard_sum;
     Act sum = r.conv(p + ".conv6.0", o5, c6);
     r.drop(o5);
     if (pre1_out) *pre1_out = pre1; else r.drop(pre1);
@@ -926,11 +970,10 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     r.drop(d1);
 
     Act pre_a, out_a;
-    Act s1 = hourglass(r, P + ".dres2", x1, v3, nullptr, nullptr, x1, &pre_a, &out_a);
-    r.drop(x1); r.drop(v3);
     const int h4 = H / 4, w4 = W / 4;
     float *cost1 = (float *)r.raw((int64_t)B * N * h4 * w4 * sizeof(float));
-    { ConvOpt of; of.outf = cost1; r.conv(P + ".classif1.0", s1, of); }
+    Act s1 = hourglass(r, P + ".dres2", x1, v3, nullptr, nullptr, x1, &pre_a, &out_a, P + ".classif1.0", cost1, false);
+    r.drop(x1); r.drop(v3);
     r.tap_f32("cost1", cost1, (int64_t)B * N * h4 * w4);
     regress(r, "regress.pred1", cost1, B, N, h4, w4, H, W, fd, fst, out[1]);
     r.drop_raw(cost1);
@@ -938,21 +981,19 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     Act x2 = r.conv(P + ".deconv_2.0", s1);
     r.drop(s1);
     Act pre_b, out_b;
-    Act s2 = hourglass(r, P + ".dres3", x2, v2, &pre_a, &out_a, x2, &pre_b, &out_b);
-    r.drop(x2); r.drop(v2); r.drop(pre_a); r.drop(out_a);
     const int h2 = H / 2, w2 = W / 2;
     float *cost2 = (float *)r.raw((int64_t)B * N * h2 * w2 * sizeof(float));
-    { ConvOpt of; of.outf = cost2; r.conv(P + ".classif2.0", s2, of); }
+    Act s2 = hourglass(r, P + ".dres3", x2, v2, &pre_a, &out_a, x2, &pre_b, &out_b, P + ".classif2.0", cost2, false);
+    r.drop(x2); r.drop(v2); r.drop(pre_a); r.drop(out_a);
     r.tap_f32("cost2", cost2, (int64_t)B * N * h2 * w2);
     regress(r, "regress.pred2", cost2, B, N, h2, w2, H, W, fd, fst, out[2]);
     r.drop_raw(cost2);
 
     Act x3 = r.conv(P + ".deconv_3.0", s2);
     r.drop(s2);
-    Act s3 = hourglass(r, P + ".dres4", x3, v1, &pre_b, &out_b, x3, nullptr, nullptr);
-    r.drop(x3); r.drop(v1); r.drop(pre_b); r.drop(out_b);
     float *cost3 = (float *)r.raw((int64_t)B * N * H * W * sizeof(float));
-    { ConvOpt of; of.outf = cost3; r.conv(P + ".classif3.0", s3, of); }
+    Act s3 = hourglass(r, P + ".dres4", x3, v1, &pre_b, &out_b, x3, nullptr, nullptr, P + ".classif3.0", cost3, true);  // only its score is used
+    r.drop(x3); r.drop(v1); r.drop(pre_b); r.drop(out_b);
     r.drop(s3);
     r.tap_f32("cost3", cost3, (int64_t)B * N * H * W);
     regress(r, "regress.pred3", cost3, B, N, H, W, H, W, fd, fst, out[3]);

@@ -44,6 +44,8 @@ struct ConvArgs {
     uint16_t *out;              // output volume, or null
     uint16_t *out_pre;          // optional second output: value before the residual add
     float *outf;                // fp32 score volume (B,No,Ho,Wo) for Cout == 1 layers, or null
+    const float *cls_w;         // fused 1x1x1 classifier (DEN.py:51-55): Cout fp32 weights applied to the final value, or null
+    float *cls_out;             // its fp32 score volume (B,No,Ho,Wo)
     int relu;                   // 0: none   1: relu(acc+res)   2: relu(acc)+res
     int dbg;                    // ablation switches for profiling (0 in production): 1 no fill, 2 no MFMA loop, 4 no stores
     const uint16_t *zero;       // >= 16 zero bytes in device memory (source of out-of-volume LDS-DMA lanes)
@@ -58,6 +60,9 @@ hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int 
 hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *out, int B, int N, int H, int W, int C, hipStream_t s);
+bool srd_attention_supported(int C);
+hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, const float *w3, const float *w1, int B, int N,
+                                int H, int W, int C, hipStream_t s);
 hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd,
                           int64_t fsb, int64_t fsn, int64_t fsh, int64_t fsw, float *depth, hipStream_t s);
 

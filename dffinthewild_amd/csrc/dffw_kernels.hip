@@ -107,68 +107,13 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a) {
         }
     }
 
-    // ---- epilogue: BatchNorm shift, residuals, ReLU, split to storage format ---------------------
-    const int Cout = a.Cout;
+    // ---- epilogue (shared with conv_tile, see dffw_device.h) ------------------------------------------------
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if (!pv[mt]) continue;
+        float cls = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int c0 = nt * 16 + g * 4;
-            if (c0 >= Cout) continue;
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][i] + a.bias[c0 + i];
-            if (a.outf) {  // 1-channel score volume, fp32, layout (B,No,Ho,Wo)
-                if (c0 == 0) a.outf[opix[mt]] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
-                continue;
-            }
-            const int64_t eo = opix[mt] * (PARTS * Cout) + c0;
-            if (a.out_pre) {
-                short4v h, l;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint16_t hi, lo;
-                    Fmt<PREC>::split(v[i], hi, lo);
-                    h[i] = (short)hi;
-                    l[i] = (short)lo;
-                }
-                *reinterpret_cast<short4v *>(a.out_pre + eo) = h;
-                if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out_pre + eo + Cout) = l;
-            }
-            if (a.relu == 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            if (a.res0) {
-                const short4v h = *reinterpret_cast<const short4v *>(a.res0 + eo);
-                short4v l = short4v{0, 0, 0, 0};
-                if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res0 + eo + Cout);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
-            }
-            if (a.res1) {
-                const short4v h = *reinterpret_cast<const short4v *>(a.res1 + eo);
-                short4v l = short4v{0, 0, 0, 0};
-                if constexpr (PARTS == 2) l = *reinterpret_cast<const short4v *>(a.res1 + eo + Cout);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], (uint16_t)l[i]);
-            }
-            if (a.relu == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-            }
-            short4v h, l;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint16_t hi, lo;
-                Fmt<PREC>::split(v[i], hi, lo);
-                h[i] = (short)hi;
-                l[i] = (short)lo;
-            }
-            *reinterpret_cast<short4v *>(a.out + eo) = h;
-            if constexpr (PARTS == 2) *reinterpret_cast<short4v *>(a.out + eo + Cout) = l;
-        }
+        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC>(a, acc[nt][mt], nt, g, opix[mt], pv[mt], cls);
+        epilogue_cls(a, cls, g, opix[mt], pv[mt]);
     }
 }
 
@@ -357,6 +302,98 @@ hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *o
     if (C % 8 || H % k || W % k) return hipErrorInvalidValue;
     const int64_t total = (int64_t)B * N * (H / k) * (W / k) * (C / 8);
     DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((pool_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, x, out, B, N, H, W, C, k, mode));
+    return hipGetLastError();
+}
+
+// ---- fused cross-slice attention of the SRD block ---------------------------------------------------
+// out = feat + relu(W1 . relu(W3 . [feat(n-1); feat(n); feat(n+1)]))      (DEN.py:320-330, no BN, no bias)
+// Both convs are pointwise in (y,x) and only couple neighbouring slices, so the whole chain is one
+// streaming pass: one thread per (pixel, slice) reads the three neighbouring feature vectors (the
+// two re-reads hit in L2: HBM sees every vector once) and writes the result once — the unfused form
+// moves 5x the bytes.  The 4*C*C weights are wave-uniform: they arrive through scalar loads and feed
+// the FMAs as SGPR operands, in exact fp32 (no loop around them, so they are never spilled).
+template <int PREC, int C>
+__global__ __launch_bounds__(256) void srd_attention_kernel(const uint16_t *__restrict__ feat, uint16_t *__restrict__ out,
+                                                            const float *__restrict__ w3,  // [kz][ci][co]
+                                                            const float *__restrict__ w1,  // [ci][co]
+                                                            int B, int N, int HW) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr int REC = PARTS * C;  // 16-bit elements per pixel record
+    const int64_t total = (int64_t)B * N * HW;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int n = (int)((p / HW) % N);
+    const uint16_t *src = feat + p * REC;
+    const int64_t nstride = (int64_t)HW * REC;
+
+    auto load = [&](const uint16_t *r, bool valid, float (&f)[C]) {
+#pragma unroll
+        for (int c8 = 0; c8 < C / 8; ++c8) {
+            short8 h = short8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
+            if (valid) {
+                h = *reinterpret_cast<const short8 *>(r + c8 * 8);
+                if constexpr (PARTS == 2) l = *reinterpret_cast<const short8 *>(r + C + c8 * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[c8 * 8 + j] = Fmt<PREC>::join((uint16_t)h[j], (uint16_t)l[j]);
+        }
+    };
+
+    float fp[C], fc[C], fn[C];
+    load(src - nstride, n > 0, fp);
+    load(src, true, fc);
+    load(src + nstride, n + 1 < N, fn);
+
+    float a[C];
+#pragma unroll
+    for (int co = 0; co < C; ++co) a[co] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+            a[co] = fmaf(w3[(0 * C + ci) * C + co], fp[ci], a[co]);
+            a[co] = fmaf(w3[(1 * C + ci) * C + co], fc[ci], a[co]);
+            a[co] = fmaf(w3[(2 * C + ci) * C + co], fn[ci], a[co]);
+        }
+    float o[C];
+#pragma unroll
+    for (int co = 0; co < C; ++co) o[co] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+        const float r = fmaxf(a[ci], 0.f);
+#pragma unroll
+        for (int co = 0; co < C; ++co) o[co] = fmaf(w1[ci * C + co], r, o[co]);
+    }
+    uint16_t *w = out + p * REC;
+#pragma unroll
+    for (int c8 = 0; c8 < C / 8; ++c8) {
+        short8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint16_t hi, lo;
+            Fmt<PREC>::split(fc[c8 * 8 + j] + fmaxf(o[c8 * 8 + j], 0.f), hi, lo);
+            h[j] = (short)hi;
+            l[j] = (short)lo;
+        }
+        *reinterpret_cast<short8 *>(w + c8 * 8) = h;
+        if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(w + C + c8 * 8) = l;
+    }
+}
+
+bool srd_attention_supported(int C) { return C == 8 || C == 16; }
+
+hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, const float *w3, const float *w1, int B, int N,
+                                int H, int W, int C, hipStream_t s) {
+    const int HW = H * W;
+    const int64_t total = (int64_t)B * N * HW;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (C == 8) {
+        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 8>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, HW));
+    } else if (C == 16) {
+        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 16>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, HW));
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
