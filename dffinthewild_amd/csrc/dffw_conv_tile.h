@@ -38,6 +38,7 @@ struct TileCfg {
     int tz, ty, tx;      // output tile (grid points) per workgroup
     // derived LDS image constants (host needs them to precompute tap offsets)
     int fz, fy, fx, fxl;
+    int pipe;            // 1: software-pipelined MFMA loop (compute-bound layers), 0: lean loop (bandwidth-bound)
 };
 
 struct TileArgs {
@@ -48,6 +49,8 @@ struct TileArgs {
     int ooy[4], oox[4];       // output sub-pixel phase of each pass
     int tiles_z, tiles_y, tiles_x;
     int total_tiles;
+    int tpw;                  // consecutive tiles walked by one workgroup
+    int grid;                 // workgroups to launch = 8 * ceil(ceil(total_tiles/8) / tpw)
 };
 
 // returns nullptr when no instantiation covers (geo, nt, cg)

@@ -53,7 +53,7 @@ struct TileT {
 constexpr int NWAVES = 4;
 constexpr int NTHREADS = NWAVES * 64;
 
-template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG>
+template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE>
 __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const TileArgs t) {
     using T = TileT<GEO, TZ, TY, TX, CG>;
     using G = GeoT<GEO>;
@@ -70,10 +70,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     // The image is filled by LDS-DMA (global_load_lds_dwordx4; destination = wave-uniform base +
     // lane*16, i.e. linear in chunk order [part][pixel][octet]).
     constexpr int PIXB = CG * 2;                          // bytes per pixel per plane
-    constexpr int PLANEB = T::FPIX * PIXB;
-    constexpr int NCH = PARTS * T::FPIX * CG8;            // 16-byte chunks in the image
-    constexpr int LDSB = (NCH * 16 + 1023) / 1024 * 1024;
-    constexpr int NIT = (NCH + NTHREADS - 1) / NTHREADS;
+    // plane stride: padded to whole wave instructions (1 KiB) so the tail of the hi plane's last DMA piece
+    // (zeros) can never land on lo-plane pixels
+    constexpr int PLANEB = (T::FPIX * PIXB + 1023) / 1024 * 1024;
+    constexpr int LDSB = PARTS * PLANEB;
     static_assert(PLANEB < 65536, "lo-plane offset must fit the ds_read immediate");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
 
@@ -82,26 +82,42 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     const int wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
 
-    if ((a.dbg & 8) && blockIdx.x < 1024 && ((blockIdx.x >> 8) & 1)) {   // experiment: skew the 2nd resident WG of each CU
-        for (int i = 0; i < (a.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-    }
-
-    // ---- XCD-aware tile id: XCD x (= blockIdx % 8) walks a contiguous range of tiles ----------------
-    int tile;
+    // ---- this workgroup's run of tiles.  XCD x (= blockIdx % 8) owns a contiguous range of the tile
+    // sequence (x fastest, then y, z, sample), so neighbouring tiles' halos hit in that XCD's L2; inside
+    // the range each workgroup walks t.tpw consecutive tiles. -----------------------------------------
+    // MULTI: a workgroup walks t.tpw consecutive tiles and queues the next tile's footprint DMA before the
+    // current tile's epilogue.  Measured slower on MI355X for every layer of this network (the extra live
+    // state costs occupancy and the exposed latencies are not the limiter), so it is compiled out.
+    constexpr bool MULTI = false;
+    int tile_begin, tile_end;
     {
         const int bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3;
         const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
-        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        const int xe = xs + q + (xcd < rem ? 1 : 0);
+        const int tpw = MULTI ? t.tpw : 1;
+        tile_begin = xs + idx * tpw;
+        tile_end = min(tile_begin + tpw, xe);
+        if (tile_begin >= tile_end) return;
     }
-    const int txi = tile % t.tiles_x;
-    int tt = tile / t.tiles_x;
-    const int tyi = tt % t.tiles_y;
-    tt /= t.tiles_y;
-    const int tzi = tt % t.tiles_z;
-    const int b = tt / t.tiles_z;
-    const int gz0 = tzi * TZ, gy0 = tyi * TY, gx0 = txi * TX;  // first grid point of the tile
-    const int iz0 = gz0 + G::MINZ, iy0 = gy0 * G::S + G::MINY, ix0 = gx0 * G::S + G::MINX;  // footprint origin
+
+    struct Coord {
+        int b, gz0, gy0, gx0;
+    };
+    auto decode = [&](int tile) {
+        Coord c;
+        const int txi = tile % t.tiles_x;
+        int tt = tile / t.tiles_x;
+        const int tyi = tt % t.tiles_y;
+        tt /= t.tiles_y;
+        const int tzi = tt % t.tiles_z;
+        c.b = tt / t.tiles_z;
+        c.gz0 = tzi * TZ;
+        c.gy0 = tyi * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
 
     // ---- per-lane LDS byte offset of each of this wave's operand tiles ------------------------------
     int pofs[MTW];
@@ -113,173 +129,270 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     }
 
     const int ps0 = PARTS * a.C0, ps1 = PARTS * a.C1;
-    const uint16_t *src0 = a.in0 + (int64_t)b * a.Ni * a.Hi * a.Wi * ps0;
-    const uint16_t *src1 = a.in1 + (int64_t)b * a.Ni * a.Hi * a.Wi * ps1;
+    const int64_t samp0 = (int64_t)a.Ni * a.Hi * a.Wi * ps0, samp1 = (int64_t)a.Ni * a.Hi * a.Wi * ps1;
 
-    for (int pass = 0; pass < G::NPASS; ++pass) {
-        f32x4 acc[NT][MTW];
+    // ---- LDS-DMA of the footprint of channel group `st` of tile `c` (issue only: no wait, no barrier) ----
+    // One wave instruction fills 64 consecutive 16-byte chunks of one plane = PPW consecutive footprint
+    // pixels.  The (expensive) pixel decode + bounds check + global address is done once per lane and
+    // feeds the DMA of the hi plane and of the lo plane.
+    auto issue_fill = [&](const Coord &c, int st) {
+        constexpr int PPW = 64 / CG8;                                  // pixels per wave instruction
+        constexpr int NPI = (T::FPIX + PPW * NWAVES - 1) / (PPW * NWAVES);  // iterations over the pixel list
+        const int iz0 = c.gz0 + G::MINZ, iy0 = c.gy0 * G::S + G::MINY, ix0 = c.gx0 * G::S + G::MINX;  // footprint origin
+        const int c8 = lane % CG8;
+        const int ch = st * CG + c8 * 8;
+        const bool second = ch >= a.C0;
+        const int cc = second ? ch - a.C0 : ch;
+        const int csrc = second ? a.C1 : a.C0;
+        const uint16_t *sp = second ? a.in1 + c.b * samp1 : a.in0 + c.b * samp0;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int it = 0; it < NPI; ++it) {
+            const int pbase = (it * NWAVES + wave) * PPW;              // wave-uniform first pixel
+            if (pbase >= T::FPIX) break;
+            const int p = pbase + lane / CG8;
+            const int lx = p % T::FXL;
+            const int fy = (p / T::FXL) % T::FY;
+            const int fz = p / (T::FXL * T::FY);
+            const int fx = (G::S == 2) ? (lx < T::FXL / 2 ? 2 * lx : 2 * (lx - T::FXL / 2) + 1) : lx;
+            const int iz = iz0 + fz, iy = iy0 + fy, ix = ix0 + fx;
+            const bool ok = p < T::FPIX && fx < T::FX && (unsigned)iz < (unsigned)a.Ni && (unsigned)iy < (unsigned)a.Hi &&
+                            (unsigned)ix < (unsigned)a.Wi;
+            const uint16_t *gp = sp + ((int64_t)((iz * a.Hi + iy) * a.Wi + ix) * (PARTS * csrc) + cc);
 #pragma unroll
-            for (int j = 0; j < MTW; ++j) acc[nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        const int KC = t.KC[pass];
-        const int *tab = t.tab[pass] + g;
-
-        for (int st = 0; st < t.nstage; ++st) {
-            if ((pass == 0 || t.nstage > 1) && !(a.dbg & 1)) {
-                // ---- stage the footprint of channel group `st` into LDS by LDS-DMA ------------------
-                __syncthreads();  // everyone is done reading the previous image
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int cbase = (it * NWAVES + wave) * 64;      // wave-uniform first chunk
-                    if (cbase >= NCH) break;
-                    const int ci = cbase + lane;
-                    const int c8 = ci % CG8;
-                    const int p = (ci / CG8) % T::FPIX;
-                    const int part = ci / (CG8 * T::FPIX);
-                    const int lx = p % T::FXL;
-                    const int fy = (p / T::FXL) % T::FY;
-                    const int fz = p / (T::FXL * T::FY);
-                    const int fx = (G::S == 2) ? (lx < T::FXL / 2 ? 2 * lx : 2 * (lx - T::FXL / 2) + 1) : lx;
-                    const int iz = iz0 + fz, iy = iy0 + fy, ix = ix0 + fx;
-                    const int c = st * CG + c8 * 8;
-                    const bool second = c >= a.C0;
-                    const int cc = second ? c - a.C0 : c;
-                    const int csrc = second ? a.C1 : a.C0;
-                    const uint16_t *sp = second ? src1 : src0;
-                    const bool ok = ci < NCH && fx < T::FX && (unsigned)iz < (unsigned)a.Ni && (unsigned)iy < (unsigned)a.Hi &&
-                                    (unsigned)ix < (unsigned)a.Wi;
-                    const uint16_t *gp = ok ? sp + ((int64_t)((iz * a.Hi + iy) * a.Wi + ix) * (PARTS * csrc) + part * csrc + cc) : a.zero;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                                     (__attribute__((address_space(3))) void *)(smem + cbase * 16), 16, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+            for (int part = 0; part < PARTS; ++part) {
+                const uint16_t *src = ok ? gp + part * csrc : a.zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(smem + part * PLANEB + pbase * PIXB), 16, 0, 0);
             }
+        }
+    };
 
-            // ---- contraction over (tap, channel-in-group) ------------------------------------------
-            // Software pipeline: the wave's MTW operand tiles are split into two groups; while the matrix
-            // cores work on one group's operands the ds_reads of the other group (same chunk or the next
-            // one) are in flight.  Within a group the three split-bf16 products are issued product-major so
-            // consecutive MFMAs never share an accumulator.
-            const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
-            constexpr int GA = MTW / 2, GB = MTW - GA;
-            short8 wcur[NT][PARTS], wnxt[NT][PARTS];
-            short8 xa[GA][PARTS], xb[GB][PARTS];
-            int tcur, tnxt = 0;
+    // residuals of the final pass are fetched BEFORE the next tile's DMA is queued (loads return in order:
+    // fetched after it they would wait for the whole footprint), when the register budget allows
+    constexpr bool EARLY = MULTI && (PIPE == 1) && (NT * MTW <= 10);
+
+    Coord cur = decode(tile_begin);
+    if (!(a.dbg & 1)) issue_fill(cur, 0);
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const bool has_next = MULTI && tile + 1 < tile_end;
+        const Coord nxt = has_next ? decode(tile + 1) : cur;
+
+        for (int pass = 0; pass < G::NPASS; ++pass) {
+            f32x4 acc[NT][MTW];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wp[(nt * PARTS + pt) * 64];
-            tcur = tab[0];
-#pragma unroll
-            for (int j = 0; j < GA; ++j)
-#pragma unroll
-                for (int pt = 0; pt < PARTS; ++pt) xa[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tcur + pt * PLANEB);
-            for (int kc = 0; kc < ((a.dbg & 2) ? 1 : KC); ++kc) {
-                const bool more = kc + 1 < KC;
-                if (more) {
-                    const short8 *wn = wp + (int64_t)(kc + 1) * (NT * PARTS * 64);
-#pragma unroll
+                for (int j = 0; j < MTW; ++j) acc[nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            const int KC = t.KC[pass];
+            const int *tab = t.tab[pass] + g;
+
+            for (int st = 0; st < t.nstage; ++st) {
+                const bool prefilled = (pass == 0 && st == 0);   // queued by the prologue / the previous tile's epilogue
+                if ((pass == 0 || t.nstage > 1) && !(a.dbg & 1)) {
+                    if (!prefilled) {
+                        __syncthreads();  // everyone is done reading the previous image
+                        issue_fill(cur, st);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+
+                // ---- contraction over (tap, channel-in-group) ------------------------------------------
+                if constexpr (PIPE == 0) {
+                    // Lean loop for bandwidth-bound layers: few registers -> 4-5 workgroups per CU hide the
+                    // fill / residual / store latencies by occupancy instead of by software pipelining.
+                    const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
+                    for (int kc = 0; kc < ((a.dbg & 2) ? 1 : KC); ++kc) {
+                        short8 wf[NT][PARTS];
+    #pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+    #pragma unroll
+                            for (int pt = 0; pt < PARTS; ++pt) wf[nt][pt] = wp[((int64_t)kc * NT * PARTS + nt * PARTS + pt) * 64];
+                        const int toff = tab[kc * 4];
+    #pragma unroll
+                        for (int j = 0; j < MTW; ++j) {
+                            const unsigned char *lp = smem + pofs[j] + toff;
+                            const short8 xh = *reinterpret_cast<const short8 *>(lp);
+                            short8 xl = xh;
+                            if constexpr (PARTS == 2) xl = *reinterpret_cast<const short8 *>(lp + PLANEB);
+    #pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                if constexpr (PARTS == 2) {
+                                    acc[nt][j] = mma<F16>(wf[nt][1], xh, acc[nt][j]);
+                                    acc[nt][j] = mma<F16>(wf[nt][0], xl, acc[nt][j]);
+                                }
+                                acc[nt][j] = mma<F16>(wf[nt][0], xh, acc[nt][j]);
+                            }
+                        }
+                    }
+                } else {
+                    // Software pipeline: the wave's MTW operand tiles are split into two groups; while the matrix
+                    // cores work on one group's operands the ds_reads of the other group (same chunk or the next
+                    // one) are in flight.  Within a group the three split-bf16 products are issued product-major so
+                    // consecutive MFMAs never share an accumulator.
+                    const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
+                    constexpr int GA = MTW / 2, GB = MTW - GA;
+                    short8 wcur[NT][PARTS], wnxt[NT][PARTS];
+                    short8 xa[GA][PARTS], xb[GB][PARTS];
+                    int tcur, tnxt = 0;
+        #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int pt = 0; pt < PARTS; ++pt) wnxt[nt][pt] = wn[(nt * PARTS + pt) * 64];
-                    tnxt = tab[(kc + 1) * 4];
-                }
-                // operands of group B for this chunk: in flight during group A's MFMAs
-#pragma unroll
-                for (int j = 0; j < GB; ++j)
-#pragma unroll
-                    for (int pt = 0; pt < PARTS; ++pt) xb[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[GA + j] + tcur + pt * PLANEB);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PARTS == 2) {
-#pragma unroll
+        #pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wp[(nt * PARTS + pt) * 64];
+                    tcur = tab[0];
+        #pragma unroll
                     for (int j = 0; j < GA; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][1], xa[j][0], acc[nt][j]);
-#pragma unroll
-                    for (int j = 0; j < GA; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][0], xa[j][1], acc[nt][j]);
+        #pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt) xa[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tcur + pt * PLANEB);
+                    for (int kc = 0; kc < ((a.dbg & 2) ? 1 : KC); ++kc) {
+                        const bool more = kc + 1 < KC;
+                        if (more) {
+                            const short8 *wn = wp + (int64_t)(kc + 1) * (NT * PARTS * 64);
+        #pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+        #pragma unroll
+                                for (int pt = 0; pt < PARTS; ++pt) wnxt[nt][pt] = wn[(nt * PARTS + pt) * 64];
+                            tnxt = tab[(kc + 1) * 4];
+                        }
+                        // operands of group B for this chunk: in flight during group A's MFMAs
+        #pragma unroll
+                        for (int j = 0; j < GB; ++j)
+        #pragma unroll
+                            for (int pt = 0; pt < PARTS; ++pt) xb[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[GA + j] + tcur + pt * PLANEB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (PARTS == 2) {
+        #pragma unroll
+                            for (int j = 0; j < GA; ++j)
+        #pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][1], xa[j][0], acc[nt][j]);
+        #pragma unroll
+                            for (int j = 0; j < GA; ++j)
+        #pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][0], xa[j][1], acc[nt][j]);
+                        }
+        #pragma unroll
+                        for (int j = 0; j < GA; ++j)
+        #pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][0], xa[j][0], acc[nt][j]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // operands of group A for the next chunk: in flight during group B's MFMAs
+                        if (more) {
+        #pragma unroll
+                            for (int j = 0; j < GA; ++j)
+        #pragma unroll
+                                for (int pt = 0; pt < PARTS; ++pt) xa[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tnxt + pt * PLANEB);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (PARTS == 2) {
+        #pragma unroll
+                            for (int j = 0; j < GB; ++j)
+        #pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][1], xb[j][0], acc[nt][GA + j]);
+        #pragma unroll
+                            for (int j = 0; j < GB; ++j)
+        #pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][0], xb[j][1], acc[nt][GA + j]);
+                        }
+        #pragma unroll
+                        for (int j = 0; j < GB; ++j)
+        #pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][0], xb[j][0], acc[nt][GA + j]);
+                        __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+        #pragma unroll
+                            for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wnxt[nt][pt];
+                        tcur = tnxt;
+                    }
                 }
+            }
+
+            // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) ---------------------------
+            const int ooy = t.ooy[pass], oox = t.oox[pass];
+            const bool last_pass = pass == G::NPASS - 1;
+            auto where = [&](int j, int64_t &opix) -> bool {   // output pixel of operand tile j; false when outside the volume
+                const int p = (wave * MTW + j) * 16 + r;
+                const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+                const int gz = cur.gz0 + tz, gy = cur.gy0 + ty, gx = cur.gx0 + tx;
+                opix = (((int64_t)cur.b * a.No + gz) * a.Ho + (gy * G::OS + ooy)) * a.Wo + (gx * G::OS + oox);
+                bool ok = gz < a.Ng && gy < a.Hg && gx < a.Wg;
+                if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
+                return ok;
+            };
+            if constexpr (EARLY) {
+                if (last_pass && has_next && !(a.dbg & 1)) {
+                    // Overlap the next tile's footprint DMA with this tile's epilogue and store drain: fetch the
+                    // residual pieces first (loads return in order), queue the DMA, then do the arithmetic + stores.
+                    uint4 pre0[NT][MTW], pre1[NT][MTW];
 #pragma unroll
-                for (int j = 0; j < GA; ++j)
+                    for (int j = 0; j < MTW; ++j) {
+                        int64_t opix;
+                        const bool pv = where(j, opix);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wcur[nt][0], xa[j][0], acc[nt][j]);
-                __builtin_amdgcn_sched_barrier(0);
-                // operands of group A for the next chunk: in flight during group B's MFMAs
-                if (more) {
+                        for (int nt = 0; nt < NT; ++nt) {
+                            pre0[nt][j] = epilogue_res_load<PREC>(a, a.res0, nt, g, opix, pv);
+                            pre1[nt][j] = epilogue_res_load<PREC>(a, a.res1, nt, g, opix, pv);
+                        }
+                    }
+                    __syncthreads();  // every wave has finished reading this tile's image
+                    issue_fill(nxt, 0);
 #pragma unroll
-                    for (int j = 0; j < GA; ++j)
+                    for (int j = 0; j < MTW; ++j) {
+                        int64_t opix;
+                        const bool pv = where(j, opix);
+                        float cls = 0.f;
 #pragma unroll
-                        for (int pt = 0; pt < PARTS; ++pt) xa[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tnxt + pt * PLANEB);
+                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true>(a, acc[nt][j], nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j]);
+                        epilogue_cls(a, cls, g, opix, pv);
+                    }
+                    continue;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PARTS == 2) {
+            }
 #pragma unroll
-                    for (int j = 0; j < GB; ++j)
+            for (int j = 0; j < MTW; ++j) {
+                int64_t opix;
+                const bool pv = where(j, opix);
+                float cls = 0.f;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][1], xb[j][0], acc[nt][GA + j]);
-#pragma unroll
-                    for (int j = 0; j < GB; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][0], xb[j][1], acc[nt][GA + j]);
+                for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{});
+                epilogue_cls(a, cls, g, opix, pv);
+            }
+            if constexpr (!EARLY) {
+                if (last_pass && has_next && !(a.dbg & 1)) {
+                    __syncthreads();  // every wave has finished reading this tile's image
+                    issue_fill(nxt, 0);
                 }
-#pragma unroll
-                for (int j = 0; j < GB; ++j)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[nt][GA + j] = mma<F16>(wcur[nt][0], xb[j][0], acc[nt][GA + j]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wnxt[nt][pt];
-                tcur = tnxt;
             }
         }
-
-        // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) -------------------------------
-        const int ooy = t.ooy[pass], oox = t.oox[pass];
-#pragma unroll
-        for (int j = 0; j < MTW; ++j) {
-            const int p = (wave * MTW + j) * 16 + r;
-            const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
-            const int gz = gz0 + tz, gy = gy0 + ty, gx = gx0 + tx;
-            bool pvalid = gz < a.Ng && gy < a.Hg && gx < a.Wg;
-            if ((a.dbg & 4) && acc[0][j][0] != 12345.f) pvalid = false;
-            const int64_t opix = (((int64_t)b * a.No + gz) * a.Ho + (gy * G::OS + ooy)) * a.Wo + (gx * G::OS + oox);
-            float cls = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC>(a, acc[nt][j], nt, g, opix, pvalid, cls);
-            epilogue_cls(a, cls, g, opix, pvalid);
-        }
+        cur = nxt;
     }
 }
 
 // ---- configuration table -----------------------------------------------------------------------
 //        id  geo   NT  TZ TY  TX  CG
-#define DFFW_TILE_CONFIGS(X)      \
-    X(0, G3S1, 1, 5, 4, 16, 16)   \
-    X(1, G3S1, 1, 5, 8, 16, 8)    \
-    X(2, G3S1, 2, 5, 4, 16, 16)   \
-    X(3, G3S1, 4, 5, 4, 16, 16)   \
-    X(4, G3S1, 8, 4, 4, 8, 16)    \
-    X(5, G3S2, 1, 5, 4, 16, 8)    \
-    X(6, G3S2, 2, 5, 4, 16, 8)    \
-    X(7, G3S2, 4, 5, 4, 16, 8)    \
-    X(8, G3S2, 8, 4, 4, 8, 8)     \
-    X(9, G3T, 1, 5, 4, 16, 16)    \
-    X(10, G3T, 2, 5, 4, 16, 16)   \
-    X(11, G3T, 4, 5, 4, 16, 16)   \
-    X(12, G2S1, 1, 5, 8, 16, 8)   \
-    X(13, G2S1, 1, 5, 8, 16, 16)  \
-    X(14, G2S1, 2, 5, 8, 16, 16)  \
-    X(15, G2D, 1, 2, 8, 16, 8)
+#define DFFW_TILE_CONFIGS(X)         \
+    X(0, G3S1, 1, 5, 4, 16, 16, 1)   \
+    X(1, G3S1, 1, 5, 8, 16, 8, 1)    \
+    X(2, G3S1, 2, 5, 4, 16, 16, 1)   \
+    X(3, G3S1, 4, 5, 4, 16, 16, 1)   \
+    X(4, G3S1, 8, 4, 4, 8, 16, 1)    \
+    X(5, G3S2, 1, 5, 4, 16, 8, 1)    \
+    X(6, G3S2, 2, 5, 4, 16, 8, 1)    \
+    X(7, G3S2, 4, 5, 4, 16, 8, 1)    \
+    X(8, G3S2, 8, 4, 4, 8, 8, 1)     \
+    X(9, G3T, 1, 5, 4, 16, 16, 0)    \
+    X(10, G3T, 2, 5, 4, 16, 16, 1)   \
+    X(11, G3T, 4, 5, 4, 16, 16, 1)   \
+    X(12, G2S1, 1, 5, 8, 16, 8, 0)   \
+    X(13, G2S1, 1, 5, 8, 16, 16, 0)  \
+    X(14, G2S1, 2, 5, 8, 16, 16, 0)  \
+    X(15, G2D, 1, 2, 8, 16, 8, 0)
 
-#define X_CFG(ID, GEO, NT, TZ, TY, TX, CG)                                                             \
+#define X_CFG(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                             \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
-            TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL},
+            TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL, PIPE},
 static const TileCfg g_cfgs[] = {DFFW_TILE_CONFIGS(X_CFG)};
 #undef X_CFG
 
@@ -292,15 +405,15 @@ const TileCfg *tile_cfg_find(int geo, int nt, int cg) {
 }
 
 void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg);
+    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe);
 }
 
 template <int PREC>
 static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
     switch (cfg->id) {
-#define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG)                                                                       \
+#define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG>), dim3((unsigned)t.total_tiles), dim3(NTHREADS), 0, s, a, t); \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid), dim3(NTHREADS), 0, s, a, t); \
         break;
         DFFW_TILE_CONFIGS(X_LAUNCH)
 #undef X_LAUNCH

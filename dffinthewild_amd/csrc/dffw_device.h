@@ -52,6 +52,37 @@ struct Fmt {
         else if constexpr (PREC == P_FP16) return h2f(hi);
         else return bf2f(hi);
     }
+    // two values at once: packed 16-bit pairs (x in the low half) of the hi and lo parts.  bf16 uses the
+    // hardware round-to-nearest-even pack (v_cvt_pk_bf16_f32): 5 instructions per pair instead of ~20.
+    static __device__ __forceinline__ void split2(float x, float y, uint32_t &hi, uint32_t &lo) {
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        if constexpr (PREC == P_FP16) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{x, y}, h2));
+            lo = 0;
+        } else {
+            typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+            hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{x, y}, b2));
+            lo = 0;
+            if constexpr (PREC == P_BF16X3) {
+                const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xFFFF0000u);
+                lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{rx, ry}, b2));
+            }
+        }
+    }
+    static __device__ __forceinline__ void join2(uint32_t hi, uint32_t lo, float &x, float &y) {
+        if constexpr (PREC == P_FP16) {
+            x = h2f((uint16_t)(hi & 0xFFFF));
+            y = h2f((uint16_t)(hi >> 16));
+        } else {
+            x = __uint_as_float(hi << 16);
+            y = __uint_as_float(hi & 0xFFFF0000u);
+            if constexpr (PREC == P_BF16X3) {
+                x += __uint_as_float(lo << 16);
+                y += __uint_as_float(lo & 0xFFFF0000u);
+            }
+        }
+    }
     static __device__ __forceinline__ void store(uint16_t *p, int C, int c, float v) {
         uint16_t hi, lo;
         split(v, hi, lo);
@@ -83,9 +114,30 @@ __device__ __forceinline__ void swap16(uint32_t &a, uint32_t &b) {
     b = r[1];
 }
 
+// raw residual piece of one lane (16 bytes in split-bf16 storage, 8 bytes otherwise); zero when absent
 template <int PREC>
+__device__ __forceinline__ uint4 epilogue_res_load(const ConvArgs &a, const uint16_t *base, int nt, int g, int64_t opix, bool pvalid) {
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (!base) return q;
+    const int Cout = a.Cout;
+    if constexpr (Fmt<PREC>::PARTS == 2) {
+        const int oct = nt * 2 + (g >> 1);
+        if (pvalid && oct * 8 < Cout) q = *reinterpret_cast<const uint4 *>(base + opix * (2 * Cout) + (g & 1) * Cout + oct * 8);
+    } else {
+        const int c0 = nt * 16 + g * 4;
+        if (pvalid && c0 < Cout) {
+            const uint2 h = *reinterpret_cast<const uint2 *>(base + opix * Cout + c0);
+            q.x = h.x;
+            q.y = h.y;
+        }
+    }
+    return q;
+}
+
+// PRE: the residual pieces were fetched earlier with epilogue_res_load (pre0/pre1), else they are loaded here
+template <int PREC, bool PRE>
 __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &accq, int nt, int g, int64_t opix, bool pvalid,
-                                              float &cls_partial) {
+                                              float &cls_partial, uint4 pre0, uint4 pre1) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     const int Cout = a.Cout;
     const int c0 = nt * 16 + g * 4;
@@ -102,32 +154,35 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
         const bool wvalid = pvalid && oct * 8 < Cout;
         const int64_t eo = opix * (2 * Cout) + (g & 1) * Cout + oct * 8;
         auto wide_store = [&](uint16_t *base) {
-            uint16_t hi[4], lo[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) Fmt<PREC>::split(v[i], hi[i], lo[i]);
-            uint32_t h01 = hi[0] | ((uint32_t)hi[1] << 16), h23 = hi[2] | ((uint32_t)hi[3] << 16);
-            uint32_t l01 = lo[0] | ((uint32_t)lo[1] << 16), l23 = lo[2] | ((uint32_t)lo[3] << 16);
+            uint32_t h01, h23, l01, l23;
+            Fmt<PREC>::split2(v[0], v[1], h01, l01);
+            Fmt<PREC>::split2(v[2], v[3], h23, l23);
             swap16(h01, l01);
             swap16(h23, l23);
             if (wvalid) *reinterpret_cast<uint4 *>(base + eo) = make_uint4(h01, h23, l01, l23);
         };
-        auto wide_add = [&](const uint16_t *base) {
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (wvalid) q = *reinterpret_cast<const uint4 *>(base + eo);
+        auto wide_add = [&](const uint16_t *base, uint4 q) {
+            if constexpr (!PRE) {
+                q = make_uint4(0, 0, 0, 0);
+                if (wvalid) q = *reinterpret_cast<const uint4 *>(base + eo);
+            }
             swap16(q.x, q.z);
             swap16(q.y, q.w);
-            v[0] += Fmt<PREC>::join((uint16_t)(q.x & 0xFFFF), (uint16_t)(q.z & 0xFFFF));
-            v[1] += Fmt<PREC>::join((uint16_t)(q.x >> 16), (uint16_t)(q.z >> 16));
-            v[2] += Fmt<PREC>::join((uint16_t)(q.y & 0xFFFF), (uint16_t)(q.w & 0xFFFF));
-            v[3] += Fmt<PREC>::join((uint16_t)(q.y >> 16), (uint16_t)(q.w >> 16));
+            float r0, r1, r2, r3;
+            Fmt<PREC>::join2(q.x, q.z, r0, r1);
+            Fmt<PREC>::join2(q.y, q.w, r2, r3);
+            v[0] += r0;
+            v[1] += r1;
+            v[2] += r2;
+            v[3] += r3;
         };
         if (a.out_pre) wide_store(a.out_pre);
         if (a.relu == 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        if (a.res0) wide_add(a.res0);
-        if (a.res1) wide_add(a.res1);
+        if (a.res0) wide_add(a.res0, pre0);
+        if (a.res1) wide_add(a.res1, pre1);
         if (a.relu == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
@@ -141,28 +196,35 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
         const bool ok = pvalid && cvalid;
         const int64_t eo = opix * Cout + c0;
         auto store4 = [&](uint16_t *base) {
-            short4v h;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint16_t hi, lo;
-                Fmt<PREC>::split(v[i], hi, lo);
-                h[i] = (short)hi;
-            }
-            if (ok) *reinterpret_cast<short4v *>(base + eo) = h;
+            uint32_t h01, h23, l01, l23;
+            Fmt<PREC>::split2(v[0], v[1], h01, l01);
+            Fmt<PREC>::split2(v[2], v[3], h23, l23);
+            if (ok) *reinterpret_cast<uint2 *>(base + eo) = make_uint2(h01, h23);
         };
-        auto add4 = [&](const uint16_t *base) {
-            short4v h = short4v{0, 0, 0, 0};
-            if (ok) h = *reinterpret_cast<const short4v *>(base + eo);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += Fmt<PREC>::join((uint16_t)h[i], 0);
+        auto add4 = [&](const uint16_t *base, uint4 q) {
+            if constexpr (!PRE) {
+                q = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    const uint2 h = *reinterpret_cast<const uint2 *>(base + eo);
+                    q.x = h.x;
+                    q.y = h.y;
+                }
+            }
+            float r0, r1, r2, r3;
+            Fmt<PREC>::join2(q.x, 0, r0, r1);
+            Fmt<PREC>::join2(q.y, 0, r2, r3);
+            v[0] += r0;
+            v[1] += r1;
+            v[2] += r2;
+            v[3] += r3;
         };
         if (a.out_pre) store4(a.out_pre);
         if (a.relu == 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        if (a.res0) add4(a.res0);
-        if (a.res1) add4(a.res1);
+        if (a.res0) add4(a.res0, pre0);
+        if (a.res1) add4(a.res1, pre1);
         if (a.relu == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);

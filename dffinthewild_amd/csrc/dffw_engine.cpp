@@ -707,6 +707,11 @@ struct Run {
             t.tiles_y = (a.Hg + cfg->ty - 1) / cfg->ty;
             t.tiles_x = (a.Wg + cfg->tx - 1) / cfg->tx;
             t.total_tiles = a.B * t.tiles_z * t.tiles_y * t.tiles_x;
+            {   // tiles per workgroup
+                t.tpw = 1;   // see MULTI in dffw_conv_tile.hip
+                const int per_xcd = (t.total_tiles + 7) / 8;
+                t.grid = 8 * ((per_xcd + t.tpw - 1) / t.tpw);
+            }
             if (e->profiling) {
                 char kn[96];
                 conv_tile_kernel_name(e->prec, cfg, kn, sizeof kn);

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
         float cls = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC>(a, acc[nt][mt], nt, g, opix[mt], pv[mt], cls);
+        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false>(a, acc[nt][mt], nt, g, opix[mt], pv[mt], cls, uint4{}, uint4{});
         epilogue_cls(a, cls, g, opix[mt], pv[mt]);
     }
 }
