@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     X(12, G2S1, 1, 5, 8, 16, 8, 0)   \
     X(13, G2S1, 1, 5, 8, 16, 16, 0)  \
     X(14, G2S1, 2, 5, 8, 16, 16, 0)  \
-    X(15, G2D, 1, 2, 8, 16, 8, 0)
+    X(15, G2D, 1, 1, 16, 32, 8, 0)
 
 #define X_CFG(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                             \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
