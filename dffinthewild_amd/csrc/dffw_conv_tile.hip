@@ -19,36 +19,9 @@
 // contiguous range of tiles so neighbouring tiles' halos hit in that XCD's L2.
 #include <cstdio>
 
-#include "dffw_conv_tile.h"
-#include "dffw_device.h"
+#include "dffw_conv_geom.h"
 
 namespace dffw {
-
-template <int GEO>
-struct GeoT;
-template <>
-struct GeoT<G3S1> { static constexpr int MINZ = -1, MAXZ = 1, MINY = -1, MAXY = 1, S = 1, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
-template <>
-struct GeoT<G3S2> { static constexpr int MINZ = -1, MAXZ = 1, MINY = -1, MAXY = 1, S = 2, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
-template <>
-struct GeoT<G3T> { static constexpr int MINZ = -1, MAXZ = 1, MINY = 0, MAXY = 1, S = 1, OS = 2, NPASS = 4, MINX = MINY, MAXX = MAXY; };
-template <>
-struct GeoT<G2S1> { static constexpr int MINZ = 0, MAXZ = 0, MINY = -1, MAXY = 1, S = 1, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
-template <>
-struct GeoT<G2D> { static constexpr int MINZ = 0, MAXZ = 0, MINY = -8, MAXY = 8, S = 1, OS = 1, NPASS = 1, MINX = -6, MAXX = 10; };
-
-template <int GEO, int TZ_, int TY_, int TX_, int CG_>
-struct TileT {
-    using G = GeoT<GEO>;
-    static constexpr int TZ = TZ_, TY = TY_, TX = TX_, CG = CG_;
-    static constexpr int FZ = TZ + G::MAXZ - G::MINZ;
-    static constexpr int FY = (TY - 1) * G::S + (G::MAXY - G::MINY) + 1;
-    static constexpr int FX = (TX - 1) * G::S + (G::MAXX - G::MINX) + 1;
-    static constexpr int FXL = (G::S == 2) ? (FX + 1) / 2 * 2 : FX;
-    static constexpr int FPIX = FZ * FY * FXL;
-    static constexpr int MT = TZ * TY * TX / 16;
-    static_assert(TZ * TY * TX % 64 == 0, "tile must split evenly over 4 waves of 16-point operand tiles");
-};
 
 constexpr int NWAVES = 4;
 constexpr int NTHREADS = NWAVES * 64;
@@ -119,13 +92,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         return c;
     };
 
-    // ---- per-lane LDS byte offset of each of this wave's operand tiles ------------------------------
-    int pofs[MTW];
+    // ---- per-lane constants of each of this wave's operand tiles: LDS byte offset of its grid point, its
+    // pixel offset inside the output volume, and its packed tile coordinates (for edge tiles only) --------
+    int pofs[MTW], ooff[MTW], tcrd[MTW];
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
         const int p = (wave * MTW + j) * 16 + r;
         const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
         pofs[j] = ((tz * T::FY + ty * G::S) * T::FXL + tx) * PIXB;
+        ooff[j] = (tz * a.Ho + ty * G::OS) * a.Wo + tx * G::OS;
+        tcrd[j] = tx | (ty << 8) | (tz << 16);
     }
 
     const int ps0 = PARTS * a.C0, ps1 = PARTS * a.C1;
@@ -312,12 +288,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
             // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) ---------------------------
             const int ooy = t.ooy[pass], oox = t.oox[pass];
             const bool last_pass = pass == G::NPASS - 1;
-            auto where = [&](int j, int64_t &opix) -> bool {   // output pixel of operand tile j; false when outside the volume
-                const int p = (wave * MTW + j) * 16 + r;
-                const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
-                const int gz = cur.gz0 + tz, gy = cur.gy0 + ty, gx = cur.gx0 + tx;
-                opix = (((int64_t)cur.b * a.No + gz) * a.Ho + (gy * G::OS + ooy)) * a.Wo + (gx * G::OS + oox);
-                bool ok = gz < a.Ng && gy < a.Hg && gx < a.Wg;
+            // output pixel of operand tile j = tile base (wave-uniform) + the lane's precomputed offset; the
+            // bounds test is only evaluated for tiles that stick out of the volume
+            const int64_t obase = (((int64_t)cur.b * a.No + cur.gz0) * a.Ho + (cur.gy0 * G::OS + ooy)) * a.Wo + (cur.gx0 * G::OS + oox);
+            const bool interior = cur.gz0 + TZ <= a.Ng && cur.gy0 + TY <= a.Hg && cur.gx0 + TX <= a.Wg;
+            auto where = [&](int j, int64_t &opix) -> bool {
+                opix = obase + ooff[j];
+                bool ok = true;
+                if (!interior) {
+                    const int c = tcrd[j];
+                    ok = cur.gz0 + (c >> 16) < a.Ng && cur.gy0 + ((c >> 8) & 255) < a.Hg && cur.gx0 + (c & 255) < a.Wg;
+                }
                 if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
                 return ok;
             };

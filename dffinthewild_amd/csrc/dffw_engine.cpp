@@ -712,15 +712,26 @@ struct Run {
                 const int per_xcd = (t.total_tiles + 7) / 8;
                 t.grid = 8 * ((per_xcd + t.tpw - 1) / t.tpw);
             }
+            // persistent warp-specialised kernel when the layer has enough tiles to keep one workgroup per CU busy
+            const TileCfg *scfg = stream_cfg_find(cfg->geo, cfg->nt, cfg->cg);
+            const bool use_stream = scfg && scfg->tz == cfg->tz && scfg->ty == cfg->ty && scfg->tx == cfg->tx &&
+                                    t.total_tiles >= 1024 && getenv_flag("DFFW_STREAM");   // opt-in: measured slower than conv_tile
+            if (use_stream) t.grid = 256;   // 8 XCDs x 32 CUs, one resident workgroup each
             if (e->profiling) {
                 char kn[96];
-                conv_tile_kernel_name(e->prec, cfg, kn, sizeof kn);
+                if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
+                else conv_tile_kernel_name(e->prec, cfg, kn, sizeof kn);
                 const double opx = (double)out.B * No * Ho * Wo;
                 const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
                                      + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
                                      + opx * L.cout * elem_bytes() * ((o.res0 ? 1 : 0) + (o.res1 ? 1 : 0))
                                      + (double)L.kd * L.kh * L.kw * L.cin * L.cout * elem_bytes();
                 prof_begin(kn, name, flops, bytes);
+            }
+            if (use_stream) {
+                check(launch_conv_stream(e->prec, scfg, a, t, s), name.c_str());
+                prof_end();
+                return out;
             }
             check(launch_conv_tile(e->prec, cfg, a, t, s), name.c_str());
             prof_end();
