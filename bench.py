@@ -81,6 +81,21 @@ def roofline_from_profile(model, FS, fd, device):
                              "share_of_forward_time": round(conv_ms / total_ms, 3)},
         "profiled_forward_ms": round(total_ms, 3), "n_launches": len(rows),
     }
+    # HBM traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    # cannot be collected from inside this process) and committed under profiles/; reported only when it
+    # was measured for this very kernel instantiation, else null
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
+            with open(path) as f:
+                tr = json.load(f)
+            if tr.get("kernel") == dom_name:
+                roof["traffic"] = round(tr["hbm_bytes_per_launch"])
+                roof["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / (dom["bytes"] / dom["launches"]), 3)
+                roof["traffic_source"] = os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; gfx950 x2 fetch correction)"
+                break
+    except (OSError, ValueError, KeyError):
+        pass
     per_kernel = {k: {"launches": a["launches"], "ms": round(a["ms"], 3),
                       "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["flops"] else None,
                       "gbs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)} for k, a in sorted(agg.items())}

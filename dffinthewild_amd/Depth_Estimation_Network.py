@@ -67,6 +67,7 @@ class Network(nn.Module):
         self._token = [0]           # bumped by load_state_dict / .to() / .cuda()
         self._guard = threading.Lock()
         self._inherited_fp = None   # set on DataParallel replicas
+        self._tensors = None        # cached list of parameters/buffers for _fingerprint
 
     # ---- weight contract ------------------------------------------------------------------------
     @staticmethod
@@ -106,11 +107,21 @@ class Network(nn.Module):
         """Forget packed weights (call after editing parameters in place)."""
         self._token[0] += 1
         self._engines.clear()
+        self._tensors = None
 
     def _fingerprint(self):
+        """Cheap change detector for the packed-weight cache: a token bumped by load_state_dict/.to() plus
+        the sum of the tensors' in-place version counters (the tensor list itself is cached: walking
+        state_dict() costs milliseconds per call, which would dominate the batch-1 latency)."""
         if self._inherited_fp is not None:
             return self._inherited_fp
-        return (self._token[0], sum(t._version for t in self.state_dict(keep_vars=True).values()))
+        ts = self._tensors
+        if ts is None:
+            ts = self._tensors = list(self.state_dict(keep_vars=True).values())
+        v = 0
+        for t in ts:
+            v += t._version
+        return (self._token[0], v)
 
     def _replicate_for_data_parallel(self):
         fp = self._fingerprint()

@@ -58,9 +58,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     // ---- this workgroup's run of tiles.  XCD x (= blockIdx % 8) owns a contiguous range of the tile
     // sequence (x fastest, then y, z, sample), so neighbouring tiles' halos hit in that XCD's L2; inside
     // the range each workgroup walks t.tpw consecutive tiles. -----------------------------------------
-    // MULTI: a workgroup walks t.tpw consecutive tiles and queues the next tile's footprint DMA before the
-    // current tile's epilogue.  Measured slower on MI355X for every layer of this network (the extra live
-    // state costs occupancy and the exposed latencies are not the limiter), so it is compiled out.
+    // MULTI: a workgroup walks t.tpw consecutive tiles (optionally queueing the next tile's footprint DMA
+    // before the current tile's epilogue, EARLY).  Measured slower on MI355X for every layer of this
+    // network: the compiler keeps the loop-invariant DMA address state live across tiles (104 -> 163 VGPRs
+    // for the dominant instantiation), which costs a resident wave per SIMD.  Compiled out.
     constexpr bool MULTI = false;
     int tile_begin, tile_end;
     {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
 
     // residuals of the final pass are fetched BEFORE the next tile's DMA is queued (loads return in order:
     // fetched after it they would wait for the whole footprint), when the register budget allows
-    constexpr bool EARLY = MULTI && (PIPE == 1) && (NT * MTW <= 10);
+    constexpr bool EARLY = false;
 
     Coord cur = decode(tile_begin);
     if (!(a.dbg & 1)) issue_fill(cur, 0);

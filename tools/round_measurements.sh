@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-end measurement set on one MI355X (run through gpurun); writes into gpurun_out/final/
+set -u
+out=gpurun_out/final; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python bench.py > $out/bench_default.json 2> $out/bench_default.err
+python bench.py --no-cpu-baseline --dump-layers $out/layers_default.tsv > $out/bench_layers.json 2>/dev/null
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $out/bench_torchrun1.json 2> $out/bench_torchrun1.err
+for p in fp16 bf16; do python bench.py --precision $p --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_$p.json 2>/dev/null; done
+python bench.py --batch 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline > $out/bench_b1_10x256.json 2>/dev/null
+python bench.py --batch 1 --slices 5 --size 224 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline > $out/bench_b1_5x224.json 2>/dev/null
+python bench.py --batch 8 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $out/bench_b8.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/rocprof_bench.json 2> $out/rocprof.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+for f in $out/bench_*.json; do echo "$f: $(cut -c1-110 $f)"; done
