@@ -95,15 +95,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
 
     // ---- per-lane constants of each of this wave's operand tiles: LDS byte offset of its grid point, its
     // pixel offset inside the output volume, and its packed tile coordinates (for edge tiles only) --------
-    int pofs[MTW], ooff[MTW], tcrd[MTW];
+    int pofs[MTW], voff[MTW], tcrd[MTW];
+    const int lanepart = (PARTS == 2) ? (g & 1) * a.Cout + (g >> 1) * 8 : g * 4;   // this lane's piece of a pixel record
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
         const int p = (wave * MTW + j) * 16 + r;
         const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
         pofs[j] = ((tz * T::FY + ty * G::S) * T::FXL + tx) * PIXB;
-        ooff[j] = (tz * a.Ho + ty * G::OS) * a.Wo + tx * G::OS;
+        voff[j] = ((tz * a.Ho + ty * G::OS) * a.Wo + tx * G::OS) * (PARTS * a.Cout) + lanepart;
         tcrd[j] = tx | (ty << 8) | (tz << 16);
     }
+    // BatchNorm shift of this lane's 4 output channels per 16-channel tile: the accumulators start from it
+    f32x4 bias4[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
 
     const int ps0 = PARTS * a.C0, ps1 = PARTS * a.C1;
     const int64_t samp0 = (int64_t)a.Ni * a.Hi * a.Wi * ps0, samp1 = (int64_t)a.Ni * a.Hi * a.Wi * ps1;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < MTW; ++j) acc[nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < MTW; ++j) acc[nt][j] = bias4[nt];
 
             const int KC = t.KC[pass];
             const int *tab = t.tab[pass] + g;
@@ -289,17 +294,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
             // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) ---------------------------
             const int ooy = t.ooy[pass], oox = t.oox[pass];
             const bool last_pass = pass == G::NPASS - 1;
-            // output pixel of operand tile j = tile base (wave-uniform) + the lane's precomputed offset; the
+            // output location of operand tile j = tile base (wave-uniform) + the lane's precomputed offset; the
             // bounds test is only evaluated for tiles that stick out of the volume
             const int64_t obase = (((int64_t)cur.b * a.No + cur.gz0) * a.Ho + (cur.gy0 * G::OS + ooy)) * a.Wo + (cur.gx0 * G::OS + oox);
+            const int64_t ubase = obase * (PARTS * a.Cout);
             const bool interior = cur.gz0 + TZ <= a.Ng && cur.gy0 + TY <= a.Hg && cur.gx0 + TX <= a.Wg;
             auto where = [&](int j, int64_t &opix) -> bool {
-                opix = obase + ooff[j];
+                const int c = tcrd[j];
+                opix = obase + (((c >> 16) * a.Ho + ((c >> 8) & 255) * G::OS) * a.Wo + (c & 255) * G::OS);   // only read by the score paths
                 bool ok = true;
-                if (!interior) {
-                    const int c = tcrd[j];
-                    ok = cur.gz0 + (c >> 16) < a.Ng && cur.gy0 + ((c >> 8) & 255) < a.Hg && cur.gx0 + (c & 255) < a.Wg;
-                }
+                if (!interior) ok = cur.gz0 + (c >> 16) < a.Ng && cur.gy0 + ((c >> 8) & 255) < a.Hg && cur.gx0 + (c & 255) < a.Wg;
                 if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
                 return ok;
             };
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                         const bool pv = where(j, opix);
                         float cls = 0.f;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true>(a, acc[nt][j], nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j]);
+                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true, true>(a, acc[nt][j], nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j], ubase, voff[j]);
                         epilogue_cls(a, cls, g, opix, pv);
                     }
                     continue;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                 const bool pv = where(j, opix);
                 float cls = 0.f;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{});
+                for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
                 epilogue_cls(a, cls, g, opix, pv);
             }
             if constexpr (!EARLY) {
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
 //        id  geo   NT  TZ TY  TX  CG
 #define DFFW_TILE_CONFIGS(X)         \
     X(0, G3S1, 1, 5, 4, 16, 16, 1)   \
-    X(1, G3S1, 1, 5, 8, 16, 8, 1)    \
+    X(1, G3S1, 1, 5, 4, 16, 8, 1)    \
     X(2, G3S1, 2, 5, 4, 16, 16, 1)   \
     X(3, G3S1, 4, 5, 4, 16, 16, 1)   \
     X(4, G3S1, 8, 4, 4, 8, 16, 1)    \

@@ -134,17 +134,21 @@ __device__ __forceinline__ uint4 epilogue_res_load(const ConvArgs &a, const uint
     return q;
 }
 
-// PRE: the residual pieces were fetched earlier with epilogue_res_load (pre0/pre1), else they are loaded here
-template <int PREC, bool PRE>
+// PRE: the residual pieces were fetched earlier with epilogue_res_load (pre0/pre1), else they are loaded here.
+// FAST (conv_tile): the BatchNorm shift is already in the accumulator (it was initialised with it) and the
+// lane's element offset inside the output volume is `voff` (32-bit, precomputed once per kernel: pixel
+// offset inside the tile * record size + this lane's 16-byte piece) relative to the wave-uniform element
+// offset `ubase` of the tile, so a store costs no per-lane 64-bit address arithmetic.
+template <int PREC, bool PRE, bool FAST = false>
 __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &accq, int nt, int g, int64_t opix, bool pvalid,
-                                              float &cls_partial, uint4 pre0, uint4 pre1) {
+                                              float &cls_partial, uint4 pre0, uint4 pre1, int64_t ubase = 0, int voff = 0) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     const int Cout = a.Cout;
     const int c0 = nt * 16 + g * 4;
     const bool cvalid = c0 < Cout;
     float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = accq[i] + a.bias[c0 + i];   // bias is zero-padded to the kernel's NT*16 channels
+    for (int i = 0; i < 4; ++i) v[i] = FAST ? accq[i] : accq[i] + a.bias[c0 + i];   // bias is zero-padded to the kernel's NT*16 channels
     if (a.outf) {  // 1-channel fp32 score volume (B,No,Ho,Wo)
         if (pvalid && c0 == 0) a.outf[opix] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
         return;
@@ -152,8 +156,9 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
     if constexpr (PARTS == 2) {
         const int oct = nt * 2 + (g >> 1);                 // which 8-channel group this lane moves
         const bool wvalid = pvalid && oct * 8 < Cout;
-        const int64_t eo = opix * (2 * Cout) + (g & 1) * Cout + oct * 8;
-        auto wide_store = [&](uint16_t *base) {
+        const int64_t eo = FAST ? (int64_t)(voff + nt * 16) : opix * (2 * Cout) + (g & 1) * Cout + oct * 8;
+        auto wide_store = [&](uint16_t *base_) {
+            uint16_t *base = FAST ? base_ + ubase : base_;
             uint32_t h01, h23, l01, l23;
             Fmt<PREC>::split2(v[0], v[1], h01, l01);
             Fmt<PREC>::split2(v[2], v[3], h23, l23);
@@ -161,7 +166,8 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
             swap16(h23, l23);
             if (wvalid) *reinterpret_cast<uint4 *>(base + eo) = make_uint4(h01, h23, l01, l23);
         };
-        auto wide_add = [&](const uint16_t *base, uint4 q) {
+        auto wide_add = [&](const uint16_t *base_, uint4 q) {
+            const uint16_t *base = FAST ? base_ + ubase : base_;
             if constexpr (!PRE) {
                 q = make_uint4(0, 0, 0, 0);
                 if (wvalid) q = *reinterpret_cast<const uint4 *>(base + eo);
@@ -194,14 +200,16 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
         if (a.out) wide_store(a.out);
     } else {
         const bool ok = pvalid && cvalid;
-        const int64_t eo = opix * Cout + c0;
-        auto store4 = [&](uint16_t *base) {
+        const int64_t eo = FAST ? (int64_t)(voff + nt * 16) : opix * Cout + c0;
+        auto store4 = [&](uint16_t *base_) {
+            uint16_t *base = FAST ? base_ + ubase : base_;
             uint32_t h01, h23, l01, l23;
             Fmt<PREC>::split2(v[0], v[1], h01, l01);
             Fmt<PREC>::split2(v[2], v[3], h23, l23);
             if (ok) *reinterpret_cast<uint2 *>(base + eo) = make_uint2(h01, h23);
         };
-        auto add4 = [&](const uint16_t *base, uint4 q) {
+        auto add4 = [&](const uint16_t *base_, uint4 q) {
+            const uint16_t *base = FAST ? base_ + ubase : base_;
             if constexpr (!PRE) {
                 q = make_uint4(0, 0, 0, 0);
                 if (ok) {
