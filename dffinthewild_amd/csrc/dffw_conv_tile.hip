@@ -160,6 +160,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         const bool has_next = MULTI && tile + 1 < tile_end;
         const Coord nxt = has_next ? decode(tile + 1) : cur;
 
+#pragma unroll 1   // one accumulator set live at a time
         for (int pass = 0; pass < G::NPASS; ++pass) {
             f32x4 acc[NT][MTW];
 #pragma unroll
@@ -336,14 +337,48 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     continue;
                 }
             }
+            if (NT == 1 && a.Cout == 8 && !a.outf) {
+                // 8 output channels occupy only lane rows 0-1 of a result tile: pack operand tiles j and j+1 into
+                // one register set (rows 2-3 <- rows 0-1 of tile j+1, v_permlane32_swap) and run ONE epilogue for both
 #pragma unroll
-            for (int j = 0; j < MTW; ++j) {
-                int64_t opix;
-                const bool pv = where(j, opix);
-                float cls = 0.f;
+                for (int j = 0; j < MTW; j += 2) {
+                    if (j + 1 < MTW) {
+                        f32x4 q;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
-                epilogue_cls(a, cls, g, opix, pv);
+                        for (int i = 0; i < 4; ++i) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][j][i]), __float_as_uint(acc[0][j + 1][i]), false, false);
+                            q[i] = __uint_as_float(sw[0]);   // lanes 0-31: tile j, lanes 32-63: lanes 0-31 of tile j+1
+                        }
+                        int64_t o0, o1;
+                        const bool p0 = where(j, o0), p1 = where(j + 1, o1);
+                        const bool up = lane >= 32;
+                        const int64_t opix = up ? o1 : o0;
+                        const bool pv = up ? p1 : p0;
+                        // lanes 32-63 carry rows 0-1 of tile j+1: their piece of the record is that of row g-2
+                        const int vo = up ? voff[j + 1] - ((PARTS == 2) ? 8 : 8) : voff[j];
+                        float cls = 0.f;
+                        epilogue_quad<PREC, false, true>(a, q, 0, g & 1, opix, pv, cls, uint4{}, uint4{}, ubase, vo);
+                        epilogue_cls(a, cls, g, opix, pv, 2);
+                        __builtin_amdgcn_sched_barrier(0);   // keep the unrolled iterations' live ranges apart (occupancy)
+                    } else {
+                        int64_t opix;
+                        const bool pv = where(j, opix);
+                        float cls = 0.f;
+                        epilogue_quad<PREC, false, true>(a, acc[0][j], 0, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
+                        epilogue_cls(a, cls, g, opix, pv);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    int64_t opix;
+                    const bool pv = where(j, opix);
+                    float cls = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
+                    epilogue_cls(a, cls, g, opix, pv);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if constexpr (!EARLY) {
                 if (last_pass && has_next && !(a.dbg & 1)) {
@@ -371,8 +406,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     X(9, G3T, 1, 5, 4, 16, 16, 0)    \
     X(10, G3T, 2, 5, 4, 16, 16, 1)   \
     X(11, G3T, 4, 5, 4, 16, 16, 1)   \
-    X(12, G2S1, 1, 5, 8, 16, 8, 0)   \
-    X(13, G2S1, 1, 5, 8, 16, 16, 0)  \
+    X(12, G2S1, 1, 5, 4, 16, 8, 0)   \
+    X(13, G2S1, 1, 5, 4, 16, 16, 0)  \
     X(14, G2S1, 2, 5, 8, 16, 16, 0)  \
     X(15, G2D, 1, 1, 16, 32, 8, 0)
 

@@ -107,6 +107,9 @@ __device__ __forceinline__ f32x4 mma(short8 a, short8 b, f32x4 c) {
 // halves of lane rows g and g^1 are exchanged with v_permlane16_swap so that every lane moves one
 // 16-byte piece (8 channels of one half) per access instead of two 8-byte pieces, i.e. a wave store
 // covers 16 pixels x 64 contiguous bytes.  `pvalid`: the lane's grid point exists.
+// relu as a signed-integer max on the bit pattern: one instruction, no float canonicalisation in front
+__device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
 __device__ __forceinline__ void swap16(uint32_t &a, uint32_t &b) {
     // a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3} (rows = 16-lane groups)
     const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
@@ -185,13 +188,13 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
         if (a.out_pre) wide_store(a.out_pre);
         if (a.relu == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu_bits(v[i]);
         }
         if (a.res0) wide_add(a.res0, pre0);
         if (a.res1) wide_add(a.res1, pre1);
         if (a.relu == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu_bits(v[i]);
         }
         if (a.cls_w && cvalid) {
 #pragma unroll
@@ -229,13 +232,13 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
         if (a.out_pre) store4(a.out_pre);
         if (a.relu == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu_bits(v[i]);
         }
         if (a.res0) add4(a.res0, pre0);
         if (a.res1) add4(a.res1, pre1);
         if (a.relu == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < 4; ++i) v[i] = relu_bits(v[i]);
         }
         if (a.cls_w && cvalid) {
 #pragma unroll
@@ -246,11 +249,13 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
 }
 
 // finish the fused 1x1x1 classifier: sum the partial dots of the 4 lane rows, row 0 writes the score
-__device__ __forceinline__ void epilogue_cls(const ConvArgs &a, float partial, int g, int64_t opix, bool pvalid) {
+// `rows`: how many 16-lane rows hold channels of the SAME pixel (4 normally; 2 when two 8-channel operand
+// tiles were packed into one register set, then rows 0-1 and 2-3 are different pixels)
+__device__ __forceinline__ void epilogue_cls(const ConvArgs &a, float partial, int g, int64_t opix, bool pvalid, int rows = 4) {
     if (!a.cls_w) return;
     partial += __shfl_xor(partial, 16);
-    partial += __shfl_xor(partial, 32);
-    if (g == 0 && pvalid) a.cls_out[opix] = partial;
+    if (rows == 4) partial += __shfl_xor(partial, 32);
+    if ((g & (rows - 1)) == 0 && pvalid) a.cls_out[opix] = partial;
 }
 
 }  // namespace dffw
