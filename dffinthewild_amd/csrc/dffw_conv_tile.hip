@@ -106,6 +106,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         tcrd[j] = tx | (ty << 8) | (tz << 16);
     }
     // BatchNorm shift of this lane's 4 output channels per 16-channel tile: the accumulators start from it
+    // (not for the 4-pass transposed conv: there hipcc then allocates three accumulator sets)
+    constexpr bool BIAS_IN_ACC = (GEO != G3T);
     f32x4 bias4[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
@@ -160,19 +162,28 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         const bool has_next = MULTI && tile + 1 < tile_end;
         const Coord nxt = has_next ? decode(tile + 1) : cur;
 
+        f32x4 acc[NT][MTW];
 #pragma unroll 1   // one accumulator set live at a time
         for (int pass = 0; pass < G::NPASS; ++pass) {
-            f32x4 acc[NT][MTW];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < MTW; ++j) acc[nt][j] = bias4[nt];
+                for (int j = 0; j < MTW; ++j) acc[nt][j] = BIAS_IN_ACC ? bias4[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
 
             const int KC = t.KC[pass];
             const int *tab = t.tab[pass] + g;
 
             for (int st = 0; st < t.nstage; ++st) {
                 const bool prefilled = (pass == 0 && st == 0);   // queued by the prologue / the previous tile's epilogue
+                // first chunk's weight fragments and tap offset: requested BEFORE waiting for the footprint DMA so
+                // that their L2 latency overlaps it
+                const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
+                short8 wfirst[NT][PARTS];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int pt = 0; pt < PARTS; ++pt) wfirst[nt][pt] = wp[(nt * PARTS + pt) * 64];
+                const int tfirst = tab[0];
                 if ((pass == 0 || t.nstage > 1) && !(a.dbg & 1)) {
                     if (!prefilled) {
                         __syncthreads();  // everyone is done reading the previous image
@@ -186,14 +197,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                 if constexpr (PIPE == 0) {
                     // Lean loop for bandwidth-bound layers: few registers -> 4-5 workgroups per CU hide the
                     // fill / residual / store latencies by occupancy instead of by software pipelining.
-                    const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
+                    short8 wf[NT][PARTS], wn[NT][PARTS];
+                    int toff = tfirst, tn = 0;
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+    #pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt) wf[nt][pt] = wfirst[nt][pt];
                     for (int kc = 0; kc < ((a.dbg & 2) ? 1 : KC); ++kc) {
-                        short8 wf[NT][PARTS];
+                        if (kc + 1 < KC) {   // next chunk's fragments travel under this chunk's MFMAs
     #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = 0; nt < NT; ++nt)
     #pragma unroll
-                            for (int pt = 0; pt < PARTS; ++pt) wf[nt][pt] = wp[((int64_t)kc * NT * PARTS + nt * PARTS + pt) * 64];
-                        const int toff = tab[kc * 4];
+                                for (int pt = 0; pt < PARTS; ++pt) wn[nt][pt] = wp[((int64_t)(kc + 1) * NT * PARTS + nt * PARTS + pt) * 64];
+                            tn = tab[(kc + 1) * 4];
+                        }
     #pragma unroll
                         for (int j = 0; j < MTW; ++j) {
                             const unsigned char *lp = smem + pofs[j] + toff;
@@ -209,6 +226,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                                 acc[nt][j] = mma<F16>(wf[nt][0], xh, acc[nt][j]);
                             }
                         }
+    #pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+    #pragma unroll
+                            for (int pt = 0; pt < PARTS; ++pt) wf[nt][pt] = wn[nt][pt];
+                        toff = tn;
                     }
                 } else {
                     // Software pipeline: the wave's MTW operand tiles are split into two groups; while the matrix
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                         const bool pv = where(j, opix);
                         float cls = 0.f;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true, true>(a, acc[nt][j], nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j], ubase, voff[j]);
+                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true, true, !BIAS_IN_ACC>(a, acc[nt][j], nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j], ubase, voff[j]);
                         epilogue_cls(a, cls, g, opix, pv);
                     }
                     continue;
@@ -357,14 +379,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                         // lanes 32-63 carry rows 0-1 of tile j+1: their piece of the record is that of row g-2
                         const int vo = up ? voff[j + 1] - ((PARTS == 2) ? 8 : 8) : voff[j];
                         float cls = 0.f;
-                        epilogue_quad<PREC, false, true>(a, q, 0, g & 1, opix, pv, cls, uint4{}, uint4{}, ubase, vo);
+                        epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, q, 0, g & 1, opix, pv, cls, uint4{}, uint4{}, ubase, vo);
                         epilogue_cls(a, cls, g, opix, pv, 2);
                         __builtin_amdgcn_sched_barrier(0);   // keep the unrolled iterations' live ranges apart (occupancy)
                     } else {
                         int64_t opix;
                         const bool pv = where(j, opix);
                         float cls = 0.f;
-                        epilogue_quad<PREC, false, true>(a, acc[0][j], 0, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
+                        epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, acc[0][j], 0, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
                         epilogue_cls(a, cls, g, opix, pv);
                     }
                 }
@@ -375,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     const bool pv = where(j, opix);
                     float cls = 0.f;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
+                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
                     epilogue_cls(a, cls, g, opix, pv);
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -142,7 +142,7 @@ __device__ __forceinline__ uint4 epilogue_res_load(const ConvArgs &a, const uint
 // lane's element offset inside the output volume is `voff` (32-bit, precomputed once per kernel: pixel
 // offset inside the tile * record size + this lane's 16-byte piece) relative to the wave-uniform element
 // offset `ubase` of the tile, so a store costs no per-lane 64-bit address arithmetic.
-template <int PREC, bool PRE, bool FAST = false>
+template <int PREC, bool PRE, bool FAST = false, bool ADD_BIAS = !FAST>
 __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &accq, int nt, int g, int64_t opix, bool pvalid,
                                               float &cls_partial, uint4 pre0, uint4 pre1, int64_t ubase = 0, int voff = 0) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
     const bool cvalid = c0 < Cout;
     float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = FAST ? accq[i] : accq[i] + a.bias[c0 + i];   // bias is zero-padded to the kernel's NT*16 channels
+    for (int i = 0; i < 4; ++i) v[i] = ADD_BIAS ? accq[i] + a.bias[c0 + i] : accq[i];   // bias is zero-padded to the kernel's NT*16 channels
     if (a.outf) {  // 1-channel fp32 score volume (B,No,Ho,Wo)
         if (pvalid && c0 == 0) a.outf[opix] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
         return;
