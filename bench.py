@@ -48,7 +48,7 @@ def build_model(precision, device):
     return model.to(device).eval(), sd
 
 
-def roofline_from_profile(model, FS, fd, device):
+def roofline_from_profile(model, FS, fd, device, precision="bf16x3"):
     eng = model._engine_on(device)
     eng.profile(True)
     with torch.no_grad():
@@ -66,21 +66,40 @@ def roofline_from_profile(model, FS, fd, device):
     total_ms = sum(a["ms"] for a in agg.values())
     conv = {k: a for k, a in agg.items() if "::conv_" in k}   # the MFMA implicit-GEMM kernels (conv_tile / conv_igemm)
     dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     conv_flops = sum(a["flops"] for a in conv.values())
     conv_ms = sum(a["ms"] for a in conv.values())
+
+    def fractions(a):
+        tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+        return tf, gbs, tf / PEAK_MFMA_TFLOPS, gbs / PEAK_HBM_GBS
+
+    tf, gbs, f_mfma, f_hbm = fractions(dom)
+    hbm_bound = f_hbm >= f_mfma          # the roof the kernel sits closer to is the one that binds it
     roof = {
-        "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+        "bound": "hbm" if hbm_bound else "mfma", "kernel": dom_name,
+        "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
+        "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(f_hbm if hbm_bound else f_mfma, 4), "traffic": None,
         "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
         "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
         "algorithmic_gb_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
+        "tflops": round(tf, 2), "frac_mfma": round(f_mfma, 4), "algorithmic_gbs": round(gbs, 1), "frac_hbm": round(f_hbm, 4),
         "share_of_forward_time": round(dom["ms"] / total_ms, 3),
         "all_conv_kernels": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                              "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
                              "share_of_forward_time": round(conv_ms / total_ms, 3)},
         "profiled_forward_ms": round(total_ms, 3), "n_launches": len(rows),
     }
+    # the heaviest kernel that is MFMA-bound by the same criterion (the 3x3x3 aggregation convs of the north star)
+    mf = {k: a for k, a in conv.items() if fractions(a)[2] > fractions(a)[3]}
+    if mf:
+        mk, ma = max(mf.items(), key=lambda kv: kv[1]["ms"])
+        mtf, mgbs, mfm, mfh = fractions(ma)
+        roof["top_mfma_bound_kernel"] = {"kernel": mk, "achieved": round(mtf, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(mfm, 4),
+                                         "frac_of_split_bf16_ceiling": round(mfm * 3, 4) if precision == "bf16x3" else None,
+                                         "launches": ma["launches"], "avg_launch_ms": round(ma["ms"] / ma["launches"], 4),
+                                         "share_of_forward_time": round(ma["ms"] / total_ms, 3)}
     # HBM traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
     # cannot be collected from inside this process) and committed under profiles/; reported only when it
     # was measured for this very kernel instantiation, else null
@@ -217,7 +236,7 @@ def main():
             "forward_tflops_algorithmic": round(value * GFLOP_PER_STACK * scale / 1e3, 2),
         }
     if rank == 0 and not args.no_roofline:
-        roof, per_kernel, rows = roofline_from_profile(model, FS, fd, device)
+        roof, per_kernel, rows = roofline_from_profile(model, FS, fd, device, args.precision)
         result["roofline"] = roof
         result["kernels"] = per_kernel
         if args.dump_layers:
