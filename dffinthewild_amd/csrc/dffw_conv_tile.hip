@@ -129,25 +129,43 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         const int cc = second ? ch - a.C0 : ch;
         const int csrc = second ? a.C1 : a.C0;
         const uint16_t *sp = second ? a.in1 + c.b * samp1 : a.in0 + c.b * samp0;
+        // footprint coordinates of this lane's pixel: decoded once, then advanced incrementally by the constant
+        // step of PPW*NWAVES pixels per iteration (no div/mod in the loop); row/column bounds tests are skipped
+        // for tiles whose footprint lies inside the image (wave-uniform), the slice test is always per lane
+        constexpr int STEP = PPW * NWAVES;
+        constexpr int DLX = STEP % T::FXL, DFY = (STEP / T::FXL) % T::FY, DFZ = STEP / (T::FXL * T::FY);
+        const int p0 = wave * PPW + lane / CG8;
+        int lx = p0 % T::FXL, fy = (p0 / T::FXL) % T::FY, fz = p0 / (T::FXL * T::FY);
+        const bool yx_in = iy0 >= 0 && iy0 + T::FY <= a.Hi && ix0 >= 0 && ix0 + T::FX <= a.Wi;
+        const int pst = PARTS * csrc;
 #pragma unroll
         for (int it = 0; it < NPI; ++it) {
             const int pbase = (it * NWAVES + wave) * PPW;              // wave-uniform first pixel
             if (pbase >= T::FPIX) break;
-            const int p = pbase + lane / CG8;
-            const int lx = p % T::FXL;
-            const int fy = (p / T::FXL) % T::FY;
-            const int fz = p / (T::FXL * T::FY);
             const int fx = (G::S == 2) ? (lx < T::FXL / 2 ? 2 * lx : 2 * (lx - T::FXL / 2) + 1) : lx;
             const int iz = iz0 + fz, iy = iy0 + fy, ix = ix0 + fx;
-            const bool ok = p < T::FPIX && fx < T::FX && (unsigned)iz < (unsigned)a.Ni && (unsigned)iy < (unsigned)a.Hi &&
-                            (unsigned)ix < (unsigned)a.Wi;
-            const uint16_t *gp = sp + ((int64_t)((iz * a.Hi + iy) * a.Wi + ix) * (PARTS * csrc) + cc);
+            bool ok = (unsigned)iz < (unsigned)a.Ni;
+            if ((it + 1) * STEP > T::FPIX) ok = ok && (pbase + lane / CG8 < T::FPIX);   // only the last iteration can run past the image
+            if (T::FXL > T::FX) ok = ok && fx < T::FX;                                   // pad column of the de-interleaved layout
+            if (!yx_in) ok = ok && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const uint16_t *gp = sp + ((int64_t)(((iz * a.Hi + iy) * a.Wi + ix) * pst) + cc);
 #pragma unroll
             for (int part = 0; part < PARTS; ++part) {
                 const uint16_t *src = ok ? gp + part * csrc : a.zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(smem + part * PLANEB + pbase * PIXB), 16, 0, 0);
             }
+            lx += DLX;
+            if (lx >= T::FXL) {
+                lx -= T::FXL;
+                fy += 1;
+            }
+            fy += DFY;
+            if (fy >= T::FY) {
+                fy -= T::FY;
+                fz += 1;
+            }
+            fz += DFZ;
         }
     };
 
