@@ -49,12 +49,16 @@ struct TileArgs {
     int ooy[4], oox[4];       // output sub-pixel phase of each pass
     int tiles_z, tiles_y, tiles_x;
     int total_tiles;
+    int nt_total;             // 16-channel output tiles of the layer (weights are packed for all of them)
+    int nsplit;               // grid.y: output-channel split, each workgroup produces nt_total/nsplit tiles
     int tpw;                  // consecutive tiles walked by one workgroup
     int grid;                 // workgroups to launch = 8 * ceil(ceil(total_tiles/8) / tpw)
 };
 
 // returns nullptr when no instantiation covers (geo, nt, cg)
 const TileCfg *tile_cfg_find(int geo, int nt, int cg);
+// configuration with the same geometry, channel group and TILE SHAPE as `base` but `nt` output tiles (for splits)
+const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt);
 int tile_cfg_count();
 const TileCfg *tile_cfg_at(int i);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);

@@ -54,6 +54,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
+    // output-channel split (few-tile layers): blockIdx.y selects which NT of the layer's t.nt_total 16-channel
+    // tiles this workgroup produces, so small grids still spread over the chip
+    const int ntb = blockIdx.y * NT;
+    const int NTT = t.nt_total;
 
     // ---- this workgroup's run of tiles.  XCD x (= blockIdx % 8) owns a contiguous range of the tile
     // sequence (x fastest, then y, z, sample), so neighbouring tiles' halos hit in that XCD's L2; inside
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     constexpr bool BIAS_IN_ACC = (GEO != G3T);
     f32x4 bias4[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+    for (int nt = 0; nt < NT; ++nt) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + (ntb + nt) * 16 + g * 4);
 
     const int ps0 = PARTS * a.C0, ps1 = PARTS * a.C1;
     const int64_t samp0 = (int64_t)a.Ni * a.Hi * a.Wi * ps0, samp1 = (int64_t)a.Ni * a.Hi * a.Wi * ps1;
@@ -195,7 +199,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                 const bool prefilled = (pass == 0 && st == 0);   // queued by the prologue / the previous tile's epilogue
                 // first chunk's weight fragments and tap offset: requested BEFORE waiting for the footprint DMA so
                 // that their L2 latency overlaps it
-                const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
+                const int wstride = NTT * PARTS * 64;   // fragments (16 B per lane) per 32-deep chunk
+                const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * wstride + ntb * PARTS * 64 + lane;
                 short8 wfirst[NT][PARTS];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
     #pragma unroll
-                                for (int pt = 0; pt < PARTS; ++pt) wn[nt][pt] = wp[((int64_t)(kc + 1) * NT * PARTS + nt * PARTS + pt) * 64];
+                                for (int pt = 0; pt < PARTS; ++pt) wn[nt][pt] = wp[(int64_t)(kc + 1) * wstride + (nt * PARTS + pt) * 64];
                             tn = tab[(kc + 1) * 4];
                         }
     #pragma unroll
@@ -255,16 +260,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     // cores work on one group's operands the ds_reads of the other group (same chunk or the next
                     // one) are in flight.  Within a group the three split-bf16 products are issued product-major so
                     // consecutive MFMAs never share an accumulator.
-                    const short8 *wp = reinterpret_cast<const short8 *>(t.wpk[pass]) + (int64_t)st * KC * (NT * PARTS * 64) + lane;
                     constexpr int GA = MTW / 2, GB = MTW - GA;
                     short8 wcur[NT][PARTS], wnxt[NT][PARTS];
                     short8 xa[GA][PARTS], xb[GB][PARTS];
-                    int tcur, tnxt = 0;
+                    int tcur = tfirst, tnxt = 0;
         #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
         #pragma unroll
-                        for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wp[(nt * PARTS + pt) * 64];
-                    tcur = tab[0];
+                        for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wfirst[nt][pt];
         #pragma unroll
                     for (int j = 0; j < GA; ++j)
         #pragma unroll
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     for (int kc = 0; kc < ((a.dbg & 2) ? 1 : KC); ++kc) {
                         const bool more = kc + 1 < KC;
                         if (more) {
-                            const short8 *wn = wp + (int64_t)(kc + 1) * (NT * PARTS * 64);
+                            const short8 *wn = wp + (int64_t)(kc + 1) * wstride;
         #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
         #pragma unroll
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                         const bool pv = where(j, opix);
                         float cls = 0.f;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true, true, !BIAS_IN_ACC>(a, acc[nt][j], nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j], ubase, voff[j]);
+                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true, true, !BIAS_IN_ACC>(a, acc[nt][j], ntb + nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j], ubase, voff[j]);
                         epilogue_cls(a, cls, g, opix, pv);
                     }
                     continue;
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     const bool pv = where(j, opix);
                     float cls = 0.f;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, acc[nt][j], nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
+                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, acc[nt][j], ntb + nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
                     epilogue_cls(a, cls, g, opix, pv);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -449,7 +452,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     X(12, G2S1, 1, 5, 4, 16, 8, 0)   \
     X(13, G2S1, 1, 5, 4, 16, 16, 0)  \
     X(14, G2S1, 2, 5, 8, 16, 16, 0)  \
-    X(15, G2D, 1, 1, 16, 32, 8, 0)
+    X(15, G2D, 1, 1, 16, 32, 8, 0)   \
+    X(16, G3S1, 2, 4, 4, 8, 16, 1)   \
+    X(17, G3S2, 2, 4, 4, 8, 8, 1)
 
 #define X_CFG(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                             \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
@@ -465,6 +470,12 @@ const TileCfg *tile_cfg_find(int geo, int nt, int cg) {
     return nullptr;
 }
 
+const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt) {
+    for (const TileCfg &c : g_cfgs)
+        if (c.geo == base->geo && c.cg == base->cg && c.nt == nt && c.tz == base->tz && c.ty == base->ty && c.tx == base->tx) return &c;
+    return nullptr;
+}
+
 void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
     snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe);
 }
@@ -474,7 +485,7 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
     switch (cfg->id) {
 #define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid), dim3(NTHREADS), 0, s, a, t); \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit), dim3(NTHREADS), 0, s, a, t); \
         break;
         DFFW_TILE_CONFIGS(X_LAUNCH)
 #undef X_LAUNCH

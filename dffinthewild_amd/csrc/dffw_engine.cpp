@@ -683,7 +683,7 @@ struct Run {
         const bool use_tile = tp.cfg && !getenv_flag("DFFW_NO_TILE") && gW * 2 >= tp.cfg->tx && gH * 2 >= tp.cfg->ty &&
                               in0.C % 8 == 0 && (!o.in1 || o.in1->C % 8 == 0);
         if (use_tile) {
-            const TileCfg *cfg = tp.cfg;
+            const TileCfg *cfg = tp.cfg;   // may be replaced by a narrower instantiation of the same tile (channel split)
             a.Ng = L.transposed ? in0.N : No;
             a.Hg = gH;
             a.Wg = gW;
@@ -707,6 +707,20 @@ struct Run {
             t.tiles_y = (a.Hg + cfg->ty - 1) / cfg->ty;
             t.tiles_x = (a.Wg + cfg->tx - 1) / cfg->tx;
             t.total_tiles = a.B * t.tiles_z * t.tiles_y * t.tiles_x;
+            t.nt_total = pc.nt;
+            t.nsplit = 1;
+            // few-tile layers (the 1/16..1/32-resolution pyramid, or batch 1): split the output channels over
+            // grid.y so that at least ~one workgroup per CU exists
+            if (t.total_tiles < 256 && pc.nt > 1 && !o.cls && !getenv_flag("DFFW_NO_SPLIT")) {
+                const int want = (256 + t.total_tiles - 1) / t.total_tiles;   // split factor that would fill the chip
+                for (int nts = pc.nt / 2; nts >= 1; nts /= 2) {               // coarsest split first
+                    const TileCfg *c2 = tile_cfg_find_like(tp.cfg, nts);
+                    if (!c2) continue;
+                    cfg = c2;
+                    t.nsplit = pc.nt / nts;
+                    if (t.nsplit >= want) break;
+                }
+            }
             {   // tiles per workgroup
                 t.tpw = 1;   // see MULTI in dffw_conv_tile.hip
                 const int per_xcd = (t.total_tiles + 7) / 8;
