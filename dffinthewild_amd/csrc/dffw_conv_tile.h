@@ -51,8 +51,7 @@ struct TileArgs {
     int total_tiles;
     int nt_total;             // 16-channel output tiles of the layer (weights are packed for all of them)
     int nsplit;               // grid.y: output-channel split, each workgroup produces nt_total/nsplit tiles
-    int tpw;                  // consecutive tiles walked by one workgroup
-    int grid;                 // workgroups to launch = 8 * ceil(ceil(total_tiles/8) / tpw)
+    int grid;                 // workgroups to launch along x = 8 * ceil(total_tiles / 8) (one tile each)
 };
 
 // returns nullptr when no instantiation covers (geo, nt, cg)

@@ -59,25 +59,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     const int ntb = blockIdx.y * NT;
     const int NTT = t.nt_total;
 
-    // ---- this workgroup's run of tiles.  XCD x (= blockIdx % 8) owns a contiguous range of the tile
-    // sequence (x fastest, then y, z, sample), so neighbouring tiles' halos hit in that XCD's L2; inside
-    // the range each workgroup walks t.tpw consecutive tiles. -----------------------------------------
-    // MULTI: a workgroup walks t.tpw consecutive tiles (optionally queueing the next tile's footprint DMA
-    // before the current tile's epilogue, EARLY).  Measured slower on MI355X for every layer of this
-    // network: the compiler keeps the loop-invariant DMA address state live across tiles (104 -> 163 VGPRs
-    // for the dominant instantiation), which costs a resident wave per SIMD.  Compiled out.
-    constexpr bool MULTI = false;
-    int tile_begin, tile_end;
+    // ---- this workgroup's tile.  XCD x (= blockIdx % 8) owns a contiguous range of the tile sequence (x
+    // fastest, then y, z, sample) so neighbouring tiles' halos hit in that XCD's L2.  (A variant walking
+    // several tiles per workgroup, with the next tile's DMA queued before the epilogue, was measured slower:
+    // hipcc keeps the DMA address state live across tiles, 104 -> 163 VGPRs, one wave per SIMD lost.) ------
+    int tile;
     {
         const int bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3;
         const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
         const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
         const int xe = xs + q + (xcd < rem ? 1 : 0);
-        const int tpw = MULTI ? t.tpw : 1;
-        tile_begin = xs + idx * tpw;
-        tile_end = min(tile_begin + tpw, xe);
-        if (tile_begin >= tile_end) return;
+        tile = xs + idx;
+        if (tile >= xe) return;
     }
 
     struct Coord {
@@ -173,17 +167,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         }
     };
 
-    // residuals of the final pass are fetched BEFORE the next tile's DMA is queued (loads return in order:
-    // fetched after it they would wait for the whole footprint), when the register budget allows
-    constexpr bool EARLY = false;
-
-    Coord cur = decode(tile_begin);
+    const Coord cur = decode(tile);
     if (!(a.dbg & 1)) issue_fill(cur, 0);
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const bool has_next = MULTI && tile + 1 < tile_end;
-        const Coord nxt = has_next ? decode(tile + 1) : cur;
-
+    {
         f32x4 acc[NT][MTW];
 #pragma unroll 1   // one accumulator set live at a time
         for (int pass = 0; pass < G::NPASS; ++pass) {
@@ -196,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
             const int *tab = t.tab[pass] + g;
 
             for (int st = 0; st < t.nstage; ++st) {
-                const bool prefilled = (pass == 0 && st == 0);   // queued by the prologue / the previous tile's epilogue
+                const bool prefilled = (pass == 0 && st == 0);   // queued by the prologue
                 // first chunk's weight fragments and tap offset: requested BEFORE waiting for the footprint DMA so
                 // that their L2 latency overlaps it
                 const int wstride = NTT * PARTS * 64;   // fragments (16 B per lane) per 32-deep chunk
@@ -351,35 +338,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                 if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
                 return ok;
             };
-            if constexpr (EARLY) {
-                if (last_pass && has_next && !(a.dbg & 1)) {
-                    // Overlap the next tile's footprint DMA with this tile's epilogue and store drain: fetch the
-                    // residual pieces first (loads return in order), queue the DMA, then do the arithmetic + stores.
-                    uint4 pre0[NT][MTW], pre1[NT][MTW];
-#pragma unroll
-                    for (int j = 0; j < MTW; ++j) {
-                        int64_t opix;
-                        const bool pv = where(j, opix);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            pre0[nt][j] = epilogue_res_load<PREC>(a, a.res0, nt, g, opix, pv);
-                            pre1[nt][j] = epilogue_res_load<PREC>(a, a.res1, nt, g, opix, pv);
-                        }
-                    }
-                    __syncthreads();  // every wave has finished reading this tile's image
-                    issue_fill(nxt, 0);
-#pragma unroll
-                    for (int j = 0; j < MTW; ++j) {
-                        int64_t opix;
-                        const bool pv = where(j, opix);
-                        float cls = 0.f;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true, true, !BIAS_IN_ACC>(a, acc[nt][j], ntb + nt, g, opix, pv, cls, pre0[nt][j], pre1[nt][j], ubase, voff[j]);
-                        epilogue_cls(a, cls, g, opix, pv);
-                    }
-                    continue;
-                }
-            }
             if (NT == 1 && a.Cout == 8 && !a.outf) {
                 // 8 output channels occupy only lane rows 0-1 of a result tile: pack operand tiles j and j+1 into
                 // one register set (rows 2-3 <- rows 0-1 of tile j+1, v_permlane32_swap) and run ONE epilogue for both
@@ -423,14 +381,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if constexpr (!EARLY) {
-                if (last_pass && has_next && !(a.dbg & 1)) {
-                    __syncthreads();  // every wave has finished reading this tile's image
-                    issue_fill(nxt, 0);
-                }
-            }
         }
-        cur = nxt;
     }
 }
 

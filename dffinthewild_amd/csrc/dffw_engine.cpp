@@ -721,11 +721,7 @@ struct Run {
                     if (t.nsplit >= want) break;
                 }
             }
-            {   // tiles per workgroup
-                t.tpw = 1;   // see MULTI in dffw_conv_tile.hip
-                const int per_xcd = (t.total_tiles + 7) / 8;
-                t.grid = 8 * ((per_xcd + t.tpw - 1) / t.tpw);
-            }
+            t.grid = 8 * ((t.total_tiles + 7) / 8);   // one tile per workgroup, grid a multiple of the 8 XCDs
             // persistent warp-specialised kernel when the layer has enough tiles to keep one workgroup per CU busy
             const TileCfg *scfg = stream_cfg_find(cfg->geo, cfg->nt, cfg->cg);
             const bool use_stream = scfg && scfg->tz == cfg->tz && scfg->ty == cfg->ty && scfg->tx == cfg->tx &&
