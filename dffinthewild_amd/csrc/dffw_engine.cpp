@@ -1295,4 +1295,15 @@ int dffw_op_regress(int device, const float *score, int B, int N, int h, int w, 
     return DFFW_OK;
 }
 
+int dffw_op_fov_warp(int device, const float *x, int B, int C, int N, int H, int W, const float *alpha, const float *fovs,
+                     int alpha_from_sample0, float *out, float *flow, void *hip_stream) {
+    if (!x || !alpha || !fovs || !out) return fail(DFFW_EINVAL, "null argument");
+    if (B < 1 || C < 1 || N < 1 || H < 1 || W < 1) return fail(DFFW_EINVAL, "bad shape");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    HIPCHK(launch_fov_warp(x, alpha, fovs, out, flow, B, C, N, H, W, alpha_from_sample0, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return DFFW_OK;
+}
+
 }  // extern "C"

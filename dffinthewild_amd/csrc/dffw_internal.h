@@ -63,6 +63,8 @@ hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *o
 bool srd_attention_supported(int C);
 hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, const float *w3, const float *w1, int B, int N,
                                 int H, int W, int C, hipStream_t s);
+hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,
+                           int H, int W, int alpha_from_sample0, hipStream_t s);
 hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd,
                           int64_t fsb, int64_t fsn, int64_t fsh, int64_t fsw, float *depth, hipStream_t s);
 

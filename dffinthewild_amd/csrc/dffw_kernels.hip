@@ -397,6 +397,82 @@ hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, c
     return hipGetLastError();
 }
 
+// ---- FOV warp of the End_to_End alignment path (reference End_to_End/End_to_End.py:106-134) ----------------
+// out[b,c,n,y,x] = trilinear sample (zeros padding, align_corners=True) of x[b,c] at
+//     (x - flow_x, y - flow_y, n),   flow_x = (W//2)*(FOV_n + a0_n - 1)*lin_x + a1_n,  flow_y likewise with
+// (H//2), lin_y and a2_n.  The reference builds five (B,.,N,H,W) coordinate grids on the CPU and copies them
+// to the device on every call; here the grid is analytic, one thread per (b,n,y,x) computes the four
+// bilinear corners once and reuses them for every channel.  The fp32 operation order of the reference
+// (normalise to [-1,1], then grid_sample's un-normalise) is kept so the result matches to rounding.
+__global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__ x, const float *__restrict__ alpha,
+                                                       const float *__restrict__ fov, float *__restrict__ out,
+                                                       float *__restrict__ flow, int B, int C, int N, int H, int W,
+                                                       int alpha_from_sample0) {
+    const int64_t plane = (int64_t)H * W;
+    const int64_t total = (int64_t)B * N * plane;
+    const float stepx = 2.0f / (float)(W > 1 ? W - 1 : 1), stepy = 2.0f / (float)(H > 1 ? H - 1 : 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        int64_t t = i / W;
+        const int yy = (int)(t % H);
+        t /= H;
+        const int n = (int)(t % N);
+        const int b = (int)(t / N);
+        const int ab = alpha_from_sample0 ? 0 : b;   // the reference's batch>1 broadcast takes sample 0's alpha
+        const float a0 = alpha[(ab * 3 + 0) * N + n], a1 = alpha[(b * 3 + 1) * N + n], a2 = alpha[(b * 3 + 2) * N + n];
+        const float f = a0 + fov[(alpha_from_sample0 ? 0 : b) * N + n];
+        // torch.linspace(-1, 1, steps): start + i*step in the first half, end - (steps-1-i)*step in the second
+        const float lx = xx < W / 2 ? -1.0f + (float)xx * stepx : 1.0f - (float)(W - 1 - xx) * stepx;
+        const float ly = yy < H / 2 ? -1.0f + (float)yy * stepy : 1.0f - (float)(H - 1 - yy) * stepy;
+        const float fx = (float)(W / 2) * (f - 1.0f) * lx + a1;
+        const float fy = (float)(H / 2) * (f - 1.0f) * ly + a2;
+        if (flow) {
+            flow[((int64_t)(b * 2 + 0) * N + n) * plane + (int64_t)yy * W + xx] = fx;
+            flow[((int64_t)(b * 2 + 1) * N + n) * plane + (int64_t)yy * W + xx] = fy;
+        }
+        // normalised grid, then grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
+        const float gx = 2.0f * ((float)xx - fx) / (float)(W > 1 ? W - 1 : 1) - 1.0f;
+        const float gy = 2.0f * ((float)yy - fy) / (float)(H > 1 ? H - 1 : 1) - 1.0f;
+        const float gz = 2.0f * (float)n / (float)(N > 1 ? N - 1 : 1) - 1.0f;
+        const float sx = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
+        const float sy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+        const float sz = ((gz + 1.0f) * 0.5f) * (float)(N - 1);
+        const float x0f = floorf(sx), y0f = floorf(sy), z0f = floorf(sz);
+        const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+        const float wx1 = sx - x0f, wy1 = sy - y0f, wz1 = sz - z0f;
+        const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1}, wz[2] = {1.0f - wz1, wz1};
+        for (int c = 0; c < C; ++c) {
+            const float *src = x + ((int64_t)b * C + c) * N * plane;
+            float acc = 0.f;
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) {
+                const int zz = z0 + dz;
+                if (zz < 0 || zz >= N || wz[dz] == 0.f) continue;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int yc = y0 + dy;
+                    if (yc < 0 || yc >= H) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int xc = x0 + dx;
+                        if (xc < 0 || xc >= W) continue;
+                        acc += src[(int64_t)zz * plane + (int64_t)yc * W + xc] * (wx[dx] * wy[dy] * wz[dz]);
+                    }
+                }
+            }
+            out[(((int64_t)b * C + c) * N + n) * plane + (int64_t)yy * W + xx] = acc;
+        }
+    }
+}
+
+hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,
+                           int H, int W, int alpha_from_sample0, hipStream_t s) {
+    const int64_t total = (int64_t)B * N * H * W;
+    hipLaunchKernelGGL(fov_warp_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, alpha, fov, out, flow, B, C, N, H, W,
+                       alpha_from_sample0);
+    return hipGetLastError();
+}
+
 // ---- depth regression --------------------------------------------------------------------------
 // One thread per output pixel; the N <= ~15 per-slice scores of a pixel are consumed in a register
 // loop (for fixed slice n consecutive lanes read consecutive x: coalesced), so the soft-argmin

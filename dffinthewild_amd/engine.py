@@ -63,6 +63,8 @@ def _load():
                                    POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int,
                                    POINTER(c_float), POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p]
     lib.dffw_op_pool.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.dffw_op_fov_warp.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_void_p]
     lib.dffw_op_regress.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     POINTER(c_int64), c_void_p, c_void_p]
     return lib
@@ -75,6 +77,7 @@ ABI_SYMBOLS = (
     "dffw_version", "dffw_last_error", "dffw_param_count", "dffw_param_info", "dffw_engine_create",
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
     "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
+    "dffw_op_fov_warp",
 )
 
 
@@ -254,3 +257,20 @@ def op_regress(score, focus_dists, H, W):
                                    (c_int64 * 4)(*fd.stride()), c_void_p(depth.data_ptr()), _stream_ptr(dev)),
                "dffw_op_regress")
     return depth
+
+
+def op_fov_warp(x, alpha, fovs, compat_batch_alpha0=False):
+    """FlowNetwork.FOV_warp of the reference's End_to_End path (End_to_End.py:106-134) on the GPU.
+    x (B,C,N,H,W), alpha (B,3,N,1,1) or (B,3,N), fovs (B,1,N,1,1) or (B,N); returns (warped, flow (B,2,N,H,W))."""
+    B, C, N, H, W = x.shape
+    x = x.contiguous()
+    a = alpha.reshape(B, 3, N).contiguous().float()
+    f = fovs.reshape(B, N).contiguous().float()
+    out = torch.empty_like(x)
+    flow = torch.empty((B, 2, N, H, W), dtype=torch.float32, device=x.device)
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(dev):
+        _check(lib.dffw_op_fov_warp(dev, c_void_p(x.data_ptr()), B, C, N, H, W, c_void_p(a.data_ptr()), c_void_p(f.data_ptr()),
+                                    int(compat_batch_alpha0), c_void_p(out.data_ptr()), c_void_p(flow.data_ptr()),
+                                    _stream_ptr(dev)), "dffw_op_fov_warp")
+    return out, flow

@@ -134,6 +134,15 @@ int dffw_op_regress(int device, const float *score, int B, int N, int h, int w, 
                     const float *focus_dists, const int64_t fd_strides[4], float *depth,
                     void *hip_stream);
 
+/* First operator of the End_to_End alignment path (the rest of that path is
+ * not built yet).  Replaces FlowNetwork.FOV_warp (End_to_End/End_to_End.py:106-134): warps x (B,C,N,H,W)
+ * by the per-slice field-of-view scale and translation.  alpha: device fp32 (B,3,N) = (scale offset,
+ * x shift, y shift) per slice; fovs: device fp32 (B,N); out: (B,C,N,H,W); flow: (B,2,N,H,W) or NULL (the
+ * pixel-unit flow the reference returns as its second value).  alpha_from_sample0 != 0 reproduces the
+ * reference's batch>1 broadcast quirk (every sample uses sample 0's scale offset and FOV). */
+int dffw_op_fov_warp(int device, const float *x, int B, int C, int N, int H, int W, const float *alpha,
+                     const float *fovs, int alpha_from_sample0, float *out, float *flow, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

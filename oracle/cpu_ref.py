@@ -186,6 +186,34 @@ def dff_forward(sd, FS, focus_dists, prefix="DFF_net.", taps=None):
     return mid_out, pred1, pred2, pred3
 
 
+def fov_warp(x, alpha, FOVs):
+    """Restatement of FlowNetwork.FOV_warp (End_to_End/End_to_End.py:106-134) with per-sample semantics
+    (the reference only ever runs batch 1, TRS.py:23; its batch>1 broadcast of alpha is a bug):
+    flow_x = (W//2)*(FOV+alpha0-1)*linspace(-1,1,W) + alpha1, flow_y likewise with H and alpha2; sample x at
+    (x-flow_x, y-flow_y, n) with trilinear grid_sample, zeros padding, align_corners=True.
+    x (B,C,N,H,W); alpha (B,3,N,1,1); FOVs (B,1,N,1,1).  Returns (warped, flow (B,2,N,H,W))."""
+    B, C, N, H, W = x.shape
+    outs, flows = [], []
+    for b in range(B):
+        a = alpha[b].reshape(3, N, 1, 1)
+        f = a[0] + FOVs[b].reshape(N, 1, 1)
+        lx = torch.linspace(-1, 1, steps=W).reshape(1, 1, W)
+        ly = torch.linspace(-1, 1, steps=H).reshape(1, H, 1)
+        fx = (W // 2) * (f - 1) * lx + a[1]
+        fy = (H // 2) * (f - 1) * ly + a[2]
+        fx, fy = fx.expand(N, H, W), fy.expand(N, H, W)
+        xs = torch.arange(W, dtype=torch.float32).reshape(1, 1, W).expand(N, H, W)
+        ys = torch.arange(H, dtype=torch.float32).reshape(1, H, 1).expand(N, H, W)
+        zs = torch.arange(N, dtype=torch.float32).reshape(N, 1, 1).expand(N, H, W)
+        gx = 2.0 * (xs - fx) / max(W - 1, 1) - 1.0
+        gy = 2.0 * (ys - fy) / max(H - 1, 1) - 1.0
+        gz = 2.0 * zs / max(N - 1, 1) - 1.0
+        grid = torch.stack((gx, gy, gz), dim=-1).unsqueeze(0)
+        outs.append(F.grid_sample(x[b:b + 1], grid, align_corners=True))
+        flows.append(torch.stack((fx, fy), 0).unsqueeze(0))
+    return torch.cat(outs, 0), torch.cat(flows, 0)
+
+
 def to_torch_state(sd_numpy):
     """numpy state dict (dffinthewild_amd.synth) -> CPU torch tensors."""
     return {k: torch.from_numpy(v) for k, v in sd_numpy.items()}
