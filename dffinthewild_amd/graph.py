@@ -114,6 +114,50 @@ def dff_net_convs(prefix: str = "DFF_net") -> List[ConvSpec]:
     return rows
 
 
+def _of_block(prefix, cin, cout):
+    """resnet_block_2d_OF (End_to_End.py:135-145): convbn 1x3x3 (stride s) -> relu -> convbn 1x3x3, plus a
+    bias-free 1x1x1 (stride s) shortcut called ``feature``.  Registration order: conv, then feature."""
+    return [
+        _cb(prefix + ".conv.0", cin, cout, (1, 3, 3)),
+        _cb(prefix + ".conv.2", cout, cout, (1, 3, 3)),
+        ConvSpec(prefix + ".feature", cin, cout, (1, 1, 1)),
+    ]
+
+
+def _alpha_head(prefix, cin, c):
+    """conv1/conv2/conv3 of FlowNetwork (End_to_End.py:37-69): three convbn 1x3x3 + relu, then a biased
+    1x3x3 conv to the 3 warp parameters (the AdaptiveAvgPool3d that follows has no parameters)."""
+    return [
+        _cb(prefix + ".0", cin, c, (1, 3, 3)),
+        _cb(prefix + ".2", c, c, (1, 3, 3)),
+        _cb(prefix + ".4", c, c, (1, 3, 3)),
+        ConvSpec(prefix + ".6", c, 3, (1, 3, 3), bias=True),
+    ]
+
+
+FLOW_PLANES = 8     # FlowNetwork(inplanes=8), End_to_End.py:11
+FLOW_SLICES = 10    # AdaptiveAvgPool3d((10,1,1)), End_to_End.py:46,57,68: the alignment net is built for 10 slices
+
+
+def flow_net_convs(prefix: str = "optical_flow_aggregation") -> List[ConvSpec]:
+    """All conv rows of FlowNetwork (End_to_End.py:18-69) in registration order (138 state-dict entries)."""
+    P, C = prefix, FLOW_PLANES
+    rows: List[ConvSpec] = []
+    rows += _of_block(P + ".OF_feature.0", 3, C) + _of_block(P + ".OF_feature.1", C, C)
+    rows += _of_block(P + ".OF_feature1.0", C, 2 * C) + _of_block(P + ".OF_feature1.1", 2 * C, 2 * C)
+    rows += _of_block(P + ".OF_feature2.0", 2 * C, 4 * C) + _of_block(P + ".OF_feature2.1", 4 * C, 4 * C)
+    rows += _alpha_head(P + ".conv1", 8 * C + 2, 8 * C)
+    rows += _alpha_head(P + ".conv2", 4 * C + 2, 4 * C)
+    rows += _alpha_head(P + ".conv3", 2 * C + 2, 2 * C)
+    return rows
+
+
+def e2e_convs() -> List[ConvSpec]:
+    """End_to_End.Network (End_to_End.py:9-16): DFF_net registered first, then optical_flow_aggregation
+    (522 state-dict entries)."""
+    return dff_net_convs("DFF_net") + flow_net_convs("optical_flow_aggregation")
+
+
 # role tags used by synth.py to pick a distribution per entry
 ROLE_CONV, ROLE_CONVT, ROLE_BIAS = "conv", "convT", "bias"
 ROLE_BN_W, ROLE_BN_B, ROLE_BN_MEAN, ROLE_BN_VAR, ROLE_BN_NBT = "bn_w", "bn_b", "bn_mean", "bn_var", "bn_nbt"
@@ -155,4 +199,20 @@ def check_stack_shape(FS_shape, focus_shape=None):
         for got, want, name in zip(fs, (B, N, H, W), "BNHW"):
             if got != want and got != 1:
                 raise ValueError(f"focus_dists dim {name}={got} does not broadcast to {want}")
+    return B, N, H, W
+
+
+def check_e2e_shape(FS_shape, focus_shape, fov_shape):
+    """Shape contract of ``End_to_End.Network.forward(FS, focus_dists, FOVs)`` (End_to_End.py:13-16,
+    Test_dataloader.py:54-70): FS (B,3,10,H,W); focus_dists broadcastable to (B,10,H,W); FOVs one relative
+    field of view per slice, (B,1,10,1,1) (any shape with B*10 elements in (b,n) order is accepted)."""
+    B, N, H, W = check_stack_shape(FS_shape, focus_shape)
+    if N != FLOW_SLICES:
+        raise ValueError(f"the alignment network is built for {FLOW_SLICES} focal slices "
+                         f"(AdaptiveAvgPool3d((10,1,1)), End_to_End.py:46), got {N}")
+    n = 1
+    for v in fov_shape:
+        n *= int(v)
+    if n != B * N:
+        raise ValueError(f"FOVs must hold one value per (sample, slice) = {B}x{N}, got shape {tuple(fov_shape)}")
     return B, N, H, W

@@ -57,7 +57,8 @@ def tensor_for(key: str, shape, role: str, seed: int = 0, profile: str = "smooth
 
     profile ``"smooth"``: the 1-channel score convs (classif1-3, confidence.2) are damped so the
     per-slice scores stay within a few units (soft-argmin in its responsive regime, as for a
-    trained net).  profile ``"he"``: every conv uses the plain He scale, which saturates the
+    trained net), and the 3-channel warp-parameter convs of the End_to_End alignment heads so that
+    the predicted shifts stay at a pixel or two.  profile ``"he"``: every conv uses the plain He scale, which saturates the
     soft-argmin (the hardest case for numerical parity).
     """
     shape = tuple(int(s) for s in shape)
@@ -70,6 +71,8 @@ def tensor_for(key: str, shape, role: str, seed: int = 0, profile: str = "smooth
         std = (2.0 / (kd * kh * kw * cout)) ** 0.5          # He scale, DEN.py:62-64
         if profile == "smooth" and cout == 1:
             std *= 0.25
+        if profile == "smooth" and cout == 3:
+            std *= 0.15                                      # alpha heads of FlowNetwork: shifts of a pixel or two
         return (bell(key, n, seed) * std).astype(np.float32).reshape(shape)
     u = uniform01(key, n, seed)
     if role == "bn_w":

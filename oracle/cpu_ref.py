@@ -1,7 +1,8 @@
 """ORACLE — test infrastructure, not product code.
 
 CPU restatement (PyTorch-CPU, fp32, functional) of the reference's depth-from-focus forward pass,
-``DFF_net.forward`` in ``/root/reference/Depth_Estimation_Test/Depth_Estimation_Network.py:74-127``.
+``DFF_net.forward`` in ``/root/reference/Depth_Estimation_Test/Depth_Estimation_Network.py:74-127``, and of
+the End_to_End variant (``/root/reference/End_to_End/End_to_End.py``: FlowNetwork alignment + DFF_net).
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
 this module; nothing under ``dffinthewild_amd/`` does.
 
@@ -212,6 +213,60 @@ def fov_warp(x, alpha, FOVs):
         outs.append(F.grid_sample(x[b:b + 1], grid, align_corners=True))
         flows.append(torch.stack((fx, fy), 0).unsqueeze(0))
     return torch.cat(outs, 0), torch.cat(flows, 0)
+
+
+def _of_block(x, w, stride):
+    """resnet_block_2d_OF (End_to_End.py:135-145): relu(feature(x) + BN(conv(relu(BN(conv_s(x)))))) where
+    ``feature`` is a bias-free 1x1x1 conv with the same (1,s,s) stride."""
+    y = F.relu(_conv_bn(x, w, "conv.0", (1, stride, stride), (0, 1, 1)))
+    y = _conv_bn(y, w, "conv.2", 1, (0, 1, 1))
+    return F.relu(_conv(x, w, "feature", (1, stride, stride), 0) + y)
+
+
+def _alpha_head(vol, w):
+    """conv1/2/3 of FlowNetwork (End_to_End.py:37-69): 3x(convbn 1x3x3 + relu), biased 1x3x3 conv to 3
+    channels, AdaptiveAvgPool3d((10,1,1)) — for the 10-slice stacks the network is built for this is the
+    plain mean over H and W of every slice."""
+    y = vol
+    for i in (0, 2, 4):
+        y = F.relu(_conv_bn(y, w, str(i), 1, (0, 1, 1)))
+    y = F.conv3d(y, w("6.weight"), w("6.bias"), 1, (0, 1, 1))
+    return F.adaptive_avg_pool3d(y, (10, 1, 1))
+
+
+def flow_forward(sd, FS, FOVs, prefix="optical_flow_aggregation.", taps=None):
+    """Restatement of FlowNetwork.forward (End_to_End.py:71-105), per-sample semantics for batch>1.
+
+    Three feature levels (full, 1/2, 1/4 resolution); coarse to fine, each level is warped with the
+    warp parameters found so far, paired with its last slice (the reference slice) and the flow field,
+    and an alpha head regresses a per-slice update (scale term damped by 0.001).  Returns the warped
+    focal stack (B,3,N,H,W) and the accumulated alpha (B,3,N,1,1)."""
+    w = _W(sd, prefix)
+    B, _, N, H, W = FS.shape
+    FOVs = FOVs.reshape(B, 1, N, 1, 1)
+    fe1 = _of_block(_of_block(FS, w.sub("OF_feature.0"), 1), w.sub("OF_feature.1"), 1)
+    fe2 = _of_block(_of_block(fe1, w.sub("OF_feature1.0"), 2), w.sub("OF_feature1.1"), 1)
+    fe3 = _of_block(_of_block(fe2, w.sub("OF_feature2.0"), 2), w.sub("OF_feature2.1"), 1)
+    alpha = torch.zeros(B, 3, N, 1, 1)
+    for tag, fe, head in (("3", fe3, "conv1"), ("2", fe2, "conv2"), ("1", fe1, "conv3")):
+        warped, flow = fov_warp(fe, alpha, FOVs)
+        ref = warped[:, :, -1:].expand_as(warped)                    # End_to_End.py:82,90,98
+        step = _alpha_head(torch.cat((ref, warped, flow), 1), w.sub(head)).clone()
+        if taps is not None:
+            taps["head" + tag] = step.clone()                        # before the 0.001 damping
+        step[:, 0] = 0.001 * step[:, 0]                              # End_to_End.py:86,94,102
+        alpha = alpha + step
+        if taps is not None:
+            taps["alpha" + tag] = alpha.clone()
+    warped_FS, _ = fov_warp(FS, alpha, FOVs)
+    return warped_FS, alpha
+
+
+def e2e_forward(sd, FS, focus_dists, FOVs, taps=None):
+    """Restatement of End_to_End.Network.forward (End_to_End.py:13-16): align the stack, then DFF_net on
+    the aligned stack.  Returns (mid_out, pred1, pred2, pred3, aligned FS) like End_to_End.py:259."""
+    warped, _ = flow_forward(sd, FS, FOVs, taps=taps)
+    return dff_forward(sd, warped, focus_dists, "DFF_net.", taps) + (warped,)
 
 
 def to_torch_state(sd_numpy):
