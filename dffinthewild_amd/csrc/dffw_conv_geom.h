@@ -16,6 +16,8 @@ struct GeoT<G3T> { static constexpr int MINZ = -1, MAXZ = 1, MINY = 0, MAXY = 1,
 template <>
 struct GeoT<G2S1> { static constexpr int MINZ = 0, MAXZ = 0, MINY = -1, MAXY = 1, S = 1, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
 template <>
+struct GeoT<G2S2> { static constexpr int MINZ = 0, MAXZ = 0, MINY = -1, MAXY = 1, S = 2, OS = 1, NPASS = 1, MINX = MINY, MAXX = MAXY; };
+template <>
 struct GeoT<G2D> { static constexpr int MINZ = 0, MAXZ = 0, MINY = -8, MAXY = 8, S = 1, OS = 1, NPASS = 1, MINX = -6, MAXX = 10; };
 
 template <int GEO, int TZ_, int TY_, int TX_, int CG_>

@@ -11,7 +11,8 @@ enum Geo {
     G3T = 2,   // transposed 3x3x3 s(1,2,2) p1 op(0,1,1): 4 sub-pixel passes over one input tile (11 layers)
     G2S1 = 3,  // 1x3x3 per-slice conv, pad (0,1,1)           (6 layers)
     G2D = 4,   // the stem: 1x9x9, dilation (1,2,2), pad (0,8,8), on the paired-pixel (W+2)-wide input (see stack_in)
-    GEO_COUNT = 5
+    G2S2 = 5,  // 1x3x3 per-slice conv, stride (1,2,2), pad (0,1,1): the down-sampling blocks of the alignment network
+    GEO_COUNT = 6
 };
 
 struct GeoInfo {
@@ -27,6 +28,7 @@ inline GeoInfo geo_info(int geo) {
         case G3S2: return GeoInfo{-1, 1, -1, 1, -1, 1, 2, 1, 1};
         case G3T: return GeoInfo{-1, 1, 0, 1, 0, 1, 1, 2, 4};
         case G2D: return GeoInfo{0, 0, -8, 8, -6, 10, 1, 1, 1};
+        case G2S2: return GeoInfo{0, 0, -1, 1, -1, 1, 2, 1, 1};
         default: return GeoInfo{0, 0, -1, 1, -1, 1, 1, 1, 1};
     }
 }

@@ -405,7 +405,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     X(14, G2S1, 2, 5, 8, 16, 16, 0)  \
     X(15, G2D, 1, 1, 16, 32, 8, 0)   \
     X(16, G3S1, 2, 4, 4, 8, 16, 1)   \
-    X(17, G3S2, 2, 4, 4, 8, 8, 1)
+    X(17, G3S2, 2, 4, 4, 8, 8, 1)    \
+    X(18, G2S1, 2, 5, 4, 16, 8, 0)   \
+    X(19, G2S1, 4, 5, 4, 16, 16, 0)  \
+    X(20, G2S1, 4, 5, 4, 16, 8, 0)   \
+    X(21, G2S2, 1, 5, 4, 16, 8, 0)   \
+    X(22, G2S2, 2, 5, 4, 16, 8, 0)
 
 #define X_CFG(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                             \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \

@@ -152,8 +152,15 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = ADD_BIAS ? accq[i] + a.bias[c0 + i] : accq[i];   // bias is zero-padded to the kernel's NT*16 channels
-    if (a.outf) {  // 1-channel fp32 score volume (B,No,Ho,Wo)
-        if (pvalid && c0 == 0) a.outf[opix] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
+    if (a.outf) {  // fp32 planar output: 1-channel score volume (B,No,Ho,Wo), or the <= 4 channels of an alignment head
+        if (pvalid && c0 == 0) {
+            if (a.outf_ch <= 1) {
+                a.outf[opix] = (a.relu == 1) ? fmaxf(v[0], 0.f) : v[0];
+            } else {
+                const int64_t b = opix / a.outf_plane, q = opix - b * a.outf_plane;
+                for (int i = 0; i < a.outf_ch; ++i) a.outf[(b * a.outf_ch + i) * a.outf_plane + q] = v[i];
+            }
+        }
         return;
     }
     if constexpr (PARTS == 2) {

@@ -1,7 +1,8 @@
 // Host side of libdffw.so: the layer table (weight contract), BatchNorm folding + MFMA-fragment
 // weight packing, the static workspace arena and the whole-graph executor of DFF_net.forward
-// (reference Depth_Estimation_Test/Depth_Estimation_Network.py:74-127), behind the C ABI of
-// include/dffw.h.  All arithmetic of the forward runs in the gfx950 kernels of dffw_kernels.hip;
+// (reference Depth_Estimation_Test/Depth_Estimation_Network.py:74-127) and of the End_to_End variant
+// (End_to_End/End_to_End.py: alignment network + FOV warp in front of the same DFF_net), behind the C ABI
+// of include/dffw.h.  All arithmetic of the forward runs in the gfx950 kernels of dffw_kernels.hip;
 // nothing here touches activation values.
 #include <algorithm>
 #include <cmath>
@@ -97,6 +98,39 @@ class Table {
         deconv(p + ".conv6", 2 * c, c);
     }
 
+    void biased(const std::string &key, int cin, int cout, int kd, int kh, int kw, int pd, int ph, int pw) {
+        LayerDef L{key, "", cin, cout, kd, kh, kw, 1, 1, pd, ph, pw, 1, 1, false, true, true};
+        add(L);
+    }
+    void of_block(const std::string &p, int cin, int cout, int s) {  // resnet_block_2d_OF, End_to_End.py:135-145
+        conv(p + ".conv.0", cin, cout, 1, 3, 3, s, 0, 1, 1, 1, true);
+        conv(p + ".conv.2", cout, cout, 1, 3, 3, 1, 0, 1, 1, 1, true);
+        conv(p + ".feature", cin, cout, 1, 1, 1, s, 0, 0, 0, 1, false);
+    }
+    void alpha_head(const std::string &p, int cin, int c) {  // conv1/conv2/conv3 of FlowNetwork, End_to_End.py:37-69
+        conv(p + ".0", cin, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
+        conv(p + ".2", c, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
+        conv(p + ".4", c, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
+        biased(p + ".6", c, 3, 1, 3, 3, 0, 1, 1);
+    }
+
+    // End_to_End.Network (End_to_End.py:9-12): DFF_net registered first, then optical_flow_aggregation = FlowNetwork(8)
+    static Table e2e_net() {
+        Table t = depth_net();
+        const std::string P = "optical_flow_aggregation";
+        const int C = 8;
+        t.of_block(P + ".OF_feature.0", 3, C, 1);
+        t.of_block(P + ".OF_feature.1", C, C, 1);
+        t.of_block(P + ".OF_feature1.0", C, 2 * C, 2);
+        t.of_block(P + ".OF_feature1.1", 2 * C, 2 * C, 1);
+        t.of_block(P + ".OF_feature2.0", 2 * C, 4 * C, 2);
+        t.of_block(P + ".OF_feature2.1", 4 * C, 4 * C, 1);
+        t.alpha_head(P + ".conv1", 8 * C + 2, 8 * C);
+        t.alpha_head(P + ".conv2", 4 * C + 2, 4 * C);
+        t.alpha_head(P + ".conv3", 2 * C + 2, 2 * C);
+        return t;
+    }
+
     static Table depth_net() {
         Table t;
         const std::string P = "DFF_net";
@@ -166,10 +200,11 @@ class Table {
     }
 };
 
+static bool known_net(int net) { return net == DFFW_NET_DEPTH || net == DFFW_NET_E2E; }
 static const Table &table_for(int net) {
     static const Table depth = Table::depth_net();
-    (void)net;
-    return depth;
+    static const Table e2e = Table::e2e_net();
+    return net == DFFW_NET_E2E ? e2e : depth;
 }
 
 // ---- host number formats -----------------------------------------------------------------------
@@ -384,7 +419,8 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     else if (L.kd == 3 && L.kh == 3 && L.kw == 3 && L.dh == 1 && L.pd == 1 && L.ph == 1 && L.sh == 1) geo = G3S1;
     else if (L.kd == 3 && L.kh == 3 && L.kw == 3 && L.dh == 1 && L.pd == 1 && L.ph == 1 && L.sh == 2) geo = G3S2;
     else if (L.kd == 1 && L.kh == 3 && L.kw == 3 && L.dh == 1 && L.pd == 0 && L.ph == 1 && L.sh == 1) geo = G2S1;
-    int cin_t = L.cin;  // channels the tiled kernel contracts over
+    else if (L.kd == 1 && L.kh == 3 && L.kw == 3 && L.dh == 1 && L.pd == 0 && L.ph == 1 && L.sh == 2) geo = G2S2;
+    int cin_t = cin_pad;  // channels the tiled kernel contracts over (padding channels carry zero weights)
     if (stem) {
         // paired-pixel input (stack_in): record q = RGB(q-2) | RGB(q).  Taps (ky, jx) for jx in {0,2,4,6,8}
         // read record x+2*jx-6 and carry the weights of x-taps jx (channels 0..2) and jx+1 (channels
@@ -396,7 +432,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
             for (int jx = 0; jx < 9; jx += 2) tapsets[0].push_back(Tap{0, 2 * ky - 8, 2 * jx - 6, 0, ky, jx});
     }
     auto wval_t = [&](int cout, int cin, const Tap &t) -> double {
-        if (!stem) return wval(cout, cin, t);
+        if (!stem) return cin < L.cin ? wval(cout, cin, t) : 0.0;
         if ((cin & 3) == 3) return 0.0;
         Tap u = t;
         if (cin >= 4) {
@@ -406,7 +442,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         return wval(cout, cin & 3, u);
     };
     if (geo >= 0 && cin_t % 8 == 0) {
-        const int cg = (geo == G3S2) ? 8 : (cin_t % 16 == 0 ? 16 : 8);
+        const int cg = (geo == G3S2 || geo == G2S2) ? 8 : (cin_t % 16 == 0 ? 16 : 8);
         const TileCfg *cfg = tile_cfg_find(geo, pc.nt, cg);
         if (cfg && cin_t % cg == 0) {
             const GeoInfo gi = geo_info(geo);
@@ -552,7 +588,8 @@ struct ConvOpt {
     const Act *res0 = nullptr, *res1 = nullptr;
     int relu = 0;
     Act *out_pre = nullptr;  // receives the pre-residual value (allocated here)
-    float *outf = nullptr;   // fp32 score output instead of an activation volume
+    float *outf = nullptr;   // fp32 planar output (B,outf_ch,N,H,W) instead of an activation volume
+    int outf_ch = 1;
     const char *cls = nullptr;  // name of a 1x1x1 C->1 layer to apply to the final value inside the epilogue
     float *cls_out = nullptr;   // its fp32 score volume
     bool discard = false;       // the activation output itself is not needed (only cls_out / out_pre)
@@ -672,6 +709,8 @@ struct Run {
         a.out = out.p;
         a.out_pre = o.out_pre ? o.out_pre->p : nullptr;
         a.outf = o.outf;
+        a.outf_ch = o.outf_ch;
+        a.outf_plane = (int64_t)No * Ho * Wo;
         a.cls_w = cls_w;
         a.cls_out = o.cls_out;
         a.relu = o.relu;
@@ -1027,6 +1066,96 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     return r.err;
 }
 
+// resnet_block_2d_OF (End_to_End.py:135-145): relu(feature(x) + BN(conv(relu(BN(conv_s(x))))))
+static Act of_block(Run &r, const std::string &p, const Act &x) {
+    ConvOpt rl; rl.relu = 1;
+    Act t = r.conv(p + ".conv.0.0", x, rl);
+    Act f = r.conv(p + ".feature", x);
+    ConvOpt o; o.relu = 1; o.res0 = &f;
+    Act out = r.conv(p + ".conv.2.0", t, o);
+    r.drop(t);
+    r.drop(f);
+    return out;
+}
+
+// End_to_End.Network.forward (End_to_End.py:13-16): FlowNetwork.forward (End_to_End.py:71-105) aligns the stack,
+// DFF_net runs on the aligned stack.  `aligned` receives the warped focal stack (the 5th return value).
+static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4], const float *fov, int B, int N, int H, int W,
+                   float *const out[4], float *aligned) {
+    const std::string P = "optical_flow_aggregation";
+    const int prec = r.e->prec;
+    ConvOpt rl; rl.relu = 1;
+    Act in = r.act(B, N, H, W, 8);
+    if (r.ok() && !r.dry) {
+        char kn[56];
+        snprintf(kn, sizeof kn, "dffw::from_ncdhw_pad_kernel<%d>", prec);
+        r.prof_begin(kn, "flow.stack_in", 0.0, (double)B * N * H * W * (3 * 4.0 + 8 * r.elem_bytes()));
+        r.check(launch_from_ncdhw_pad(prec, FS, in.p, B, 3, 8, N, H, W, r.s), "from_ncdhw_pad");
+        r.prof_end();
+    }
+    // three feature levels: full, 1/2, 1/4 resolution                               End_to_End.py:72-74
+    Act a0 = of_block(r, P + ".OF_feature.0", in);
+    r.drop(in);
+    Act fe1 = of_block(r, P + ".OF_feature.1", a0);
+    r.drop(a0);
+    Act a1 = of_block(r, P + ".OF_feature1.0", fe1);
+    Act fe2 = of_block(r, P + ".OF_feature1.1", a1);
+    r.drop(a1);
+    Act a2 = of_block(r, P + ".OF_feature2.0", fe2);
+    Act fe3 = of_block(r, P + ".OF_feature2.1", a2);
+    r.drop(a2);
+
+    const int64_t na = (int64_t)B * 3 * N;
+    float *alpha = (float *)r.raw(na * sizeof(float));   // accumulated (scale offset, x shift, y shift) per (b, slice)
+    float *rawh = (float *)r.raw(na * sizeof(float));    // last head output before damping (debug tap)
+    if (r.ok() && !r.dry) r.check(hipMemsetAsync(alpha, 0, na * sizeof(float), r.s), "alpha memset");
+
+    struct Level { Act *fe; const char *head; const char *tap; };
+    Level levels[3] = {{&fe3, ".conv1", "head3"}, {&fe2, ".conv2", "head2"}, {&fe1, ".conv3", "head1"}};
+    for (const Level &lv : levels) {                      // coarse to fine, End_to_End.py:77-103
+        Act &fe = *lv.fe;
+        const int Cv = 2 * fe.C + 8;                      // 2C+2 channels of End_to_End.py:81-84, padded to a multiple of 8
+        Act vol = r.act(B, N, fe.H, fe.W, Cv);
+        if (r.ok() && !r.dry) {
+            char kn[56];
+            snprintf(kn, sizeof kn, "dffw::flow_volume_kernel<%d>", prec);
+            r.prof_begin(kn, std::string("flow") + lv.head + ".volume", 0.0, (double)fe.pixels() * (2.0 * fe.C + Cv) * r.elem_bytes());
+            r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, r.s), "flow_volume");
+            r.prof_end();
+        }
+        r.drop(fe);
+        const std::string hp = P + lv.head;
+        Act y0 = r.conv(hp + ".0.0", vol, rl);
+        r.drop(vol);
+        Act y1 = r.conv(hp + ".2.0", y0, rl);
+        r.drop(y0);
+        Act y2 = r.conv(hp + ".4.0", y1, rl);
+        r.drop(y1);
+        const int64_t hw = (int64_t)y2.H * y2.W;
+        float *hf = (float *)r.raw(na * hw * sizeof(float));
+        ConvOpt of; of.outf = hf; of.outf_ch = 3;
+        r.conv(hp + ".6", y2, of);
+        r.drop(y2);
+        if (r.ok() && !r.dry) {
+            r.prof_begin("dffw::alpha_mean_kernel", std::string("flow") + lv.head + ".mean", 0.0, (double)na * hw * 4.0);
+            r.check(launch_alpha_mean(hf, alpha, rawh, B, N, hw, r.s), "alpha_mean");
+            r.prof_end();
+        }
+        r.drop_raw(hf);
+        r.tap_f32(lv.tap, rawh, na);
+    }
+    r.tap_f32("alpha", alpha, na);
+    if (r.ok() && !r.dry) {                               // End_to_End.py:104
+        r.prof_begin("dffw::fov_warp_kernel", "flow.warp_stack", 0.0, (double)B * N * H * W * 3 * 8.0);
+        r.check(launch_fov_warp(FS, alpha, fov, aligned, nullptr, B, 3, N, H, W, 0, r.s), "fov_warp");
+        r.prof_end();
+    }
+    r.drop_raw(rawh);
+    r.drop_raw(alpha);
+    if (!r.ok()) return r.err;
+    return run_depth(r, aligned, fd, fst, B, N, H, W, out);
+}
+
 static int check_dims(int B, int N, int H, int W) {
     if (B < 1 || N < 1) return fail(DFFW_EINVAL, "B and N must be >= 1 (got B=%d N=%d)", B, N);
     if (H < 32 || W < 32 || H % 32 || W % 32)
@@ -1043,12 +1172,12 @@ const char *dffw_version(void) { return "dffw 0.1 (gfx950)"; }
 const char *dffw_last_error(void) { return g_err.c_str(); }
 
 int dffw_param_count(int net) {
-    if (net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "unknown net %d", net);
+    if (!known_net(net)) return fail(DFFW_EINVAL, "unknown net %d", net);
     return (int)table_for(net).params.size();
 }
 
 int dffw_param_info(int net, int index, const char **name, int64_t shape[5], int *ndim, int *flags) {
-    if (net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "unknown net %d", net);
+    if (!known_net(net)) return fail(DFFW_EINVAL, "unknown net %d", net);
     const Table &t = table_for(net);
     if (index < 0 || index >= (int)t.params.size()) return fail(DFFW_EINVAL, "param index %d out of range", index);
     const ParamInfo &p = t.params[index];
@@ -1062,7 +1191,7 @@ int dffw_param_info(int net, int index, const char **name, int64_t shape[5], int
 int dffw_engine_create(int device, int net, const dffw_tensor *tensors, int n_tensors, int precision, dffw_engine **out) {
     if (!out) return fail(DFFW_EINVAL, "out is null");
     *out = nullptr;
-    if (net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "unknown net %d", net);
+    if (!known_net(net)) return fail(DFFW_EINVAL, "unknown net %d", net);
     if (precision < 0 || precision > 2) return fail(DFFW_EINVAL, "unknown precision %d", precision);
     if (!tensors || n_tensors <= 0) return fail(DFFW_EINVAL, "no tensors given");
     HIPCHK(hipSetDevice(device));
@@ -1123,12 +1252,33 @@ int64_t dffw_workspace_bytes(const dffw_engine *e, int B, int N, int H, int W) {
     if (!e) return fail(DFFW_EINVAL, "null engine");
     int rc = check_dims(B, N, H, W);
     if (rc) return rc;
+    if (e->net == DFFW_NET_E2E && N != DFFW_E2E_SLICES)
+        return fail(DFFW_EINVAL, "the alignment network is built for %d focal slices (End_to_End.py:46), got %d", DFFW_E2E_SLICES, N);
     Run r(const_cast<dffw_engine *>(e), nullptr, true, nullptr, INT64_MAX / 2);
     const int64_t st[4] = {0, 0, 0, 0};
     float *outs[4] = {nullptr, nullptr, nullptr, nullptr};
-    rc = run_depth(r, nullptr, nullptr, st, B, N, H, W, outs);
+    rc = e->net == DFFW_NET_E2E ? run_e2e(r, nullptr, nullptr, st, nullptr, B, N, H, W, outs, nullptr)
+                                : run_depth(r, nullptr, nullptr, st, B, N, H, W, outs);
     if (rc) return rc;
     return r.arena.peak();
+}
+
+int dffw_forward_e2e(dffw_engine *e, const float *FS, const float *focus_dists, const int64_t fd_strides[4], const float *fovs,
+                     int B, int N, int H, int W, float *const out[4], float *aligned, void *workspace, int64_t workspace_bytes,
+                     void *hip_stream, const dffw_tap *taps, int n_taps) {
+    if (!e || !FS || !focus_dists || !fd_strides || !fovs || !out || !aligned) return fail(DFFW_EINVAL, "null argument");
+    if (e->net != DFFW_NET_E2E) return fail(DFFW_EINVAL, "engine was not created with DFFW_NET_E2E");
+    int rc = check_dims(B, N, H, W);
+    if (rc) return rc;
+    if (N != DFFW_E2E_SLICES)
+        return fail(DFFW_EINVAL, "the alignment network is built for %d focal slices (End_to_End.py:46), got %d", DFFW_E2E_SLICES, N);
+    if (!workspace) return fail(DFFW_ENOMEM, "workspace is null");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->profiling) e->clear_recs();
+    Run r(e, (hipStream_t)hip_stream, false, (char *)workspace, workspace_bytes);
+    r.taps = taps;
+    r.n_taps = taps ? n_taps : 0;
+    return run_e2e(r, FS, focus_dists, fd_strides, fovs, B, N, H, W, out, aligned);
 }
 
 int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists, const int64_t fd_strides[4], int B, int N,

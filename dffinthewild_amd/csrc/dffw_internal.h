@@ -43,7 +43,9 @@ struct ConvArgs {
     const uint16_t *res0, *res1;// residual volumes in the output's geometry, or null
     uint16_t *out;              // output volume, or null
     uint16_t *out_pre;          // optional second output: value before the residual add
-    float *outf;                // fp32 score volume (B,No,Ho,Wo) for Cout == 1 layers, or null
+    float *outf;                // fp32 planar output (B,outf_ch,No,Ho,Wo) instead of an activation volume, or null
+    int outf_ch;                // 1: score volume of a Cout == 1 layer; 3: warp parameters of the alignment heads
+    int64_t outf_plane;         // No*Ho*Wo (used when outf_ch > 1)
     const float *cls_w;         // fused 1x1x1 classifier (DEN.py:51-55): Cout fp32 weights applied to the final value, or null
     float *cls_out;             // its fp32 score volume (B,No,Ho,Wo)
     int relu;                   // 0: none   1: relu(acc+res)   2: relu(acc)+res
@@ -63,6 +65,10 @@ hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *o
 bool srd_attention_supported(int C);
 hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, const float *w3, const float *w1, int B, int N,
                                 int H, int W, int C, hipStream_t s);
+hipError_t launch_from_ncdhw_pad(int prec, const float *x, uint16_t *out, int B, int Cs, int C, int N, int H, int W, hipStream_t s);
+hipError_t launch_flow_volume(int prec, const uint16_t *fe, uint16_t *out, const float *alpha, const float *fov, int B, int N,
+                              int H, int W, int C, hipStream_t s);
+hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B, int N, int64_t hw, hipStream_t s);
 hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,
                            int H, int W, int alpha_from_sample0, hipStream_t s);
 hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd,

@@ -204,6 +204,21 @@ __global__ __launch_bounds__(256) void from_ncdhw_kernel(const float *__restrict
     }
 }
 
+// planar fp32 (B,Cs,plane) -> channels-last C-channel volume, channels Cs..C-1 zero (the 3-channel focal stack
+// as the 8-channel input of the alignment network's first block)
+template <int PREC>
+__global__ __launch_bounds__(256) void from_ncdhw_pad_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int B,
+                                                             int Cs, int C, int64_t plane) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int64_t total = (int64_t)B * plane * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int64_t b = pix / plane, q = pix - b * plane;
+        Fmt<PREC>::store(out + pix * (PARTS * C), C, c, c < Cs ? x[(b * Cs + c) * plane + q] : 0.f);
+    }
+}
+
 template <int PREC>
 __global__ __launch_bounds__(256) void to_ncdhw_kernel(const uint16_t *__restrict__ x, float *__restrict__ out, int B,
                                                        int C, int64_t plane) {
@@ -242,6 +257,12 @@ hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int 
 hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s) {
     const int64_t plane = (int64_t)N * H * W;
     DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((from_ncdhw_kernel<PR>), dim3(grid_for(B * plane * C)), dim3(256), 0, s, x, out, B, C, plane));
+    return hipGetLastError();
+}
+
+hipError_t launch_from_ncdhw_pad(int prec, const float *x, uint16_t *out, int B, int Cs, int C, int N, int H, int W, hipStream_t s) {
+    const int64_t plane = (int64_t)N * H * W;
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((from_ncdhw_pad_kernel<PR>), dim3(grid_for(B * plane * C)), dim3(256), 0, s, x, out, B, Cs, C, plane));
     return hipGetLastError();
 }
 
@@ -404,13 +425,33 @@ hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, c
 // to the device on every call; here the grid is analytic, one thread per (b,n,y,x) computes the four
 // bilinear corners once and reuses them for every channel.  The fp32 operation order of the reference
 // (normalise to [-1,1], then grid_sample's un-normalise) is kept so the result matches to rounding.
+// flow of grid point (xx,yy) of a slice with scale f = FOV + a0 and shifts a1, a2, and the un-normalised sample
+// position (sx,sy) grid_sample(align_corners=True) derives from it
+struct WarpPoint {
+    float fx, fy, sx, sy;
+};
+__device__ __forceinline__ WarpPoint warp_point(int xx, int yy, int H, int W, float f, float a1, float a2) {
+    const float stepx = 2.0f / (float)(W > 1 ? W - 1 : 1), stepy = 2.0f / (float)(H > 1 ? H - 1 : 1);
+    // torch.linspace(-1, 1, steps): start + i*step in the first half, end - (steps-1-i)*step in the second
+    const float lx = xx < W / 2 ? -1.0f + (float)xx * stepx : 1.0f - (float)(W - 1 - xx) * stepx;
+    const float ly = yy < H / 2 ? -1.0f + (float)yy * stepy : 1.0f - (float)(H - 1 - yy) * stepy;
+    WarpPoint p;
+    p.fx = (float)(W / 2) * (f - 1.0f) * lx + a1;
+    p.fy = (float)(H / 2) * (f - 1.0f) * ly + a2;
+    // normalised grid, then grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
+    const float gx = 2.0f * ((float)xx - p.fx) / (float)(W > 1 ? W - 1 : 1) - 1.0f;
+    const float gy = 2.0f * ((float)yy - p.fy) / (float)(H > 1 ? H - 1 : 1) - 1.0f;
+    p.sx = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
+    p.sy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+    return p;
+}
+
 __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__ x, const float *__restrict__ alpha,
                                                        const float *__restrict__ fov, float *__restrict__ out,
                                                        float *__restrict__ flow, int B, int C, int N, int H, int W,
                                                        int alpha_from_sample0) {
     const int64_t plane = (int64_t)H * W;
     const int64_t total = (int64_t)B * N * plane;
-    const float stepx = 2.0f / (float)(W > 1 ? W - 1 : 1), stepy = 2.0f / (float)(H > 1 ? H - 1 : 1);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int xx = (int)(i % W);
         int64_t t = i / W;
@@ -421,21 +462,13 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
         const int ab = alpha_from_sample0 ? 0 : b;   // the reference's batch>1 broadcast takes sample 0's alpha
         const float a0 = alpha[(ab * 3 + 0) * N + n], a1 = alpha[(b * 3 + 1) * N + n], a2 = alpha[(b * 3 + 2) * N + n];
         const float f = a0 + fov[(alpha_from_sample0 ? 0 : b) * N + n];
-        // torch.linspace(-1, 1, steps): start + i*step in the first half, end - (steps-1-i)*step in the second
-        const float lx = xx < W / 2 ? -1.0f + (float)xx * stepx : 1.0f - (float)(W - 1 - xx) * stepx;
-        const float ly = yy < H / 2 ? -1.0f + (float)yy * stepy : 1.0f - (float)(H - 1 - yy) * stepy;
-        const float fx = (float)(W / 2) * (f - 1.0f) * lx + a1;
-        const float fy = (float)(H / 2) * (f - 1.0f) * ly + a2;
+        const WarpPoint wp = warp_point(xx, yy, H, W, f, a1, a2);
         if (flow) {
-            flow[((int64_t)(b * 2 + 0) * N + n) * plane + (int64_t)yy * W + xx] = fx;
-            flow[((int64_t)(b * 2 + 1) * N + n) * plane + (int64_t)yy * W + xx] = fy;
+            flow[((int64_t)(b * 2 + 0) * N + n) * plane + (int64_t)yy * W + xx] = wp.fx;
+            flow[((int64_t)(b * 2 + 1) * N + n) * plane + (int64_t)yy * W + xx] = wp.fy;
         }
-        // normalised grid, then grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
-        const float gx = 2.0f * ((float)xx - fx) / (float)(W > 1 ? W - 1 : 1) - 1.0f;
-        const float gy = 2.0f * ((float)yy - fy) / (float)(H > 1 ? H - 1 : 1) - 1.0f;
         const float gz = 2.0f * (float)n / (float)(N > 1 ? N - 1 : 1) - 1.0f;
-        const float sx = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
-        const float sy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+        const float sx = wp.sx, sy = wp.sy;
         const float sz = ((gz + 1.0f) * 0.5f) * (float)(N - 1);
         const float x0f = floorf(sx), y0f = floorf(sy), z0f = floorf(sz);
         const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
@@ -470,6 +503,119 @@ hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov,
     const int64_t total = (int64_t)B * N * H * W;
     hipLaunchKernelGGL(fov_warp_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, alpha, fov, out, flow, B, C, N, H, W,
                        alpha_from_sample0);
+    return hipGetLastError();
+}
+
+// ---- alignment-network glue (reference End_to_End/End_to_End.py:71-105) -------------------------------------
+// flow_volume: the input of one alpha head, built in one pass from the level's feature volume `fe`
+// (channels-last, C channels): per pixel of slice n
+//     [ warp(fe)[last slice] (C) | warp(fe)[slice n] (C) | flow_x, flow_y of slice n | 6 zero channels ]
+// = torch.cat of End_to_End.py:81-84 padded to a multiple of 8 channels.  The warp is FOV_warp with the
+// warp parameters accumulated so far (bilinear in-plane; the slice coordinate of the reference's 3-D grid is
+// the slice index itself up to 1 ulp, so no blend across slices is done).  One thread per (pixel, 8-channel
+// group): 4 corner records of 16 bytes per part in, one record out.
+template <int PREC>
+__global__ __launch_bounds__(256) void flow_volume_kernel(const uint16_t *__restrict__ fe, uint16_t *__restrict__ out,
+                                                          const float *__restrict__ alpha, const float *__restrict__ fov, int B,
+                                                          int N, int H, int W, int C) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int CG = C / 8, G = 2 * CG + 1, Cout = G * 8;
+    const int64_t total = (int64_t)B * N * H * W * G;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        const int64_t pix = i / G;
+        const int xx = (int)(pix % W);
+        int64_t t = pix / W;
+        const int yy = (int)(t % H);
+        t /= H;
+        const int n = (int)(t % N);
+        const int b = (int)(t / N);
+        const int src = g < CG ? N - 1 : n;   // reference slice for the first C channels, this slice otherwise
+        const float f = alpha[(b * 3 + 0) * N + src] + fov[b * N + src];
+        const WarpPoint wp = warp_point(xx, yy, H, W, f, alpha[(b * 3 + 1) * N + src], alpha[(b * 3 + 2) * N + src]);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (g == G - 1) {
+            v[0] = wp.fx;
+            v[1] = wp.fy;
+        } else {
+            const int cg = g < CG ? g : g - CG;
+            const float x0f = floorf(wp.sx), y0f = floorf(wp.sy);
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const float wx1 = wp.sx - x0f, wy1 = wp.sy - y0f;
+            const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1};
+            const uint16_t *slice = fe + ((int64_t)(b * N + src) * H * W) * (PARTS * C) + cg * 8;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int yc = y0 + dy;
+                if (yc < 0 || yc >= H) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int xc = x0 + dx;
+                    if (xc < 0 || xc >= W) continue;
+                    const uint16_t *rec = slice + ((int64_t)yc * W + xc) * (PARTS * C);
+                    const uint4 h = *reinterpret_cast<const uint4 *>(rec);
+                    uint4 l = make_uint4(0, 0, 0, 0);
+                    if constexpr (PARTS == 2) l = *reinterpret_cast<const uint4 *>(rec + C);
+                    const float wgt = wx[dx] * wy[dy];
+                    float a, c;
+                    Fmt<PREC>::join2(h.x, l.x, a, c); v[0] += a * wgt; v[1] += c * wgt;
+                    Fmt<PREC>::join2(h.y, l.y, a, c); v[2] += a * wgt; v[3] += c * wgt;
+                    Fmt<PREC>::join2(h.z, l.z, a, c); v[4] += a * wgt; v[5] += c * wgt;
+                    Fmt<PREC>::join2(h.w, l.w, a, c); v[6] += a * wgt; v[7] += c * wgt;
+                }
+            }
+        }
+        uint4 h, l;
+        Fmt<PREC>::split2(v[0], v[1], h.x, l.x);
+        Fmt<PREC>::split2(v[2], v[3], h.y, l.y);
+        Fmt<PREC>::split2(v[4], v[5], h.z, l.z);
+        Fmt<PREC>::split2(v[6], v[7], h.w, l.w);
+        uint16_t *dst = out + pix * (PARTS * Cout) + g * 8;
+        *reinterpret_cast<uint4 *>(dst) = h;
+        if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(dst + Cout) = l;
+    }
+}
+
+hipError_t launch_flow_volume(int prec, const uint16_t *fe, uint16_t *out, const float *alpha, const float *fov, int B, int N,
+                              int H, int W, int C, hipStream_t s) {
+    const int64_t total = (int64_t)B * N * H * W * (2 * (C / 8) + 1);
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((flow_volume_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, fe, out, alpha, fov, B, N, H, W, C));
+    return hipGetLastError();
+}
+
+// alpha_mean: the AdaptiveAvgPool3d((10,1,1)) that ends every alpha head (End_to_End.py:46,57,68) fused with the
+// update of End_to_End.py:86-87,94-95,102-103.  head: fp32 (B,3,N,h,w) from the head's last conv; one workgroup
+// per (b, parameter, slice) averages its plane (fixed reduction order: deterministic), writes the raw mean to
+// raw[(b*3+c)*N+n] and adds it — the scale term c == 0 damped by 0.001 — to the accumulated alpha.
+__global__ __launch_bounds__(256) void alpha_mean_kernel(const float *__restrict__ head, float *__restrict__ alpha,
+                                                         float *__restrict__ raw, int N, int64_t hw) {
+    __shared__ float part[4];
+    const int idx = blockIdx.x;
+    const float *src = head + (int64_t)idx * hw;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t i = threadIdx.x;
+    for (; i + 768 < hw; i += 1024) {
+        s0 += src[i];
+        s1 += src[i + 256];
+        s2 += src[i + 512];
+        s3 += src[i + 768];
+    }
+    for (; i < hw; i += 256) s0 += src[i];
+    float sum = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = ((part[0] + part[1]) + (part[2] + part[3])) / (float)hw;
+        const int c = (idx / N) % 3;
+        if (raw) raw[idx] = m;
+        alpha[idx] += (c == 0) ? 0.001f * m : m;
+    }
+}
+
+hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B, int N, int64_t hw, hipStream_t s) {
+    hipLaunchKernelGGL(alpha_mean_kernel, dim3(B * 3 * N), dim3(256), 0, s, head, alpha, raw, N, hw);
     return hipGetLastError();
 }
 

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdffw.so")
 
 PRECISIONS = {"bf16x3": 0, "fp16": 1, "bf16": 2}
-NET_DEPTH = 0
+NET_DEPTH = 0   # Depth_Estimation_Network.Network: DFF_net alone
+NET_E2E = 1     # End_to_End.Network: alignment network + FOV warp + DFF_net
 
 
 class DffwError(RuntimeError):
@@ -57,6 +58,8 @@ def _load():
            POINTER(c_void_p), c_void_p, c_int64, c_void_p]
     lib.dffw_forward.argtypes = fwd
     lib.dffw_forward_taps.argtypes = fwd + [POINTER(_Tap), c_int]
+    lib.dffw_forward_e2e.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_int, c_int, c_int, c_int,
+                                     POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_void_p, POINTER(_Tap), c_int]
     lib.dffw_profile_enable.argtypes = [c_void_p, c_int]
     lib.dffw_profile_collect.argtypes = [c_void_p, POINTER(_Prof), c_int]
     lib.dffw_op_conv3d.argtypes = [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int,
@@ -77,7 +80,7 @@ ABI_SYMBOLS = (
     "dffw_version", "dffw_last_error", "dffw_param_count", "dffw_param_info", "dffw_engine_create",
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
     "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
-    "dffw_op_fov_warp",
+    "dffw_op_fov_warp", "dffw_forward_e2e",
 )
 
 
@@ -189,8 +192,37 @@ class Engine:
             return tuple(outs), bufs
 
 
+    def forward_e2e(self, FS, focus_dists, fovs, taps=None):
+        """End_to_End.Network.forward: FS (B,3,10,H,W), focus_dists broadcastable to (B,10,H,W), fovs with B*10
+        elements in (sample, slice) order.  Returns (mid_out, pred1, pred2, pred3, aligned FS); with ``taps``
+        also a dict of intermediate values (head3/head2/head1/alpha as (B,3,N), plus the DFF_net taps)."""
+        B, C, N, H, W = FS.shape
+        FS = FS.contiguous()
+        fd = focus_dists.expand(B, N, H, W)
+        fov = fovs.reshape(B, N).contiguous()
+        strides = (c_int64 * 4)(*fd.stride())
+        outs = [torch.empty((B, H, W), dtype=torch.float32, device=FS.device) for _ in range(4)]
+        aligned = torch.empty_like(FS)
+        optrs = (c_void_p * 4)(*[o.data_ptr() for o in outs])
+        with self._lock, torch.cuda.device(self.index):
+            ws = self._workspace(B, N, H, W)
+            bufs, tarr, nt = {}, None, 0
+            if taps:
+                shapes = _tap_shapes(B, N, H, W)
+                bufs = {nm: torch.empty(shapes[nm], dtype=torch.float32, device=FS.device) for nm in taps}
+                tarr = (_Tap * len(bufs))(*[_Tap(nm.encode(), c_void_p(t.data_ptr()), t.numel()) for nm, t in bufs.items()])
+                nt = len(bufs)
+            _check(lib.dffw_forward_e2e(self._h, c_void_p(FS.data_ptr()), c_void_p(fd.data_ptr()), strides,
+                                        c_void_p(fov.data_ptr()), B, N, H, W, optrs, c_void_p(aligned.data_ptr()),
+                                        c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index), tarr, nt),
+                   "dffw_forward_e2e")
+        res = tuple(outs) + (aligned,)
+        return (res, bufs) if taps else res
+
+
 def _tap_shapes(B, N, H, W):
     return {
+        "head3": (B, 3, N), "head2": (B, 3, N), "head1": (B, 3, N), "alpha": (B, 3, N),
         "V1": (B, 8, N, H, W), "V2": (B, 16, N, H // 2, W // 2), "V3": (B, 32, N, H // 4, W // 4),
         "FS_volume": (B, 32, N, H // 8, W // 8), "conf": (B, N, H // 8, W // 8),
         "cost1": (B, N, H // 4, W // 4), "cost2": (B, N, H // 2, W // 2), "cost3": (B, N, H, W),

@@ -33,7 +33,9 @@ extern "C" {
 #define DFFW_PREC_BF16 2   /* single bf16 product (~5e-3..1e-2 rel-L2; does not meet the 1e-3 target) */
 
 /* Which network of the reference an engine implements. */
-#define DFFW_NET_DEPTH 0 /* Depth_Estimation_Network.Network  (DEN.py:7-13)  */
+#define DFFW_NET_DEPTH 0 /* Depth_Estimation_Network.Network  (DEN.py:7-13): DFF_net alone, 384 entries */
+#define DFFW_NET_E2E 1   /* End_to_End.Network (End_to_End/End_to_End.py:9-16): FlowNetwork alignment + DFF_net, 522 entries */
+#define DFFW_E2E_SLICES 10 /* the alignment heads end in AdaptiveAvgPool3d((10,1,1)) (End_to_End.py:46,57,68) */
 
 typedef struct dffw_engine dffw_engine;
 
@@ -48,7 +50,9 @@ typedef struct dffw_tensor {
 
 /* Optional debug tap: after the forward, the named intermediate volume is written to `dst`
  * (device, fp32, reference layout (B,C,N,h,w), or (B,N,h,w) for the 1-channel score volumes).
- * Names: V1 V2 V3 FS_volume conf cost1 cost2 cost3. */
+ * Names: V1 V2 V3 FS_volume conf cost1 cost2 cost3; for dffw_forward_e2e also
+ * head3 head2 head1 (each alpha head's output before the 0.001 damping, (B,3,N)) and alpha (the accumulated
+ * warp parameters the stack is finally warped with, (B,3,N)). */
 typedef struct dffw_tap {
     const char *name;
     float *dst;
@@ -73,8 +77,9 @@ int dffw_engine_create(int device, int net, const dffw_tensor *tensors, int n_te
 void dffw_engine_destroy(dffw_engine *e);
 int dffw_engine_precision(const dffw_engine *e);
 
-/* Bytes of scratch dffw_forward needs for one (B,N,H,W) call; the caller allocates it (torch's
- * caching allocator in the Python binding) so nothing is hipMalloc'ed per call. */
+/* Bytes of scratch the engine's forward (dffw_forward for DFFW_NET_DEPTH, dffw_forward_e2e for
+ * DFFW_NET_E2E) needs for one (B,N,H,W) call; the caller allocates it (torch's caching allocator in the
+ * Python binding) so nothing is hipMalloc'ed per call. */
 int64_t dffw_workspace_bytes(const dffw_engine *e, int B, int N, int H, int W);
 
 /* Replaces `mid, p1, p2, p3 = model(FS, focus_dists)` (test.py:118; DFF_net.forward DEN.py:74-127).
@@ -94,6 +99,21 @@ int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists,
                       const int64_t fd_strides[4], int B, int N, int H, int W, float *const out[4],
                       void *workspace, int64_t workspace_bytes, void *hip_stream,
                       const dffw_tap *taps, int n_taps);
+
+/* Replaces `mid, p1, p2, p3, aligned = model(FS, focus_dists, FOVs)` of the End_to_End variant
+ * (End_to_End/End_to_End.py:13-16; call site End_to_End/TRS.py:44): FlowNetwork.forward (End_to_End.py:71-105)
+ * estimates per-slice warp parameters coarse to fine and warps the stack (FOV_warp, End_to_End.py:106-134),
+ * DFF_net runs on the aligned stack.  Engine must have been created with DFFW_NET_E2E.
+ *   FS, focus_dists, fd_strides, out[4], workspace, hip_stream   as for dffw_forward, N must be 10
+ *   fovs          device fp32 (B,N): relative field of view of every slice (Test_dataloader.py:56-70)
+ *   aligned       device fp32 (B,3,N,H,W): receives the aligned focal stack (5th return value); required
+ *   taps          optional (NULL, 0)
+ * Batch > 1 uses per-sample warp parameters, i.e. equals a stack of batch-1 reference calls (the reference's
+ * own batch>1 path broadcasts sample 0's scale term by accident and is only ever run with batch 1, TRS.py:23). */
+int dffw_forward_e2e(dffw_engine *e, const float *FS, const float *focus_dists,
+                     const int64_t fd_strides[4], const float *fovs, int B, int N, int H, int W,
+                     float *const out[4], float *aligned, void *workspace, int64_t workspace_bytes,
+                     void *hip_stream, const dffw_tap *taps, int n_taps);
 
 /* ---- per-launch timing (bench.py's roofline figures) -------------------------------------------
  * With profiling enabled every kernel launch of the next forward is bracketed by HIP events on the
@@ -134,8 +154,8 @@ int dffw_op_regress(int device, const float *score, int B, int N, int h, int w, 
                     const float *focus_dists, const int64_t fd_strides[4], float *depth,
                     void *hip_stream);
 
-/* First operator of the End_to_End alignment path (the rest of that path is
- * not built yet).  Replaces FlowNetwork.FOV_warp (End_to_End/End_to_End.py:106-134): warps x (B,C,N,H,W)
+/* The warp operator of the End_to_End alignment path on its own.
+ * Replaces FlowNetwork.FOV_warp (End_to_End/End_to_End.py:106-134): warps x (B,C,N,H,W)
  * by the per-slice field-of-view scale and translation.  alpha: device fp32 (B,3,N) = (scale offset,
  * x shift, y shift) per slice; fovs: device fp32 (B,N); out: (B,C,N,H,W); flow: (B,2,N,H,W) or NULL (the
  * pixel-unit flow the reference returns as its second value).  alpha_from_sample0 != 0 reproduces the
