@@ -11,6 +11,9 @@ driver launches one rank per GPU with torch.distributed.run; every rank processe
 stacks (weak scaling, no data-path collective) and the per-rank depth maps are collected with one
 RCCL all-gather inside the timed step.
 
+`--workload e2e` runs BASELINE.json's config 5 instead (not the default line): the End_to_End variant —
+alignment network + FOV warp + DFF_net (End_to_End/End_to_End.py) — on 10-slice 480x640 stacks, batch 8.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel (by summed time) of one profiled forward: algorithmic FLOPs per
                 launch / HIP-event duration per launch against the dense MFMA peak of the
@@ -39,20 +42,24 @@ PEAK_MFMA_TFLOPS = 2500.0         # dense bf16/f16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-def build_model(precision, device):
-    from dffinthewild_amd.Depth_Estimation_Network import Network
-    entries = list(graph.param_entries(graph.dff_net_convs()))
+def build_model(precision, device, workload="depth"):
+    if workload == "e2e":
+        from dffinthewild_amd.End_to_End import Network
+        entries = list(graph.param_entries(graph.e2e_convs()))
+    else:
+        from dffinthewild_amd.Depth_Estimation_Network import Network
+        entries = list(graph.param_entries(graph.dff_net_convs()))
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, seed=0, profile="smooth").items()}
     model = Network(precision=precision)
     model.load_state_dict(sd)
     return model.to(device).eval(), sd
 
 
-def roofline_from_profile(model, FS, fd, device, precision="bf16x3"):
+def roofline_from_profile(model, inputs, device, precision="bf16x3"):
     eng = model._engine_on(device)
     eng.profile(True)
     with torch.no_grad():
-        model(FS, fd)
+        model(*inputs)
     torch.cuda.synchronize(device)
     rows = eng.profile_collect()
     eng.profile(False)
@@ -121,6 +128,38 @@ def roofline_from_profile(model, FS, fd, device, precision="bf16x3"):
     return roof, per_kernel, rows
 
 
+def relative_fovs(B, N):
+    """Relative field of view per slice, decreasing to 1 at the last (reference) slice (Test_dataloader.py:56-70)."""
+    f = 1.0 + 0.06 * torch.arange(N - 1, -1, -1, dtype=torch.float32) / max(N - 1, 1)
+    return f.reshape(1, 1, N, 1, 1).repeat(B, 1, 1, 1, 1)
+
+
+def cpu_baseline_e2e(sd, seconds, H, W, batch=2):
+    """Oracle End_to_End forward (oracle/cpu_ref.py e2e_forward) on `batch` stacks of the same shape, same
+    thread policy as cpu_baseline."""
+    from oracle import cpu_ref
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 32)
+    torch.set_num_threads(cores)
+    FS = torch.from_numpy(synth.focal_stack(batch, 10, H, W, seed=1000))
+    fd = torch.from_numpy(synth.focus_dists(batch, 10, 1, 1))
+    fov = relative_fovs(batch, 10)
+    with torch.no_grad():
+        ref = cpu_ref.e2e_forward(sd, FS, fd, fov)
+        times = []
+        t_end = time.time() + seconds
+        while len(times) < 1 or (time.time() < t_end and len(times) < 10):
+            t0 = time.perf_counter()
+            cpu_ref.e2e_forward(sd, FS, fd, fov)
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    base = {"value": round(batch / best, 3), "unit": "stacks/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} End_to_End forwards of one batch of {batch} 10x3x{H}x{W} stacks after 1 warm-up, best of "
+                      f"(mean {sum(times)/len(times):.2f} s per batch); oracle/cpu_ref.py e2e_forward; {avail} logical cores "
+                      f"available, {cores} threads used"}
+    return base, ref
+
+
 def cpu_baseline(sd, seconds, batch=8):
     """Oracle forward on a bounded sample (one batch of `batch` 10x256x256 stacks, repeated) on this box's
     host cores.  PyTorch-CPU stops scaling (and degrades) past ~32 threads for these small convs
@@ -163,9 +202,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="stacks per GPU per step")
+    ap.add_argument("--workload", choices=("depth", "e2e"), default="depth",
+                    help="depth: DFF_net forward (BASELINE config 3/4, the headline); e2e: End_to_End forward (config 5)")
+    ap.add_argument("--batch", type=int, default=None, help="stacks per GPU per step (default 32; 8 for --workload e2e)")
     ap.add_argument("--slices", type=int, default=10)
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--size", type=int, default=None, help="square stack size (default 256)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--precision", default=os.environ.get("DFFW_PRECISION", "bf16x3"))
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,14 +229,23 @@ def main():
     if world > 1:
         ddist.init_process_group("nccl")
 
-    B, N, S = args.batch, args.slices, args.size
-    model, sd = build_model(args.precision, device)
-    FS = torch.from_numpy(synth.focal_stack(B, N, S, S, seed=1000 + rank)).to(device)
-    fd = torch.from_numpy(synth.focus_dists(B, N, S, S)).to(device)       # dense tile, as test_Dataloader.py:24
+    e2e = args.workload == "e2e"
+    B, N = args.batch or (8 if e2e else 32), args.slices
+    Hh = args.height or args.size or (480 if e2e else 256)
+    Ww = args.width or args.size or (640 if e2e else 256)
+    S = Hh if Hh == Ww else None
+    model, sd = build_model(args.precision, device, args.workload)
+    FS = torch.from_numpy(synth.focal_stack(B, N, Hh, Ww, seed=1000 + rank)).to(device)
+    if e2e:
+        fd = torch.from_numpy(synth.focus_dists(B, N, 1, 1)).to(device)   # (B,10,1,1), as Test_dataloader.py:52-54
+        inputs = (FS, fd, relative_fovs(B, N).to(device))
+    else:
+        fd = torch.from_numpy(synth.focus_dists(B, N, Hh, Ww)).to(device)  # dense tile, as test_Dataloader.py:24
+        inputs = (FS, fd)
 
     def step():
         with torch.no_grad():
-            outs = model(FS, fd)
+            outs = model(*inputs)
             gathered = ddist.all_gather_depth(outs[3]) if world > 1 else outs[3]
         return outs, gathered
 
@@ -218,25 +270,29 @@ def main():
 
     result = None
     if rank == 0:
-        scale = (N * S * S) / (10 * 256 * 256)
+        scale = (N * Hh * Ww) / (10 * 256 * 256)
         result = {
-            "metric": "focal-stacks/sec (10x3x256x256)", "value": round(value, 2), "unit": "stacks/s",
+            "metric": "focal-stacks/sec (10x3x480x640, End_to_End)" if e2e else "focal-stacks/sec (10x3x256x256)",
+            "value": round(value, 2), "unit": "stacks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA operands hi+lo, fp32 accumulate, fp32-accurate)",
                       "fp16": "f16 (MFMA, fp32 accumulate)", "bf16": "bf16 (MFMA, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"DFF_net forward, {N}-slice 3x{S}x{S} focal stacks, batch {B} per GPU "
-                                   f"(BASELINE.json config 3{'/4' if world > 1 else ''}), dense focus_dists, "
-                                   f"synthetic weights seed 0",
-                       "batch_per_gpu": B, "global_batch": B * world, "slices": N, "height": S, "width": S,
+            "config": {"workload": (f"End_to_End forward (alignment network + FOV warp + DFF_net), {N}-slice 3x{Hh}x{Ww} focal "
+                                    f"stacks, batch {B} per GPU (BASELINE.json config 5), broadcast focus_dists, synthetic "
+                                    f"weights seed 0") if e2e else
+                                   (f"DFF_net forward, {N}-slice 3x{Hh}x{Ww} focal stacks, batch {B} per GPU "
+                                    f"(BASELINE.json config 3{'/4' if world > 1 else ''}), dense focus_dists, "
+                                    f"synthetic weights seed 0"),
+                       "batch_per_gpu": B, "global_batch": B * world, "slices": N, "height": Hh, "width": Ww,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of pred3" if world > 1 else "single GPU",
                        "precision": args.precision},
-            "forward_tflops_algorithmic": round(value * GFLOP_PER_STACK * scale / 1e3, 2),
+            "forward_tflops_algorithmic": round(value * GFLOP_PER_STACK * scale / 1e3, 2),   # DFF_net's convs only
         }
     if rank == 0 and not args.no_roofline:
-        roof, per_kernel, rows = roofline_from_profile(model, FS, fd, device, args.precision)
+        roof, per_kernel, rows = roofline_from_profile(model, inputs, device, args.precision)
         result["roofline"] = roof
         result["kernels"] = per_kernel
         if args.dump_layers:
@@ -244,9 +300,9 @@ def main():
                 f.write("kernel\tlayer\tgflop\talg_MB\tms\ttflops\talg_GBs\n")
                 for k, l, fl, by, ms in rows:
                     f.write(f"{k}\t{l}\t{fl/1e9:.3f}\t{by/1e6:.2f}\t{ms:.4f}\t{fl/(ms*1e-3)/1e12 if ms else 0:.2f}\t{by/(ms*1e-3)/1e9 if ms else 0:.1f}\n")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and (N, S) == (10, 256):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and (e2e or (N, S) == (10, 256)):
         from oracle import cpu_ref
-        base, ref = cpu_baseline(sd, args.cpu_seconds)
+        base, ref = cpu_baseline_e2e(sd, args.cpu_seconds, Hh, Ww) if e2e else cpu_baseline(sd, args.cpu_seconds)
         result["cpu_baseline"] = base
         nb = min(ref[3].shape[0], outs[3].shape[0])
         got = outs[3][:nb].float().cpu()

@@ -49,6 +49,9 @@ struct LayerDef {
     bool transposed;       // ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1)
     bool live;
     bool bias;
+    std::string shortcut = "";  // prefix of a bias-free 1x1x1 stride-1 conv over a SECOND input whose result is added to this
+                                // layer's: folded into this layer's weights as centre-tap columns of a channel concat
+    bool folded = false;        // this layer is such a shortcut: it is never launched on its own
 };
 
 struct ParamInfo {
@@ -106,6 +109,10 @@ class Table {
         conv(p + ".conv.0", cin, cout, 1, 3, 3, s, 0, 1, 1, 1, true);
         conv(p + ".conv.2", cout, cout, 1, 3, 3, 1, 0, 1, 1, 1, true);
         conv(p + ".feature", cin, cout, 1, 1, 1, s, 0, 0, 0, 1, false);
+        if (s == 1) {   // same resolution on both branches: the shortcut rides in conv.2's contraction
+            layers[by_name[p + ".conv.2.0"]].shortcut = p + ".feature";
+            layers[by_name[p + ".feature"]].folded = true;
+        }
     }
     void alpha_head(const std::string &p, int cin, int c) {  // conv1/conv2/conv3 of FlowNetwork, End_to_End.py:37-69
         conv(p + ".0", cin, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
@@ -277,6 +284,7 @@ struct PackedConv {
     std::vector<Variant> variants;
     TilePack tile;
     float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
+    int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
 
 static void free_packed(PackedConv &pc) {
@@ -299,13 +307,16 @@ static void free_packed(PackedConv &pc) {
 }
 
 // weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
+// shortcut_w: (cout, shortcut_cin) weights of a folded 1x1x1 shortcut over a second input, or null.
 static int pack_conv(const LayerDef &L, int prec, const float *weight, const float *bn, const float *conv_bias,
-                     PackedConv &pc) {
+                     PackedConv &pc, const float *shortcut_w = nullptr, int shortcut_cin = 0) {
     pc.def = L;
     pc.nt = conv_nt_for(L.cout);
     const int parts = prec_parts(prec);
-    const int cin_pad = (L.cin + 7) / 8 * 8;
+    const int cin_own = (L.cin + 7) / 8 * 8;
+    const int cin_pad = cin_own + (shortcut_w ? (shortcut_cin + 7) / 8 * 8 : 0);   // channels of the (virtual) input concat
     const int c8n = cin_pad / 8;
+    pc.cin_all = cin_pad;
 
     // fold BatchNorm (eval mode, eps 1e-5): y = conv(x)*scale + shift
     std::vector<double> scale(L.cout, 1.0), shift(L.cout, 0.0);
@@ -359,6 +370,11 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
 
     const int kvol = L.kd * L.kh * L.kw;
     auto wval = [&](int cout, int cin, const Tap &t) -> double {
+        if (cin >= cin_own) {   // folded shortcut: its own weight on the centre tap (not scaled by this layer's BatchNorm)
+            const int ce = cin - cin_own;
+            return (ce < shortcut_cin && t.dz == 0 && t.dy == 0 && t.dx == 0) ? (double)shortcut_w[(int64_t)cout * shortcut_cin + ce] : 0.0;
+        }
+        if (cin >= L.cin) return 0.0;
         const int64_t kidx = ((int64_t)t.kz * L.kh + t.ky) * L.kw + t.kx;
         const int64_t i = L.transposed ? ((int64_t)cin * L.cout + cout) * kvol + kidx : ((int64_t)cout * L.cin + cin) * kvol + kidx;
         return (double)weight[i] * scale[cout];
@@ -390,7 +406,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                         const int k = kc * 32 + (lane >> 4) * 8 + j;
                         const int tapi = k / cin_pad, cin = k % cin_pad;
                         float val = 0.f;
-                        if (cout < L.cout && tapi < (int)taps.size() && cin < L.cin) val = (float)wval(cout, cin, taps[tapi]);
+                        if (cout < L.cout && tapi < (int)taps.size()) val = (float)wval(cout, cin, taps[tapi]);
                         uint16_t hi, lo;
                         host_split(prec, val, hi, lo);
                         const size_t base = (((size_t)kc * pc.nt + nt) * parts) * 512 + (size_t)lane * 8 + j;
@@ -432,7 +448,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
             for (int jx = 0; jx < 9; jx += 2) tapsets[0].push_back(Tap{0, 2 * ky - 8, 2 * jx - 6, 0, ky, jx});
     }
     auto wval_t = [&](int cout, int cin, const Tap &t) -> double {
-        if (!stem) return cin < L.cin ? wval(cout, cin, t) : 0.0;
+        if (!stem) return wval(cout, cin, t);
         if ((cin & 3) == 3) return 0.0;
         Tap u = t;
         if (cin >= 4) {
@@ -665,7 +681,7 @@ struct Run {
         const PackedConv &pc = it->second;
         const LayerDef &L = pc.def;
         const int cin = in0.C + (o.in1 ? o.in1->C : 0);
-        const int cin_pad = (L.cin + 7) / 8 * 8;
+        const int cin_pad = pc.cin_all;
         if (cin != cin_pad) {
             err = fail(DFFW_EINVAL, "layer %s expects %d input channels, got %d", name.c_str(), cin_pad, cin);
             return out;
@@ -1070,6 +1086,12 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
 static Act of_block(Run &r, const std::string &p, const Act &x) {
     ConvOpt rl; rl.relu = 1;
     Act t = r.conv(p + ".conv.0.0", x, rl);
+    if (r.e->convs.find(p + ".feature") == r.e->convs.end()) {   // stride-1 block: shortcut folded into conv.2 over [t | x]
+        ConvOpt o; o.relu = 1; o.in1 = &x;
+        Act out = r.conv(p + ".conv.2.0", t, o);
+        r.drop(t);
+        return out;
+    }
     Act f = r.conv(p + ".feature", x);
     ConvOpt o; o.relu = 1; o.res0 = &f;
     Act out = r.conv(p + ".conv.2.0", t, o);
@@ -1218,7 +1240,15 @@ int dffw_engine_create(int device, int net, const dffw_tensor *tensors, int n_te
     const Table &t = table_for(net);
     for (const LayerDef &L : t.layers) {
         if (!L.live) continue;
-        const float *w = nullptr, *cb = nullptr;
+        const float *w = nullptr, *cb = nullptr, *sw = nullptr;
+        int scin = 0;
+        if (!L.shortcut.empty()) {
+            const LayerDef &S = t.layers[t.by_name.at(L.shortcut)];
+            scin = S.cin;
+            int rc2 = need(S.conv + ".weight", (int64_t)S.cin * S.cout, &sw);
+            if (rc2) return rc2;
+        }
+        if (L.folded) continue;
         int rc = need(L.conv + ".weight", (int64_t)L.cin * L.cout * L.kd * L.kh * L.kw, &w);
         if (rc) return rc;
         if (L.bias && (rc = need(L.conv + ".bias", L.cout, &cb))) return rc;
@@ -1233,7 +1263,7 @@ int dffw_engine_create(int device, int net, const dffw_tensor *tensors, int n_te
             }
         }
         PackedConv &pc = e->convs[L.conv];
-        rc = pack_conv(L, precision, w, bn.empty() ? nullptr : bn.data(), cb, pc);
+        rc = pack_conv(L, precision, w, bn.empty() ? nullptr : bn.data(), cb, pc, sw, scin);
         if (rc) return rc;
     }
     *out = e.release();
