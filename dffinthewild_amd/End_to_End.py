@@ -35,8 +35,10 @@ class Network(_DepthNetwork):
     def _check_e2e(self, FS, focus_dists, FOVs):
         if not torch.is_tensor(FOVs):
             raise TypeError("FOVs must be a tensor")
-        FS, focus_dists = self._check_inputs(FS, focus_dists)
+        if not (torch.is_tensor(FS) and torch.is_tensor(focus_dists)):
+            raise TypeError("FS and focus_dists must be tensors")
         _graph.check_e2e_shape(FS.shape, focus_dists.shape, FOVs.shape)
+        FS, focus_dists = self._check_inputs(FS, focus_dists)
         if FOVs.device != FS.device:
             raise RuntimeError(f"FS is on {FS.device} but FOVs on {FOVs.device}")
         if FOVs.dtype != torch.float32:

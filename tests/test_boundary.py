@@ -40,6 +40,26 @@ def test_native_param_table_matches_python_table(eng):
     assert len(dead) == 24 and all(("pre_conv" in k or "redir3" in k) for k in dead)
 
 
+def test_native_param_table_e2e(eng):
+    """DFFW_NET_E2E: the 522 entries of End_to_End.Network in the reference's registration order."""
+    native = eng.param_table(eng.NET_E2E)
+    rows = list(graph.param_entries(graph.e2e_convs()))
+    assert len(native) == len(rows) == 522
+    for (nk, nshape, flags), (k, shape, role, is_buf) in zip(native, rows):
+        assert nk == k and tuple(nshape) == tuple(shape)
+        assert bool(flags & 1) == is_buf
+    from dffinthewild_amd.End_to_End import Network
+    m = Network()
+    assert list(m.state_dict().keys()) == [k for k, *_ in rows]
+    new = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(rows).items()}
+    m.load_state_dict({"module." + k: v for k, v in new.items()})
+    m.eval()
+    with pytest.raises(RuntimeError):                      # CPU tensors: no fallback
+        m(torch.zeros(1, 3, 10, 32, 32), torch.zeros(1, 10, 1, 1), torch.ones(1, 1, 10, 1, 1))
+    with pytest.raises(ValueError):                        # the heads pool to 10 slices
+        m(torch.zeros(1, 3, 5, 32, 32), torch.zeros(1, 5, 1, 1), torch.ones(1, 1, 5, 1, 1))
+
+
 def test_state_dict_contract(eng):
     from dffinthewild_amd import Network
     m = Network()
