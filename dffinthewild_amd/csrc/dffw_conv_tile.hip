@@ -410,7 +410,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     X(19, G2S1, 4, 5, 4, 16, 16, 0)  \
     X(20, G2S1, 4, 5, 4, 16, 8, 0)   \
     X(21, G2S2, 1, 5, 4, 16, 8, 0)   \
-    X(22, G2S2, 2, 5, 4, 16, 8, 0)
+    X(22, G2S2, 2, 5, 4, 16, 8, 0)   \
+    X(23, G3T, 1, 5, 4, 16, 32, 0)   \
+    X(24, G3T, 2, 5, 4, 16, 32, 1)   \
+    X(25, G3T, 4, 5, 4, 16, 32, 1)
 
 #define X_CFG(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                             \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \

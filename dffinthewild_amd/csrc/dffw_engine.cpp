@@ -458,7 +458,10 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         return wval(cout, cin & 3, u);
     };
     if (geo >= 0 && cin_t % 8 == 0) {
-        const int cg = (geo == G3S2 || geo == G2S2) ? 8 : (cin_t % 16 == 0 ? 16 : 8);
+        int cg = (geo == G3S2 || geo == G2S2) ? 8 : (cin_t % 16 == 0 ? 16 : 8);
+        // transposed conv: its 4 sub-pixel passes share one LDS image only when the whole contraction depth is
+        // staged at once, so 32-channel groups (one fill instead of 4 x 2) where an instantiation exists
+        if (geo == G3T && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;
         const TileCfg *cfg = tile_cfg_find(geo, pc.nt, cg);
         if (cfg && cin_t % cg == 0) {
             const GeoInfo gi = geo_info(geo);
@@ -873,7 +876,9 @@ struct Run {
 };
 
 // SRD block (DEN.py:317-330): x -> feat = relu(x + BN(conv(relu(BN(conv x))))) ; feat + relu(conv1(relu(conv3x1x1 feat)))
-static Act srd(Run &r, const std::string &p, Act &x, bool drop_x) {
+// pooled (optional): receives max_pool(1,2,2) of the block's output when the fused attention kernel can produce it
+// on the way (else it is left empty and the caller pools separately).
+static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = nullptr) {
     ConvOpt o1; o1.relu = 1;
     Act t = r.conv(p + ".Focus_Measure.conv.0.0", x, o1);
     ConvOpt o2; o2.relu = 1; o2.res0 = &x;
@@ -886,13 +891,15 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x) {
     if (srd_attention_supported(feat.C) && i3 != r.e->convs.end() && i1 != r.e->convs.end() && i3->second.w32 && i1->second.w32 &&
         !getenv_flag("DFFW_NO_FUSED_ATTENTION")) {
         out = r.act(feat.B, feat.N, feat.H, feat.W, feat.C);
+        const bool with_pool = pooled && !getenv_flag("DFFW_NO_FUSED_POOL");
+        if (with_pool) *pooled = r.act(feat.B, feat.N, feat.H / 2, feat.W / 2, feat.C);
         if (r.ok() && !r.dry) {
             char kn[64];
             snprintf(kn, sizeof kn, "dffw::srd_attention_kernel<%d, %d>", r.e->prec, feat.C);
             const double px = (double)feat.pixels();
-            r.prof_begin(kn, p + ".N_ch_attention", 2.0 * px * 4 * feat.C * feat.C, 2.0 * px * feat.C * r.elem_bytes());
+            r.prof_begin(kn, p + ".N_ch_attention", 2.0 * px * 4 * feat.C * feat.C, (with_pool ? 2.25 : 2.0) * px * feat.C * r.elem_bytes());
             r.check(launch_srd_attention(r.e->prec, feat.p, out.p, i3->second.w32, i1->second.w32, feat.B, feat.N, feat.H, feat.W,
-                                         feat.C, r.s), "srd_attention");
+                                         feat.C, with_pool ? pooled->p : nullptr, r.s), "srd_attention");
             r.prof_end();
         }
     } else {
@@ -907,9 +914,9 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x) {
 }
 
 // EFD block (DEN.py:306-315)
-static Act efd(Run &r, const std::string &p, const Act &x) {
+static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr) {
     Act a = r.conv(p + ".stride_conv.0", x);
-    Act m = r.pool(x, 0, 2);
+    Act m = (pooled && pooled->p) ? *pooled : r.pool(x, 0, 2);
     ConvOpt o; o.relu = 1; o.res0 = &a;
     Act out = r.conv(p + ".max_pooling.1.0", m, o);
     r.drop(m);
@@ -1016,12 +1023,13 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     }
     Act stem = r.conv(P + ".FM_measure.Focus_extraction.0.0", in, rl);
     r.drop(in);
-    Act v1 = srd(r, P + ".FM_measure.Focus_extraction.2", stem, true);
+    Act v1p, v2p;   // max-pooled copies written by the attention kernels on the way (EFD's second branch)
+    Act v1 = srd(r, P + ".FM_measure.Focus_extraction.2", stem, true, &v1p);
     r.tap("V1", v1);
-    Act e1 = efd(r, P + ".FM_conv1.0", v1);
-    Act v2 = srd(r, P + ".FM_conv1.1", e1, true);
+    Act e1 = efd(r, P + ".FM_conv1.0", v1, &v1p);
+    Act v2 = srd(r, P + ".FM_conv1.1", e1, true, &v2p);
     r.tap("V2", v2);
-    Act e2 = efd(r, P + ".FM_conv2.0", v2);
+    Act e2 = efd(r, P + ".FM_conv2.0", v2, &v2p);
     Act v3 = srd(r, P + ".FM_conv2.1", e2, true);
     r.tap("V3", v3);
 

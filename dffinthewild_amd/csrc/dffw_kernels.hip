@@ -333,17 +333,29 @@ hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *o
 // two re-reads hit in L2: HBM sees every vector once) and writes the result once — the unfused form
 // moves 5x the bytes.  The 4*C*C weights are wave-uniform: they arrive through scalar loads and feed
 // the FMAs as SGPR operands, in exact fp32 (no loop around them, so they are never spilled).
-template <int PREC, int C>
+// Threads are laid out so that 4 consecutive lanes hold a 2x2 pixel block (a wave = 2 rows x 32 columns, still
+// 1 KiB contiguous per row): when `pooled` is given, the (1,2,2) max-pool of the result that the following EFD
+// block needs (DEN.py:310) is reduced across the quad with two DPP shuffles per channel and written by the
+// quad's first lane, which replaces a separate pooling pass over the full-resolution volume.  H, W even.
+template <int PREC, int C, bool POOL>
 __global__ __launch_bounds__(256) void srd_attention_kernel(const uint16_t *__restrict__ feat, uint16_t *__restrict__ out,
                                                             const float *__restrict__ w3,  // [kz][ci][co]
                                                             const float *__restrict__ w1,  // [ci][co]
-                                                            int B, int N, int HW) {
+                                                            int B, int N, int H, int W, uint16_t *__restrict__ pooled) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr int REC = PARTS * C;  // 16-bit elements per pixel record
+    const int HW = H * W;
     const int64_t total = (int64_t)B * N * HW;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total) return;
-    const int n = (int)((p / HW) % N);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;          // total is a multiple of 4: whole quads leave together
+    const int64_t q = t >> 2;
+    const int W2 = W >> 1, H2 = H >> 1;
+    const int qx = (int)(q % W2);
+    const int64_t qr = q / W2;
+    const int qy = (int)(qr % H2);
+    const int64_t bn = qr / H2;
+    const int n = (int)(bn % N);
+    const int64_t p = (bn * H + 2 * qy + (int)((t >> 1) & 1)) * W + 2 * qx + (int)(t & 1);
     const uint16_t *src = feat + p * REC;
     const int64_t nstride = (int64_t)HW * REC;
 
@@ -386,6 +398,7 @@ __global__ __launch_bounds__(256) void srd_attention_kernel(const uint16_t *__re
         for (int co = 0; co < C; ++co) o[co] = fmaf(w1[ci * C + co], r, o[co]);
     }
     uint16_t *w = out + p * REC;
+    short8 ph[C / 8], pl[C / 8];
 #pragma unroll
     for (int c8 = 0; c8 < C / 8; ++c8) {
         short8 h, l;
@@ -395,23 +408,45 @@ __global__ __launch_bounds__(256) void srd_attention_kernel(const uint16_t *__re
             Fmt<PREC>::split(fc[c8 * 8 + j] + fmaxf(o[c8 * 8 + j], 0.f), hi, lo);
             h[j] = (short)hi;
             l[j] = (short)lo;
+            if constexpr (POOL) {   // max over the quad of the value as stored (what a separate pooling pass would read)
+                float m = Fmt<PREC>::join(hi, lo);
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+                Fmt<PREC>::split(m, hi, lo);
+                ph[c8][j] = (short)hi;
+                pl[c8][j] = (short)lo;
+            }
         }
         *reinterpret_cast<short8 *>(w + c8 * 8) = h;
         if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(w + C + c8 * 8) = l;
+    }
+    if constexpr (POOL) {
+        if ((t & 3) == 0) {
+            uint16_t *pw = pooled + ((bn * H2 + qy) * W2 + qx) * REC;
+#pragma unroll
+            for (int c8 = 0; c8 < C / 8; ++c8) {
+                *reinterpret_cast<short8 *>(pw + c8 * 8) = ph[c8];
+                if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(pw + C + c8 * 8) = pl[c8];
+            }
+        }
     }
 }
 
 bool srd_attention_supported(int C) { return C == 8 || C == 16; }
 
 hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, const float *w3, const float *w1, int B, int N,
-                                int H, int W, int C, hipStream_t s) {
-    const int HW = H * W;
-    const int64_t total = (int64_t)B * N * HW;
+                                int H, int W, int C, uint16_t *pooled, hipStream_t s) {
+    if ((H | W) & 1) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * N * H * W;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (C == 8) {
-        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 8>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, HW));
+    if (C == 8 && pooled) {
+        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 8, true>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, H, W, pooled));
+    } else if (C == 8) {
+        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 8, false>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, H, W, pooled));
+    } else if (C == 16 && pooled) {
+        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 16, true>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, H, W, pooled));
     } else if (C == 16) {
-        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 16>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, HW));
+        DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((srd_attention_kernel<PR, 16, false>), dim3(grid), dim3(256), 0, s, feat, out, w3, w1, B, N, H, W, pooled));
     } else {
         return hipErrorInvalidValue;
     }
@@ -626,6 +661,35 @@ hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B,
 //   s_n   = bilinear(score[b,n], y, x)             (align_corners=False, PyTorch's index rule)
 //   p_n   = softplus(s_n) + 1e-6                   (beta 1, threshold 20)
 //   depth = sum_n fd_n p_n / sum_n p_n             (DEN.py:88-90)
+// softplus (beta 1, threshold 20) = v > 20 ? v : log1p(exp(v)) on the hardware transcendentals instead of libm's
+// expf/log1pf (the regression kernels were bound by those two calls):
+//   e = exp(v) = exp2(v*log2e), the product carried in two floats so that the result keeps ~1 ulp for |v| up to 88;
+//   log1p(e)  = series for e < 0.1 (9 terms, truncation < 2e-10), else log(1+e) * e/((1+e)-1) (the classic
+//               correction for the rounding of 1+e) on v_log_f32.
+// Measured against torch.nn.functional.softplus in tests/test_gpu_ops.py::test_regression_head (2e-6 rel-L2).
+__device__ __forceinline__ float softplus_fast(float v) {
+    if (v > 20.f) return v;
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500414e-08f;
+    const float hi = v * L2E;
+    const float lo = __builtin_fmaf(v, L2E, -hi) + v * L2E_LO;
+    float e = __builtin_amdgcn_exp2f(hi);
+    e = __builtin_fmaf(e, lo * 0.693147182464599609375f, e);
+    if (e < 0.1f) {
+        float s = -1.f / 9.f;
+        s = __builtin_fmaf(s, e, 1.f / 8.f);
+        s = __builtin_fmaf(s, e, -1.f / 7.f);
+        s = __builtin_fmaf(s, e, 1.f / 6.f);
+        s = __builtin_fmaf(s, e, -1.f / 5.f);
+        s = __builtin_fmaf(s, e, 1.f / 4.f);
+        s = __builtin_fmaf(s, e, -1.f / 3.f);
+        s = __builtin_fmaf(s, e, 1.f / 2.f);
+        s = __builtin_fmaf(-s, e, 1.f);
+        return e * s;
+    }
+    const float w = 1.f + e;
+    return __builtin_amdgcn_logf(w) * 0.693147182464599609375f * (e / (w - 1.f));
+}
+
 __global__ __launch_bounds__(256) void regress_kernel(const float *__restrict__ score, int B, int N, int h, int w, int H,
                                                       int W, const float *__restrict__ fd, int64_t fsb, int64_t fsn,
                                                       int64_t fsh, int64_t fsw, float *__restrict__ depth) {
@@ -651,7 +715,7 @@ __global__ __launch_bounds__(256) void regress_kernel(const float *__restrict__ 
             const float *pl = sp + (int64_t)n * h * w;
             const float v = hy * (hx * pl[y0 * w + x0] + lx * pl[y0 * w + x1]) +
                             ly * (hx * pl[y1 * w + x0] + lx * pl[y1 * w + x1]);
-            const float p = (v > 20.f ? v : log1pf(expf(v))) + 1e-6f;
+            const float p = softplus_fast(v) + 1e-6f;
             den += p;
             num += fp[n * fsn] * p;
         }
