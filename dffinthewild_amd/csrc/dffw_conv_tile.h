@@ -41,6 +41,7 @@ struct TileCfg {
     // derived LDS image constants (host needs them to precompute tap offsets)
     int fz, fy, fx, fxl;
     int pipe;            // 1: software-pipelined MFMA loop (compute-bound layers), 0: lean loop (bandwidth-bound)
+    int nw;              // waves per workgroup (4, or 8 for the wide tiles)
 };
 
 struct TileArgs {
@@ -57,7 +58,8 @@ struct TileArgs {
 };
 
 // returns nullptr when no instantiation covers (geo, nt, cg)
-const TileCfg *tile_cfg_find(int geo, int nt, int cg);
+// wide: prefer an 8-wave 640-point instantiation when one exists
+const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide = false);
 // configuration with the same geometry, channel group and TILE SHAPE as `base` but `nt` output tiles (for splits)
 const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt);
 int tile_cfg_count();

@@ -18,16 +18,16 @@
 // 8-byte channels-last stores.  Workgroup -> tile mapping is XCD-aware: each of the 8 XCDs walks a
 // contiguous range of tiles so neighbouring tiles' halos hit in that XCD's L2.
 #include <cstdio>
+#include <cstdlib>
 
 #include "dffw_conv_geom.h"
 
 namespace dffw {
 
-constexpr int NWAVES = 4;
-constexpr int NTHREADS = NWAVES * 64;
-
-template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE>
-__global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const TileArgs t) {
+// NWAVES waves per workgroup: 4 for the 320-point tiles, 8 for the "wide" 640-point variants (same work per
+// wave, one more resident wave per SIMD for the same LDS, smaller halo share)
+template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4>
+__global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const TileArgs t) {
     using T = TileT<GEO, TZ, TY, TX, CG>;
     using G = GeoT<GEO>;
     constexpr int PARTS = Fmt<PREC>::PARTS;
@@ -167,8 +167,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         }
     };
 
+    // debug timeline (DFFW_TRACE_LAYER): wave 0 stamps s_memtime at the phase boundaries of its tile
+    // (compiled in only with -DDFFW_TRACE_BUILD: the checks cost a few percent on the large layers)
+    auto stamp = [&](int k) {
+#ifdef DFFW_TRACE_BUILD
+        if (a.trace && tid == 0) a.trace[(int64_t)tile * 8 + k] = __builtin_amdgcn_s_memtime();
+#else
+        (void)k;
+#endif
+    };
+    stamp(0);
     const Coord cur = decode(tile);
     if (!(a.dbg & 1)) issue_fill(cur, 0);
+    stamp(1);
 
     {
         f32x4 acc[NT][MTW];
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
+                    if (prefilled) stamp(2);
                 }
 
                 // ---- contraction over (tap, channel-in-group) ------------------------------------------
@@ -250,7 +262,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                     constexpr int GA = MTW / 2, GB = MTW - GA;
                     short8 wcur[NT][PARTS], wnxt[NT][PARTS];
                     short8 xa[GA][PARTS], xb[GB][PARTS];
-                    int tcur = tfirst, tnxt = 0;
+                    // tap offsets run two chunks ahead: the one for chunk kc+1 is consumed in the MIDDLE of iteration kc
+                    // (group A's next operands), so a load issued at the top of the same iteration would be waited
+                    // for ~100 cycles later together with the weight fragments behind it
+                    int tcur = tfirst, tnxt = (KC > 1) ? tab[4] : 0, tn2 = 0;
         #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
         #pragma unroll
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
                             for (int nt = 0; nt < NT; ++nt)
         #pragma unroll
                                 for (int pt = 0; pt < PARTS; ++pt) wnxt[nt][pt] = wn[(nt * PARTS + pt) * 64];
-                            tnxt = tab[(kc + 1) * 4];
+                            if (kc + 2 < KC) tn2 = tab[(kc + 2) * 4];
                         }
                         // operands of group B for this chunk: in flight during group A's MFMAs
         #pragma unroll
@@ -318,11 +333,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
         #pragma unroll
                             for (int pt = 0; pt < PARTS; ++pt) wcur[nt][pt] = wnxt[nt][pt];
                         tcur = tnxt;
+                        tnxt = tn2;
                     }
                 }
             }
 
             // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) ---------------------------
+            if (pass == G::NPASS - 1) stamp(3);
             const int ooy = t.ooy[pass], oox = t.oox[pass];
             const bool last_pass = pass == G::NPASS - 1;
             // output location of operand tile j = tile base (wave-uniform) + the lane's precomputed offset; the
@@ -383,6 +400,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
             }
         }
     }
+#ifdef DFFW_TRACE_BUILD
+    if (a.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of this wave issued AND acknowledged
+        stamp(4);
+        if (tid == 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            a.trace[(int64_t)tile * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+#endif
 }
 
 // ---- configuration table -----------------------------------------------------------------------
@@ -414,29 +444,47 @@ __global__ __launch_bounds__(NTHREADS) void conv_tile(const ConvArgs a, const Ti
     X(23, G3T, 1, 5, 4, 16, 32, 0)   \
     X(24, G3T, 2, 5, 4, 16, 32, 1)   \
     X(25, G3T, 4, 5, 4, 16, 32, 1)
+// 8-wave "wide" variants: 640-point tiles, same work per wave.  Measured +8..17 % on the bandwidth-bound
+// single-stage layers with <= 16 output channels (one more resident wave per SIMD for the same LDS, 17 % less
+// halo per output), -10 % on the 32-channel / multi-stage ones, so the engine asks for them only for the former.
+#define DFFW_TILE_CONFIGS_W8(X)      \
+    X(26, G3S1, 1, 5, 8, 16, 16, 1)  \
+    X(27, G3T, 1, 5, 8, 16, 16, 0)   \
+    X(28, G2S1, 1, 5, 8, 16, 8, 0)   \
+    X(29, G2S1, 1, 5, 8, 16, 16, 0)  \
+    X(30, G2S1, 2, 5, 8, 16, 16, 0)  \
+    X(31, G2D, 1, 1, 32, 32, 8, 0)
 
 #define X_CFG(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                             \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
-            TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL, PIPE},
-static const TileCfg g_cfgs[] = {DFFW_TILE_CONFIGS(X_CFG)};
+            TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL, PIPE, 4},
+#define X_CFG8(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                            \
+    TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
+            TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL, PIPE, 8},
+static const TileCfg g_cfgs[] = {DFFW_TILE_CONFIGS(X_CFG) DFFW_TILE_CONFIGS_W8(X_CFG8)};
 #undef X_CFG
+#undef X_CFG8
 
 int tile_cfg_count() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
 const TileCfg *tile_cfg_at(int i) { return (i >= 0 && i < tile_cfg_count()) ? &g_cfgs[i] : nullptr; }
-const TileCfg *tile_cfg_find(int geo, int nt, int cg) {
+const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide) {
+    if (wide)
+        for (const TileCfg &c : g_cfgs)
+            if (c.nw == 8 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
     for (const TileCfg &c : g_cfgs)
-        if (c.geo == geo && c.nt == nt && c.cg == cg) return &c;
+        if (c.nw == 4 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
     return nullptr;
 }
 
 const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt) {
     for (const TileCfg &c : g_cfgs)
-        if (c.geo == base->geo && c.cg == base->cg && c.nt == nt && c.tz == base->tz && c.ty == base->ty && c.tx == base->tx) return &c;
+        if (c.geo == base->geo && c.cg == base->cg && c.nt == nt && c.tz == base->tz && c.ty == base->ty && c.tx == base->tx && c.nw == base->nw) return &c;
     return nullptr;
 }
 
 void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe);
+    if (c->nw == 4) snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe);
+    else snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw);
 }
 
 template <int PREC>
@@ -444,10 +492,16 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
     switch (cfg->id) {
 #define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit), dim3(NTHREADS), 0, s, a, t); \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit), dim3(256), 0, s, a, t); \
         break;
         DFFW_TILE_CONFIGS(X_LAUNCH)
 #undef X_LAUNCH
+#define X_LAUNCH8(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                      \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE, 8>), dim3((unsigned)t.grid, (unsigned)t.nsplit), dim3(512), 0, s, a, t); \
+        break;
+        DFFW_TILE_CONFIGS_W8(X_LAUNCH8)
+#undef X_LAUNCH8
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

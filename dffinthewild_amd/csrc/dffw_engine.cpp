@@ -462,7 +462,9 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         // transposed conv: its 4 sub-pixel passes share one LDS image only when the whole contraction depth is
         // staged at once, so 32-channel groups (one fill instead of 4 x 2) where an instantiation exists
         if (geo == G3T && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;
-        const TileCfg *cfg = tile_cfg_find(geo, pc.nt, cg);
+        // wide (8-wave, 640-point) tile wherever an instantiation exists (dffw_conv_tile.hip lists what was measured)
+        const bool wide = !getenv("DFFW_NO_WIDE");
+        const TileCfg *cfg = tile_cfg_find(geo, pc.nt, cg, wide);
         if (cfg && cin_t % cg == 0) {
             const GeoInfo gi = geo_info(geo);
             TilePack &tp = pc.tile;
@@ -801,8 +803,27 @@ struct Run {
                 prof_end();
                 return out;
             }
+            // debug timeline of one layer: DFFW_TRACE_LAYER=<layer name> DFFW_TRACE_OUT=<file>; per tile 8 x u64
+            // (s_memtime at start / fill issued / fill landed / contraction done / stores acknowledged, HW_ID)
+            unsigned long long *trace = nullptr;
+            const char *tl = getenv("DFFW_TRACE_LAYER"), *tout = getenv("DFFW_TRACE_OUT");
+            if (tl && tout && name == tl) {
+                check(hipMalloc((void **)&trace, (size_t)t.total_tiles * 64), "trace alloc");
+                if (ok()) check(hipMemsetAsync(trace, 0, (size_t)t.total_tiles * 64, s), "trace memset");
+                a.trace = trace;
+            }
             check(launch_conv_tile(e->prec, cfg, a, t, s), name.c_str());
             prof_end();
+            if (trace && ok()) {
+                std::vector<unsigned long long> host((size_t)t.total_tiles * 8);
+                check(hipStreamSynchronize(s), "trace sync");
+                check(hipMemcpy(host.data(), trace, host.size() * 8, hipMemcpyDeviceToHost), "trace copy");
+                if (FILE *f = fopen(tout, "wb")) {
+                    fwrite(host.data(), 8, host.size(), f);
+                    fclose(f);
+                }
+                (void)hipFree(trace);
+            }
             return out;
         }
         for (const Variant &v : pc.variants) {

@@ -51,6 +51,7 @@ struct ConvArgs {
     int relu;                   // 0: none   1: relu(acc+res)   2: relu(acc)+res
     int dbg;                    // ablation switches for profiling (0 in production): 1 no fill, 2 no MFMA loop, 4 no stores
     const uint16_t *zero;       // >= 16 zero bytes in device memory (source of out-of-volume LDS-DMA lanes)
+    unsigned long long *trace;  // debug (DFFW_TRACE_LAYER): 8 x u64 per tile = s_memtime at phase boundaries + HW_ID, or null
     int64_t M;                  // B*Ng*Hg*Wg
 };
 

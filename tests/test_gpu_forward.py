@@ -140,20 +140,23 @@ def test_full_size_properties(lib_built):
     assert cpu_ref.rel_l2(outs2[3].cpu(), (outs[3] * 3.0).cpu()) <= 1e-6
 
 
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_STREAM", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL", "DFFW_NO_CG32"])
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_STREAM", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
+                                 "DFFW_NO_CG32", "DFFW_NO_WIDE"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback
     (conv_igemm, DFFW_NO_TILE), the persistent warp-specialised conv_stream (DFFW_STREAM), the un-split
-    few-tile launches and the unfused attention convs.  The switches are read per launch."""
+    few-tile launches, the unfused attention convs / pooling, and the narrow (4-wave, 16-channel-stage) tile variants."""
     path = [p for p in GOLDEN if which in p][0]
     g, meta, FS, fd, sd = case(path)
     model = model_for(sd, (meta["wseed"], meta["profile"]))
     monkeypatch.setenv(env, "1")
+    model.invalidate()                 # DFFW_NO_CG32 / DFFW_NO_WIDE pick the kernel variant when the weights are packed
     with torch.no_grad():
         outs = model(FS.cuda(), fd.cuda())
     torch.cuda.synchronize()
     monkeypatch.delenv(env)
+    model.invalidate()
     for name, o in zip(("mid_out", "pred1", "pred2", "pred3"), outs):
         if name in g.files:
             assert cpu_ref.rel_l2(o.cpu(), g[name]) <= OUT_TOL["bf16x3"], (env, name)
