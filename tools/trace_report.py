@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
-a = a[a[:, 4] > 0]
+a = a[(a[:, 4] > 0) & (a[:, 0] > 0)]
 t = a[:, :5].astype(np.int64)
 t0 = t[:, 0].min()
 span = t[:, 4].max() - t0
