@@ -483,8 +483,8 @@ const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt) {
 }
 
 void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
-    if (c->nw == 4) snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe);
-    else snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw);
+    // exactly as rocprofv3 --kernel-trace prints the instantiation (all nine template arguments)
+    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw);
 }
 
 template <int PREC>
