@@ -67,9 +67,10 @@ def all_gather_depth(local, total=None):
     return torch.cat(parts, 0)
 
 
-def sharded_depth(model, FS_local, fd_local, total=None, gather=True):
+def sharded_depth(model, FS_local, fd_local, *extra_local, total=None, gather=True):
     """Run ``model`` (a dffinthewild_amd Network, or any callable with its signature) on this rank's
-    slice of the batch and return (local 4-tuple, gathered pred3 or None)."""
-    outs = model(FS_local, fd_local)
+    slice of the batch and return (local output tuple, gathered pred3 or None).  ``extra_local`` are further
+    per-sample inputs sliced the same way — the FOVs of the End_to_End variant: ``model(FS, fd, FOVs)``."""
+    outs = model(FS_local, fd_local, *extra_local)
     gathered = all_gather_depth(outs[3], total) if gather else None
     return outs, gathered

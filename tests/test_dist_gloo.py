@@ -27,6 +27,12 @@ def _fake_model(FS, fd):
     return m, m, m, m + fd.reshape(B, -1)[:, :1].reshape(B, 1, 1) * 0
 
 
+def _fake_e2e_model(FS, fd, fovs):
+    # End_to_End signature: 5 outputs, the FOVs take part so that a mis-sliced third input would show
+    m, _, _, p3 = _fake_model(FS, fd)
+    return m, m, m, p3 + fovs.reshape(FS.shape[0], -1)[:, :1].reshape(-1, 1, 1), FS
+
+
 def _worker(rank, world, port, total, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -38,6 +44,10 @@ def _worker(rank, world, port, total, q):
     fd = torch.ones(total, 2, 1, 1)
     outs, gathered = ddist.sharded_depth(_fake_model, full[s:e], fd[s:e], total=total)
     assert outs[3].shape[0] == e - s
+    # End_to_End variant: a third per-sample input, sliced like the others
+    fov = 100.0 * torch.arange(total, dtype=torch.float32).reshape(total, 1, 1, 1, 1).expand(total, 1, 2, 1, 1).contiguous()
+    outs5, g5 = ddist.sharded_depth(_fake_e2e_model, full[s:e], fd[s:e], fov[s:e], total=total)
+    assert len(outs5) == 5 and g5[:, 0, 0].tolist() == [101.0 * i for i in range(total)]
     q.put((rank, gathered[:, 0, 0].tolist()))
     dist.barrier()
     dist.destroy_process_group()
