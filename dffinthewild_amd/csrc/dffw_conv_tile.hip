@@ -178,7 +178,47 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     };
     stamp(0);
     const Coord cur = decode(tile);
-    if (!(a.dbg & 1)) issue_fill(cur, 0);
+    // ---- stem: footprint straight from the fp32 focal stack.  Record q of the virtual (W+2)-wide paired volume is
+    // RGB(pixel q-2) | RGB(pixel q) (see stack_in_kernel); each thread gathers its records' six values from the
+    // three colour planes (consecutive lanes = consecutive columns), splits them and writes hi/lo to the two LDS
+    // planes.  Saves writing and re-reading the 32 B/pixel record volume (12 B/pixel of stack instead). ----
+    auto fill_from_stack = [&](const Coord &c) {
+        const int W = a.Wi - 2;
+        const int64_t plane = (int64_t)a.Ni * a.Hi * W;
+        const float *src = a.fs32 + (int64_t)c.b * 3 * plane + (int64_t)c.gz0 * a.Hi * W;
+        const int iy0 = c.gy0 + G::MINY, ix0 = c.gx0 + G::MINX;
+        constexpr int NIT = (T::FPIX + NWAVES * 64 - 1) / (NWAVES * 64);
+#pragma unroll   // constant trip count: the loads of all iterations can be in flight together
+        for (int it = 0; it < NIT; ++it) {
+            const int p = tid + it * NWAVES * 64;
+            if (p >= T::FPIX) break;
+            const int fy = p / T::FXL, fx = p - fy * T::FXL;
+            const int iy = iy0 + fy, q = ix0 + fx;
+            short8 h = short8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
+            if ((unsigned)iy < (unsigned)a.Hi) {
+                const float *row = src + (int64_t)iy * W;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    uint16_t hi, lo;
+                    Fmt<PREC>::split((unsigned)(q - 2) < (unsigned)W ? row[ch * plane + q - 2] : 0.f, hi, lo);
+                    h[ch] = (short)hi;
+                    l[ch] = (short)lo;
+                    Fmt<PREC>::split((unsigned)q < (unsigned)W ? row[ch * plane + q] : 0.f, hi, lo);
+                    h[4 + ch] = (short)hi;
+                    l[4 + ch] = (short)lo;
+                }
+            }
+            *reinterpret_cast<short8 *>(smem + p * PIXB) = h;
+            if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(smem + PLANEB + p * PIXB) = l;
+        }
+    };
+    bool from_stack = false;
+    if constexpr (GEO == G2D) from_stack = a.fs32 != nullptr;
+    if (from_stack) {
+        if constexpr (GEO == G2D) fill_from_stack(cur);
+    } else if (!(a.dbg & 1)) {
+        issue_fill(cur, 0);
+    }
     stamp(1);
 
     {

@@ -626,6 +626,7 @@ struct ConvOpt {
     Act *out_pre = nullptr;  // receives the pre-residual value (allocated here)
     float *outf = nullptr;   // fp32 planar output (B,outf_ch,N,H,W) instead of an activation volume
     int outf_ch = 1;
+    const float *fs32 = nullptr;  // stem: read the fp32 focal stack directly (in0 then only carries the geometry)
     const char *cls = nullptr;  // name of a 1x1x1 C->1 layer to apply to the final value inside the epilogue
     float *cls_out = nullptr;   // its fp32 score volume
     bool discard = false;       // the activation output itself is not needed (only cls_out / out_pre)
@@ -727,6 +728,14 @@ struct Run {
     }
     double elem_bytes() const { return 2.0 * prec_parts(e->prec); }
 
+    // does the LDS-tiled kernel serve layer `name` for an output grid of gH x gW (same test as in conv())?
+    bool tiled(const std::string &name, int gH, int gW) const {
+        auto it = e->convs.find(name);
+        if (it == e->convs.end()) return false;
+        const TileCfg *c = it->second.tile.cfg;
+        return c && !getenv_flag("DFFW_NO_TILE") && gW * 2 >= c->tx && gH * 2 >= c->ty;
+    }
+
     Act conv(const std::string &name, const Act &in0, const ConvOpt &o = ConvOpt()) {
         Act out;
         if (!ok()) return out;
@@ -782,6 +791,7 @@ struct Run {
         a.out = out.p;
         a.out_pre = o.out_pre ? o.out_pre->p : nullptr;
         a.outf = o.outf;
+        a.fs32 = o.fs32;
         a.outf_ch = o.outf_ch;
         a.outf_plane = (int64_t)No * Ho * Wo;
         a.cls_w = cls_w;
@@ -1101,16 +1111,27 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     if ((int64_t)B * N * H * W < (3 << 20) && !getenv_flag("DFFW_NO_CONCURRENT")) r.enable_concurrency();
 
     // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80
-    Act in = r.act(B, N, H, W + 2, 8);   // paired-pixel records, see stack_in_kernel
-    if (r.ok() && !r.dry) {
-        char kn[48];
-        snprintf(kn, sizeof kn, "dffw::stack_in_kernel<%d>", prec);
-        r.prof_begin(kn, "stack_in", 0.0, (double)B * N * H * W * 3 * 4.0 + (double)B * N * H * (W + 2) * 8 * r.elem_bytes());
-        r.check(launch_stack_in(prec, FS, in.p, B, N, H, W, r.s), "stack_in");
-        r.prof_end();
+    const std::string stem_name = P + ".FM_measure.Focus_extraction.0.0";
+    Act stem;
+    if (r.tiled(stem_name, H, W) && !getenv_flag("DFFW_NO_FUSED_STEM")) {
+        // the tiled stem kernel builds its paired-pixel records from the fp32 stack on the fly: no record volume
+        Act geom;
+        geom.B = B; geom.N = N; geom.H = H; geom.W = W + 2; geom.C = 8;
+        ConvOpt so = rl;
+        so.fs32 = FS;
+        stem = r.conv(stem_name, geom, so);
+    } else {
+        Act in = r.act(B, N, H, W + 2, 8);   // paired-pixel records, see stack_in_kernel
+        if (r.ok() && !r.dry) {
+            char kn[48];
+            snprintf(kn, sizeof kn, "dffw::stack_in_kernel<%d>", prec);
+            r.prof_begin(kn, "stack_in", 0.0, (double)B * N * H * W * 3 * 4.0 + (double)B * N * H * (W + 2) * 8 * r.elem_bytes());
+            r.check(launch_stack_in(prec, FS, in.p, B, N, H, W, r.s), "stack_in");
+            r.prof_end();
+        }
+        stem = r.conv(stem_name, in, rl);
+        r.drop(in);
     }
-    Act stem = r.conv(P + ".FM_measure.Focus_extraction.0.0", in, rl);
-    r.drop(in);
     Act v1p, v2p;   // max-pooled copies written by the attention kernels on the way (EFD's second branch)
     Act v1 = srd(r, P + ".FM_measure.Focus_extraction.2", stem, true, &v1p);
     r.tap("V1", v1);

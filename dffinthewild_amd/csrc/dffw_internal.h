@@ -51,6 +51,8 @@ struct ConvArgs {
     int relu;                   // 0: none   1: relu(acc+res)   2: relu(acc)+res
     int dbg;                    // ablation switches for profiling (0 in production): 1 no fill, 2 no MFMA loop, 4 no stores
     const uint16_t *zero;       // >= 16 zero bytes in device memory (source of out-of-volume LDS-DMA lanes)
+    const float *fs32;          // stem only: the fp32 planar focal stack (B,3,N,H,Wi-2); when set the kernel builds its paired-pixel
+                                // records on the fly instead of reading a materialised volume through in0
     unsigned long long *trace;  // debug (DFFW_TRACE_LAYER): 8 x u64 per tile = s_memtime at phase boundaries + HW_ID, or null
     int64_t M;                  // B*Ng*Hg*Wg
 };
