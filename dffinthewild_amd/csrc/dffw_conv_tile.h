@@ -55,6 +55,9 @@ struct TileArgs {
     int nt_total;             // 16-channel output tiles of the layer (weights are packed for all of them)
     int nsplit;               // grid.y: output-channel split, each workgroup produces nt_total/nsplit tiles
     int grid;                 // workgroups to launch along x = 8 * ceil(total_tiles / 8) (one tile each)
+    int ksplit;               // grid.z: split of the contraction depth (channel-group stages) over workgroups, 1 = none
+    float *partial;           // ksplit > 1: fp32 partial sums [ksplit][output pixel][nt_total*16], finished by splitk_finish
+    int64_t partial_stride;   // elements per split = output pixels * nt_total*16
 };
 
 // returns nullptr when no instantiation covers (geo, nt, cg)

@@ -178,6 +178,11 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     };
     stamp(0);
     const Coord cur = decode(tile);
+    // split-K (few-tile layers with a deep contraction, see Run::conv): blockIdx.z owns a contiguous range of the
+    // channel-group stages and writes raw fp32 partial sums; splitk_finish adds them up and runs the epilogue
+    const bool splitk = t.ksplit > 1;
+    const int st_lo = splitk ? (int)blockIdx.z * t.nstage / t.ksplit : 0;
+    const int st_hi = splitk ? ((int)blockIdx.z + 1) * t.nstage / t.ksplit : t.nstage;
     // ---- stem: footprint straight from the fp32 focal stack.  Record q of the virtual (W+2)-wide paired volume is
     // RGB(pixel q-2) | RGB(pixel q) (see stack_in_kernel); each thread gathers its records' six values from the
     // three colour planes (consecutive lanes = consecutive columns), splits them and writes hi/lo to the two LDS
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     if (from_stack) {
         if constexpr (GEO == G2D) fill_from_stack(cur);
     } else if (!(a.dbg & 1)) {
-        issue_fill(cur, 0);
+        issue_fill(cur, st_lo);
     }
     stamp(1);
 
@@ -228,13 +233,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < MTW; ++j) acc[nt][j] = BIAS_IN_ACC ? bias4[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < MTW; ++j) acc[nt][j] = (BIAS_IN_ACC && !splitk) ? bias4[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
 
             const int KC = t.KC[pass];
             const int *tab = t.tab[pass] + g;
 
-            for (int st = 0; st < t.nstage; ++st) {
-                const bool prefilled = (pass == 0 && st == 0);   // queued by the prologue
+            for (int st = st_lo; st < st_hi; ++st) {
+                const bool prefilled = (pass == 0 && st == st_lo);   // queued by the prologue
                 // first chunk's weight fragments and tap offset: requested BEFORE waiting for the footprint DMA so
                 // that their L2 latency overlaps it
                 const int wstride = NTT * PARTS * 64;   // fragments (16 B per lane) per 32-deep chunk
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
 #pragma unroll
                     for (int pt = 0; pt < PARTS; ++pt) wfirst[nt][pt] = wp[(nt * PARTS + pt) * 64];
                 const int tfirst = tab[0];
-                if ((pass == 0 || t.nstage > 1) && !(a.dbg & 1)) {
+                if ((pass == 0 || st_hi - st_lo > 1) && !(a.dbg & 1)) {
                     if (!prefilled) {
                         __syncthreads();  // everyone is done reading the previous image
                         issue_fill(cur, st);
@@ -395,7 +400,19 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                 if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
                 return ok;
             };
-            if (NT == 1 && a.Cout == 8 && !a.outf) {
+            if (splitk) {
+                // raw partial sums: 4 consecutive channels of the lane's pixel as one 16-byte store
+                float *pz = t.partial + (int64_t)blockIdx.z * t.partial_stride;
+                const int cpad = NTT * 16;
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    int64_t opix;
+                    if (where(j, opix)) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4 *>(pz + opix * cpad + (ntb + nt) * 16 + g * 4) = acc[nt][j];
+                    }
+                }
+            } else if (NT == 1 && a.Cout == 8 && !a.outf) {
                 // 8 output channels occupy only lane rows 0-1 of a result tile: pack operand tiles j and j+1 into
                 // one register set (rows 2-3 <- rows 0-1 of tile j+1, v_permlane32_swap) and run ONE epilogue for both
 #pragma unroll
@@ -532,13 +549,13 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
     switch (cfg->id) {
 #define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit), dim3(256), 0, s, a, t); \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : 1)), dim3(256), 0, s, a, t); \
         break;
         DFFW_TILE_CONFIGS(X_LAUNCH)
 #undef X_LAUNCH
 #define X_LAUNCH8(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                      \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE, 8>), dim3((unsigned)t.grid, (unsigned)t.nsplit), dim3(512), 0, s, a, t); \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE, 8>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : 1)), dim3(512), 0, s, a, t); \
         break;
         DFFW_TILE_CONFIGS_W8(X_LAUNCH8)
 #undef X_LAUNCH8

@@ -774,7 +774,8 @@ struct Run {
             cls_w = ic->second.w32;
         }
         if (o.out_pre) *o.out_pre = act(in0.B, No, Ho, Wo, L.cout);
-        if (!ok() || dry) return out;
+        if (!ok()) return out;
+        // (the dry run that sizes the workspace continues through the launch planning below: split-K adds a scratch block)
 
         ConvArgs a;
         memset(&a, 0, sizeof a);
@@ -797,7 +798,7 @@ struct Run {
         a.cls_w = cls_w;
         a.cls_out = o.cls_out;
         a.relu = o.relu;
-        if (e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
+        if (!dry && e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
         { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? atoi(d) : 0; }
         const TilePack &tp = pc.tile;
@@ -844,6 +845,27 @@ struct Run {
                 }
             }
             t.grid = 8 * ((t.total_tiles + 7) / 8);   // one tile per workgroup, grid a multiple of the 8 XCDs
+            // split-K: when even the channel split leaves most CUs idle and the contraction is several channel-group
+            // stages deep, the stages are dealt to grid.z workgroups (fp32 partials, summed in fixed order by
+            // splitk_finish) so that one workgroup no longer walks all of them in sequence
+            t.ksplit = 1;
+            float *partial = nullptr;
+            const int64_t M_out = (int64_t)out.B * No * Ho * Wo;
+            if (t.total_tiles * t.nsplit <= 96 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && L.cout % 4 == 0 &&
+                !getenv_flag("DFFW_NO_SPLITK")) {
+                const int want = 256 / (t.total_tiles * t.nsplit);
+                t.ksplit = std::max(1, std::min(std::min(tp.nstage, want), 8));
+                if (t.ksplit > 1) {
+                    t.partial_stride = M_out * (int64_t)pc.nt * 16;
+                    partial = (float *)raw(t.ksplit * t.partial_stride * (int64_t)sizeof(float));
+                    t.partial = partial;
+                    if (!ok()) return out;
+                }
+            }
+            if (dry) {
+                drop_raw(partial);
+                return out;
+            }
             // persistent warp-specialised kernel when the layer has enough tiles to keep one workgroup per CU busy
             const TileCfg *scfg = stream_cfg_find(cfg->geo, cfg->nt, cfg->cg);
             const bool use_stream = scfg && scfg->tz == cfg->tz && scfg->ty == cfg->ty && scfg->tx == cfg->tx &&
@@ -876,6 +898,14 @@ struct Run {
             }
             check(launch_conv_tile(e->prec, cfg, a, t, s), name.c_str());
             prof_end();
+            if (t.ksplit > 1) {
+                prof_begin("dffw::splitk_finish_kernel", name + " (split-K finish)", 0.0,
+                           (double)M_out * L.cout * (4.0 * t.ksplit + elem_bytes() * (o.res0 ? 2 : 1)));
+                check(launch_splitk_finish(e->prec, partial, t.ksplit, t.partial_stride, M_out, pc.nt * 16, L.cout, pc.bias, a.res0,
+                                           o.relu, out.p, s), "splitk_finish");
+                prof_end();
+                drop_raw(partial);
+            }
             if (trace && ok()) {
                 std::vector<unsigned long long> host((size_t)t.total_tiles * 8);
                 check(hipStreamSynchronize(s), "trace sync");
@@ -888,6 +918,7 @@ struct Run {
             }
             return out;
         }
+        if (dry) return out;
         for (const Variant &v : pc.variants) {
             a.KC = v.KC;
             a.tab = v.tab;
@@ -1530,7 +1561,8 @@ int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, in
     const int No = N + 2 * pad[0] - (kernel[0] - 1);
     const int64_t opix = (int64_t)B * No * Ho * Wo;
     // run through the same Run::conv path the graph uses, on a private workspace
-    const int64_t ws_bytes = 2 * (opix * parts * std::max(Cout, 4) * 2 + 4096) + opix * 4 + 4096;
+    const int64_t ws_bytes = 2 * (opix * parts * std::max(Cout, 4) * 2 + 4096) + opix * 4 + 4096
+                             + 8 * opix * ((Cout + 15) / 16 * 16) * 4 + 4096;   // + split-K partial sums (up to 8 splits)
     char *ws = nullptr;
     HIPCHK(hipMalloc((void **)&ws, ws_bytes));
     Run r(&eng, s, false, ws, ws_bytes);

@@ -69,6 +69,8 @@ bool srd_attention_supported(int C);
 // pooled: optional (B,N,H/2,W/2,C) volume receiving the (1,2,2) max-pool of the result, or null
 hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, const float *w3, const float *w1, int B, int N,
                                 int H, int W, int C, uint16_t *pooled, hipStream_t s);
+hipError_t launch_splitk_finish(int prec, const float *partial, int ksplit, int64_t stride, int64_t M, int cpad, int Cout,
+                                const float *bias, const uint16_t *res0, int relu, uint16_t *out, hipStream_t s);
 hipError_t launch_from_ncdhw_pad(int prec, const float *x, uint16_t *out, int B, int Cs, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_flow_volume(int prec, const uint16_t *fe, uint16_t *out, const float *alpha, const float *fov, int B, int N,
                               int H, int W, int C, hipStream_t s);

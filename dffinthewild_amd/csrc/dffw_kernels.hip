@@ -272,6 +272,42 @@ hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C
     return hipGetLastError();
 }
 
+// ---- split-K finish ----------------------------------------------------------------------------------------
+// Sum of the ksplit fp32 partial volumes of a split contraction (fixed order: deterministic), then the conv
+// epilogue: BatchNorm shift, residual, ReLU, storage format.  One thread per (output pixel, 4 channels).
+template <int PREC>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float *__restrict__ partial, int ksplit, int64_t stride,
+                                                            int64_t M, int cpad, int Cout, const float *__restrict__ bias,
+                                                            const uint16_t *__restrict__ res0, int relu, uint16_t *__restrict__ out) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int q4 = Cout / 4;
+    const int64_t total = M * q4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % q4) * 4;
+        const int64_t pix = i / q4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(partial + pix * cpad + c0);
+        for (int z = 1; z < ksplit; ++z) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(partial + z * stride + pix * cpad + c0);
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = v[k] + bias[c0 + k];
+            if (relu == 2) x = fmaxf(x, 0.f);
+            if (res0) x += Fmt<PREC>::load(res0 + pix * (PARTS * Cout), Cout, c0 + k);
+            if (relu == 1) x = fmaxf(x, 0.f);
+            Fmt<PREC>::store(out + pix * (PARTS * Cout), Cout, c0 + k, x);
+        }
+    }
+}
+
+hipError_t launch_splitk_finish(int prec, const float *partial, int ksplit, int64_t stride, int64_t M, int cpad, int Cout,
+                                const float *bias, const uint16_t *res0, int relu, uint16_t *out, hipStream_t s) {
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((splitk_finish_kernel<PR>), dim3(grid_for(M * (Cout / 4))), dim3(256), 0, s, partial,
+                                                ksplit, stride, M, cpad, Cout, bias, res0, relu, out));
+    return hipGetLastError();
+}
+
 // ---- pooling -----------------------------------------------------------------------------------
 // One thread per (output pixel, 8-channel group): 16-byte loads per part, fp32 reduce, re-split.
 template <int PREC>
