@@ -55,6 +55,7 @@ struct TileArgs {
     int nt_total;             // 16-channel output tiles of the layer (weights are packed for all of them)
     int nsplit;               // grid.y: output-channel split, each workgroup produces nt_total/nsplit tiles
     int grid;                 // workgroups to launch along x = 8 * ceil(total_tiles / 8) (one tile each)
+    int pass_split;           // transposed conv on few tiles: grid.z = 4, each workgroup runs ONE sub-pixel pass (disjoint outputs)
     int ksplit;               // grid.z: split of the contraction depth (channel-group stages) over workgroups, 1 = none
     float *partial;           // ksplit > 1: fp32 partial sums [ksplit][output pixel][nt_total*16], finished by splitk_finish
     int64_t partial_stride;   // elements per split = output pixels * nt_total*16
@@ -65,6 +66,7 @@ struct TileArgs {
 const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide = false);
 // configuration with the same geometry, channel group and TILE SHAPE as `base` but `nt` output tiles (for splits)
 const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt);
+bool tile_cfg_has_splitk(const TileCfg *c);   // a split-K instantiation of this configuration exists
 int tile_cfg_count();
 const TileCfg *tile_cfg_at(int i);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);

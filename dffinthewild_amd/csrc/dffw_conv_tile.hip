@@ -26,7 +26,10 @@ namespace dffw {
 
 // NWAVES waves per workgroup: 4 for the 320-point tiles, 8 for the "wide" 640-point variants (same work per
 // wave, one more resident wave per SIMD for the same LDS, smaller halo share)
-template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4>
+// SPLITK: the split-K variant (raw fp32 partial sums, stage range from blockIdx.z).  Compile-time because as a
+// runtime branch its partial-store path cost every kernel ~50 VGPRs at the peak (one resident wave per SIMD on the
+// 64-channel kernels); only the configurations that few-tile layers actually use are instantiated with it.
+template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4, bool SPLITK = false>
 __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const TileArgs t) {
     using T = TileT<GEO, TZ, TY, TX, CG>;
     using G = GeoT<GEO>;
@@ -180,9 +183,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     const Coord cur = decode(tile);
     // split-K (few-tile layers with a deep contraction, see Run::conv): blockIdx.z owns a contiguous range of the
     // channel-group stages and writes raw fp32 partial sums; splitk_finish adds them up and runs the epilogue
-    const bool splitk = t.ksplit > 1;
+    const bool splitk = SPLITK && t.ksplit > 1;
     const int st_lo = splitk ? (int)blockIdx.z * t.nstage / t.ksplit : 0;
     const int st_hi = splitk ? ((int)blockIdx.z + 1) * t.nstage / t.ksplit : t.nstage;
+    // pass split (transposed conv, few tiles): the 4 sub-pixel passes write disjoint output phases, so they can be
+    // 4 workgroups instead of a 4x longer chain in one
+    const int pass_lo = (G::NPASS > 1 && t.pass_split) ? (int)blockIdx.z : 0;
+    const int pass_hi = (G::NPASS > 1 && t.pass_split) ? pass_lo + 1 : G::NPASS;
     // ---- stem: footprint straight from the fp32 focal stack.  Record q of the virtual (W+2)-wide paired volume is
     // RGB(pixel q-2) | RGB(pixel q) (see stack_in_kernel); each thread gathers its records' six values from the
     // three colour planes (consecutive lanes = consecutive columns), splits them and writes hi/lo to the two LDS
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     {
         f32x4 acc[NT][MTW];
 #pragma unroll 1   // one accumulator set live at a time
-        for (int pass = 0; pass < G::NPASS; ++pass) {
+        for (int pass = pass_lo; pass < pass_hi; ++pass) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             const int *tab = t.tab[pass] + g;
 
             for (int st = st_lo; st < st_hi; ++st) {
-                const bool prefilled = (pass == 0 && st == st_lo);   // queued by the prologue
+                const bool prefilled = (pass == pass_lo && st == st_lo);   // queued by the prologue
                 // first chunk's weight fragments and tap offset: requested BEFORE waiting for the footprint DMA so
                 // that their L2 latency overlaps it
                 const int wstride = NTT * PARTS * 64;   // fragments (16 B per lane) per 32-deep chunk
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
 #pragma unroll
                     for (int pt = 0; pt < PARTS; ++pt) wfirst[nt][pt] = wp[(nt * PARTS + pt) * 64];
                 const int tfirst = tab[0];
-                if ((pass == 0 || st_hi - st_lo > 1) && !(a.dbg & 1)) {
+                if ((pass == pass_lo || st_hi - st_lo > 1) && !(a.dbg & 1)) {
                     if (!prefilled) {
                         __syncthreads();  // everyone is done reading the previous image
                         issue_fill(cur, st);
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                 if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
                 return ok;
             };
-            if (splitk) {
+            if (SPLITK && splitk) {
                 // raw partial sums: 4 consecutive channels of the lane's pixel as one 16-byte store
                 float *pz = t.partial + (int64_t)blockIdx.z * t.partial_stride;
                 const int cpad = NTT * 16;
@@ -512,6 +519,27 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(30, G2S1, 2, 5, 8, 16, 16, 0)  \
     X(31, G2D, 1, 1, 32, 32, 8, 0)
 
+// the 4-wave configurations few-tile layers end up on after the channel split (3x3x3 at stride 1 and 2, <= 32 output
+// channels per workgroup): these also exist as split-K kernels
+#define DFFW_TILE_CONFIGS_SPLITK(X)  \
+    X(0, G3S1, 1, 5, 4, 16, 16, 1)   \
+    X(1, G3S1, 1, 5, 4, 16, 8, 1)    \
+    X(2, G3S1, 2, 5, 4, 16, 16, 1)   \
+    X(16, G3S1, 2, 4, 4, 8, 16, 1)   \
+    X(5, G3S2, 1, 5, 4, 16, 8, 1)    \
+    X(6, G3S2, 2, 5, 4, 16, 8, 1)    \
+    X(17, G3S2, 2, 4, 4, 8, 8, 1)
+
+bool tile_cfg_has_splitk(const TileCfg *c) {
+    switch (c->id) {
+#define X_HAS(ID, GEO, NT, TZ, TY, TX, CG, PIPE) case ID:
+        DFFW_TILE_CONFIGS_SPLITK(X_HAS)
+#undef X_HAS
+        return c->nw == 4;
+        default: return false;
+    }
+}
+
 #define X_CFG(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                             \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
             TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL, PIPE, 4},
@@ -546,19 +574,25 @@ void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
 
 template <int PREC>
 static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
-    switch (cfg->id) {
+    switch (t.ksplit > 1 ? 1000 + cfg->id : cfg->id) {
 #define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : 1)), dim3(256), 0, s, a, t); \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : (t.pass_split ? 4 : 1))), dim3(256), 0, s, a, t); \
         break;
         DFFW_TILE_CONFIGS(X_LAUNCH)
 #undef X_LAUNCH
 #define X_LAUNCH8(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                      \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE, 8>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : 1)), dim3(512), 0, s, a, t); \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE, 8>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : (t.pass_split ? 4 : 1))), dim3(512), 0, s, a, t); \
         break;
         DFFW_TILE_CONFIGS_W8(X_LAUNCH8)
 #undef X_LAUNCH8
+#define X_LAUNCHK(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                      \
+    case 1000 + ID:                                                                                                 \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE, 4, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)t.ksplit), dim3(256), 0, s, a, t); \
+        break;
+        DFFW_TILE_CONFIGS_SPLITK(X_LAUNCHK)
+#undef X_LAUNCHK
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

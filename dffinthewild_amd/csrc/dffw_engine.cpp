@@ -851,7 +851,11 @@ struct Run {
             t.ksplit = 1;
             float *partial = nullptr;
             const int64_t M_out = (int64_t)out.B * No * Ho * Wo;
-            if (t.total_tiles * t.nsplit <= 96 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && L.cout % 4 == 0 &&
+            // transposed conv on few tiles: its 4 sub-pixel passes as 4 workgroups (no reduction, any epilogue)
+            const char *thr_env = getenv("DFFW_SPLIT_WG");
+            const int thr = thr_env ? atoi(thr_env) : 256;   // measured best of 64/128/256/512 at batch 1, 4, 8
+            t.pass_split = (L.transposed && t.total_tiles * t.nsplit <= thr && !getenv_flag("DFFW_NO_SPLITK")) ? 1 : 0;
+            if (!t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && L.cout % 4 == 0 &&
                 !getenv_flag("DFFW_NO_SPLITK")) {
                 const int want = 256 / (t.total_tiles * t.nsplit);
                 t.ksplit = std::max(1, std::min(std::min(tp.nstage, want), 8));
