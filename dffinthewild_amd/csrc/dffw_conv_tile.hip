@@ -22,6 +22,10 @@
 
 #include "dffw_conv_geom.h"
 
+#ifndef DFFW_TILE_PREC
+#error "compile with -DDFFW_TILE_PREC=0|1|2 (arithmetic of this object, see the Makefile)"
+#endif
+
 namespace dffw {
 
 // NWAVES waves per workgroup: 4 for the 320-point tiles, 8 for the "wide" 640-point variants (same work per
@@ -530,6 +534,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(6, G3S2, 2, 5, 4, 16, 8, 1)    \
     X(17, G3S2, 2, 4, 4, 8, 8, 1)
 
+#if DFFW_TILE_PREC == 0   // configuration table and look-ups live in one of the three per-precision objects
 bool tile_cfg_has_splitk(const TileCfg *c) {
     switch (c->id) {
 #define X_HAS(ID, GEO, NT, TZ, TY, TX, CG, PIPE) case ID:
@@ -572,6 +577,8 @@ void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
     snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw);
 }
 
+#endif
+
 template <int PREC>
 static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
     switch (t.ksplit > 1 ? 1000 + cfg->id : cfg->id) {
@@ -598,13 +605,25 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
     return hipGetLastError();
 }
 
+// This source is compiled three times (-DDFFW_TILE_PREC=0/1/2, see the Makefile): one object per arithmetic, so the
+// ~40 kernel instantiations of each build in parallel.
+#define DFFW_CAT2(a, b) a##b
+#define DFFW_CAT(a, b) DFFW_CAT2(a, b)
+hipError_t DFFW_CAT(launch_conv_tile_prec, DFFW_TILE_PREC)(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
+    return launch_conv_tile_p<DFFW_TILE_PREC>(cfg, a, t, s);
+}
+
+#if DFFW_TILE_PREC == 0
+hipError_t launch_conv_tile_prec1(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
+hipError_t launch_conv_tile_prec2(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
     switch (prec) {
-        case P_BF16X3: return launch_conv_tile_p<P_BF16X3>(cfg, a, t, s);
-        case P_FP16: return launch_conv_tile_p<P_FP16>(cfg, a, t, s);
-        case P_BF16: return launch_conv_tile_p<P_BF16>(cfg, a, t, s);
+        case P_BF16X3: return launch_conv_tile_prec0(cfg, a, t, s);
+        case P_FP16: return launch_conv_tile_prec1(cfg, a, t, s);
+        case P_BF16: return launch_conv_tile_prec2(cfg, a, t, s);
     }
     return hipErrorInvalidValue;
 }
+#endif
 
 }  // namespace dffw

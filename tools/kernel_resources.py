@@ -6,7 +6,7 @@ import sys
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-c", src,
+out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-DDFFW_TILE_PREC=0", "-c", src,
                       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
 cur = None
 rows = []
