@@ -500,13 +500,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(11, G3T, 4, 5, 4, 16, 16, 1)   \
     X(12, G2S1, 1, 5, 4, 16, 8, 0)   \
     X(13, G2S1, 1, 5, 4, 16, 16, 0)  \
-    X(14, G2S1, 2, 5, 8, 16, 16, 0)  \
+    X(14, G2S1, 2, 5, 8, 16, 16, 1)  \
     X(15, G2D, 1, 1, 16, 32, 8, 0)   \
     X(16, G3S1, 2, 4, 4, 8, 16, 1)   \
     X(17, G3S2, 2, 4, 4, 8, 8, 1)    \
-    X(18, G2S1, 2, 5, 4, 16, 8, 0)   \
-    X(19, G2S1, 4, 5, 4, 16, 16, 0)  \
-    X(20, G2S1, 4, 5, 4, 16, 8, 0)   \
+    X(18, G2S1, 2, 5, 4, 16, 8, 1)   \
+    X(19, G2S1, 4, 5, 4, 16, 16, 1)  \
+    X(20, G2S1, 4, 5, 4, 16, 8, 1)   \
     X(21, G2S2, 1, 5, 4, 16, 8, 0)   \
     X(22, G2S2, 2, 5, 4, 16, 8, 0)   \
     X(23, G3T, 1, 5, 4, 16, 32, 0)   \
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(27, G3T, 1, 5, 8, 16, 16, 0)   \
     X(28, G2S1, 1, 5, 8, 16, 8, 0)   \
     X(29, G2S1, 1, 5, 8, 16, 16, 0)  \
-    X(30, G2S1, 2, 5, 8, 16, 16, 0)  \
+    X(30, G2S1, 2, 5, 8, 16, 16, 1)  \
     X(31, G2D, 1, 1, 32, 32, 8, 0)
 
 // the 4-wave configurations few-tile layers end up on after the channel split (3x3x3 at stride 1 and 2, <= 32 output
