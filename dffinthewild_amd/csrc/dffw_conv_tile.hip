@@ -460,8 +460,16 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                     int64_t opix;
                     const bool pv = where(j, opix);
                     float cls = 0.f;
+                    // slice-broadcast residual (alignment heads): same (y,x) record of the sample's single residual slice
+                    // (only the per-slice 1x3x3 geometry is ever launched with it, so only that one carries the arithmetic)
+                    int64_t rbase = ubase;
+                    int rvoff = voff[j];
+                    if constexpr (GEO == G2S1) {
+                        rbase = ubase - ((int64_t)cur.b * (a.No - 1) + cur.gz0) * a.Ho * a.Wo * (PARTS * a.Cout);
+                        rvoff = voff[j] - (tcrd[j] >> 16) * a.Ho * a.Wo * (PARTS * a.Cout);
+                    }
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, acc[nt][j], ntb + nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
+                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, acc[nt][j], ntb + nt, g, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j], rbase, rvoff);
                     epilogue_cls(a, cls, g, opix, pv);
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -144,7 +144,8 @@ __device__ __forceinline__ uint4 epilogue_res_load(const ConvArgs &a, const uint
 // offset `ubase` of the tile, so a store costs no per-lane 64-bit address arithmetic.
 template <int PREC, bool PRE, bool FAST = false, bool ADD_BIAS = !FAST>
 __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &accq, int nt, int g, int64_t opix, bool pvalid,
-                                              float &cls_partial, uint4 pre0, uint4 pre1, int64_t ubase = 0, int voff = 0) {
+                                              float &cls_partial, uint4 pre0, uint4 pre1, int64_t ubase = 0, int voff = 0,
+                                              int64_t rbase = 0, int rvoff = 0) {   // FAST + a.res_bcast: residual's own base/offset
     constexpr int PARTS = Fmt<PREC>::PARTS;
     const int Cout = a.Cout;
     const int c0 = nt * 16 + g * 4;
@@ -177,10 +178,18 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
             if (wvalid) *reinterpret_cast<uint4 *>(base + eo) = make_uint4(h01, h23, l01, l23);
         };
         auto wide_add = [&](const uint16_t *base_, uint4 q) {
-            const uint16_t *base = FAST ? base_ + ubase : base_;
+            const uint16_t *base = FAST ? base_ + (a.res_bcast ? rbase : ubase) : base_;
+            int64_t ro = eo;
+            if (a.res_bcast) {   // one residual slice per sample, shared by all output slices
+                if constexpr (FAST) ro = (int64_t)(rvoff + nt * 16);
+                else {
+                    const int64_t hw = (int64_t)a.Ho * a.Wo;
+                    ro = ((opix / a.outf_plane) * hw + opix % hw) * (2 * Cout) + (g & 1) * Cout + oct * 8;
+                }
+            }
             if constexpr (!PRE) {
                 q = make_uint4(0, 0, 0, 0);
-                if (wvalid) q = *reinterpret_cast<const uint4 *>(base + eo);
+                if (wvalid) q = *reinterpret_cast<const uint4 *>(base + ro);
             }
             swap16(q.x, q.z);
             swap16(q.y, q.w);
@@ -219,11 +228,19 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
             if (ok) *reinterpret_cast<uint2 *>(base + eo) = make_uint2(h01, h23);
         };
         auto add4 = [&](const uint16_t *base_, uint4 q) {
-            const uint16_t *base = FAST ? base_ + ubase : base_;
+            const uint16_t *base = FAST ? base_ + (a.res_bcast ? rbase : ubase) : base_;
+            int64_t ro = eo;
+            if (a.res_bcast) {
+                if constexpr (FAST) ro = (int64_t)(rvoff + nt * 16);
+                else {
+                    const int64_t hw = (int64_t)a.Ho * a.Wo;
+                    ro = ((opix / a.outf_plane) * hw + opix % hw) * Cout + c0;
+                }
+            }
             if constexpr (!PRE) {
                 q = make_uint4(0, 0, 0, 0);
                 if (ok) {
-                    const uint2 h = *reinterpret_cast<const uint2 *>(base + eo);
+                    const uint2 h = *reinterpret_cast<const uint2 *>(base + ro);
                     q.x = h.x;
                     q.y = h.y;
                 }

@@ -52,6 +52,8 @@ struct LayerDef {
     std::string shortcut = "";  // prefix of a bias-free 1x1x1 stride-1 conv over a SECOND input whose result is added to this
                                 // layer's: folded into this layer's weights as centre-tap columns of a channel concat
     bool folded = false;        // this layer is such a shortcut: it is never launched on its own
+    int head_split = 0;         // > 0: first conv of an alignment head over [ref (C) | cur (C) | flow (2)], C = head_split:
+                                // also packed as "<name>#ref" (ref channels, BatchNorm scale only) and "<name>#cur" (the rest)
 };
 
 struct ParamInfo {
@@ -116,6 +118,7 @@ class Table {
     }
     void alpha_head(const std::string &p, int cin, int c) {  // conv1/conv2/conv3 of FlowNetwork, End_to_End.py:37-69
         conv(p + ".0", cin, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
+        layers[by_name[p + ".0.0"]].head_split = (cin - 2) / 2;
         conv(p + ".2", c, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
         conv(p + ".4", c, c, 1, 3, 3, 1, 0, 1, 1, 1, true);
         biased(p + ".6", c, 3, 1, 3, 3, 0, 1, 1);
@@ -622,6 +625,7 @@ static bool getenv_flag(const char *name) {
 struct ConvOpt {
     const Act *in1 = nullptr;
     const Act *res0 = nullptr, *res1 = nullptr;
+    bool res_bcast = false;  // res0 has one slice per sample and is added to every output slice
     int relu = 0;
     Act *out_pre = nullptr;  // receives the pre-residual value (allocated here)
     float *outf = nullptr;   // fp32 planar output (B,outf_ch,N,H,W) instead of an activation volume
@@ -789,6 +793,11 @@ struct Run {
         a.bias = pc.bias;
         a.res0 = o.res0 ? o.res0->p : nullptr;
         a.res1 = o.res1 ? o.res1->p : nullptr;
+        a.res_bcast = o.res_bcast ? 1 : 0;
+        if (o.res_bcast && !(L.kd == 1 && L.kh == 3 && !L.transposed && L.sh == 1 && L.cout >= 16)) {
+            err = fail(DFFW_EINVAL, "slice-broadcast residual is only implemented for the per-slice 1x3x3 convs (layer %s)", name.c_str());
+            return out;
+        }
         a.out = out.p;
         a.out_pre = o.out_pre ? o.out_pre->p : nullptr;
         a.outf = o.outf;
@@ -855,7 +864,7 @@ struct Run {
             const char *thr_env = getenv("DFFW_SPLIT_WG");
             const int thr = thr_env ? atoi(thr_env) : 256;   // measured best of 64/128/256/512 at batch 1, 4, 8
             t.pass_split = (L.transposed && t.total_tiles * t.nsplit <= thr && !getenv_flag("DFFW_NO_SPLITK")) ? 1 : 0;
-            if (!t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && L.cout % 4 == 0 &&
+            if (!t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
                 !getenv_flag("DFFW_NO_SPLITK")) {
                 const int want = 256 / (t.total_tiles * t.nsplit);
                 t.ksplit = std::max(1, std::min(std::min(tp.nstage, want), 8));
@@ -1288,19 +1297,49 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
     Level levels[3] = {{&fe3, ".conv1", "head3"}, {&fe2, ".conv2", "head2"}, {&fe1, ".conv3", "head1"}};
     for (const Level &lv : levels) {                      // coarse to fine, End_to_End.py:77-103
         Act &fe = *lv.fe;
-        const int Cv = 2 * fe.C + 8;                      // 2C+2 channels of End_to_End.py:81-84, padded to a multiple of 8
-        Act vol = r.act(B, N, fe.H, fe.W, Cv);
-        if (r.ok() && !r.dry) {
-            char kn[56];
-            snprintf(kn, sizeof kn, "dffw::flow_volume_kernel<%d>", prec);
-            r.prof_begin(kn, std::string("flow") + lv.head + ".volume", 0.0, (double)fe.pixels() * (2.0 * fe.C + Cv) * r.elem_bytes());
-            r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, r.s), "flow_volume");
-            r.prof_end();
-        }
-        r.drop(fe);
         const std::string hp = P + lv.head;
-        Act y0 = r.conv(hp + ".0.0", vol, rl);
-        r.drop(vol);
+        char kn[56];
+        snprintf(kn, sizeof kn, "dffw::flow_volume_kernel<%d>", prec);
+        Act y0;
+        if (r.e->convs.count(hp + ".0.0#ref") && !getenv_flag("DFFW_NO_HEAD_SPLIT")) {
+            // the head's first conv is linear in its input channels: the part over the warped reference slice is the same
+            // for all N slices of a sample, so it runs once per sample (1/N of the work, no ref channels in the volume) and
+            // enters the per-slice conv over [cur | flow] as a slice-broadcast residual in front of the ReLU
+            Act refw = r.act(B, 1, fe.H, fe.W, fe.C);
+            Act vol = r.act(B, N, fe.H, fe.W, fe.C + 8);
+            if (r.ok() && !r.dry) {
+                r.prof_begin(kn, std::string("flow") + lv.head + ".volume", 0.0,
+                             ((double)fe.pixels() * (2.0 * fe.C + 8) + (double)refw.pixels() * 2.0 * fe.C) * r.elem_bytes());
+                r.check(launch_flow_volume(prec, fe.p, refw.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 2, r.s), "flow_volume ref");
+                r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 1, r.s), "flow_volume cur");
+                r.prof_end();
+            }
+            r.drop(fe);
+            // per-slice conv: the B reference slices are presented as the B slices of ONE sample so that the 5-slice tiles
+            // are filled (same memory either way)
+            Act refw1 = refw;
+            refw1.B = 1; refw1.N = B;
+            Act refpart = r.conv(hp + ".0.0#ref", refw1);
+            refpart.B = B; refpart.N = 1;
+            r.drop(refw);
+            ConvOpt oc = rl;
+            oc.res0 = &refpart;
+            oc.res_bcast = true;
+            y0 = r.conv(hp + ".0.0#cur", vol, oc);
+            r.drop(vol);
+            r.drop(refpart);
+        } else {
+            const int Cv = 2 * fe.C + 8;                  // 2C+2 channels of End_to_End.py:81-84, padded to a multiple of 8
+            Act vol = r.act(B, N, fe.H, fe.W, Cv);
+            if (r.ok() && !r.dry) {
+                r.prof_begin(kn, std::string("flow") + lv.head + ".volume", 0.0, (double)fe.pixels() * (2.0 * fe.C + Cv) * r.elem_bytes());
+                r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 0, r.s), "flow_volume");
+                r.prof_end();
+            }
+            r.drop(fe);
+            y0 = r.conv(hp + ".0.0", vol, rl);
+            r.drop(vol);
+        }
         Act y1 = r.conv(hp + ".2.0", y0, rl);
         r.drop(y0);
         Act y2 = r.conv(hp + ".4.0", y1, rl);
@@ -1417,6 +1456,25 @@ int dffw_engine_create(int device, int net, const dffw_tensor *tensors, int n_te
         PackedConv &pc = e->convs[L.conv];
         rc = pack_conv(L, precision, w, bn.empty() ? nullptr : bn.data(), cb, pc, sw, scin);
         if (rc) return rc;
+        if (L.head_split > 0 && !bn.empty()) {
+            // conv over [ref | cur | flow] = conv_ref(ref) + conv_cur([cur | flow]) (linearity): the ref part is the same for
+            // every slice of a sample, so it is computed once per sample and added as a slice-broadcast residual
+            const int C = L.head_split, kv = L.kd * L.kh * L.kw;
+            auto slice = [&](int c0, int c1) {
+                std::vector<float> ws((size_t)L.cout * (c1 - c0) * kv);
+                for (int co = 0; co < L.cout; ++co)
+                    memcpy(ws.data() + (size_t)co * (c1 - c0) * kv, w + ((size_t)co * L.cin + c0) * kv, (size_t)(c1 - c0) * kv * sizeof(float));
+                return ws;
+            };
+            LayerDef Lr = L, Lc = L;
+            Lr.conv = L.conv + "#ref"; Lr.cin = C; Lr.head_split = 0;
+            Lc.conv = L.conv + "#cur"; Lc.cin = L.cin - C; Lc.head_split = 0;
+            std::vector<float> bn_scale_only = bn;                       // gamma | beta | mean | var with beta = mean = 0: no shift
+            for (int c = 0; c < L.cout; ++c) bn_scale_only[L.cout + c] = bn_scale_only[2 * L.cout + c] = 0.f;
+            const std::vector<float> wr = slice(0, C), wc = slice(C, L.cin);
+            if ((rc = pack_conv(Lr, precision, wr.data(), bn_scale_only.data(), nullptr, e->convs[Lr.conv]))) return rc;
+            if ((rc = pack_conv(Lc, precision, wc.data(), bn.data(), nullptr, e->convs[Lc.conv]))) return rc;
+        }
     }
     *out = e.release();
     return DFFW_OK;

@@ -41,6 +41,7 @@ struct ConvArgs {
     const uint16_t *wpk;        // weights in MFMA fragment order [KC][NT][part][64 lanes][8]
     const float *bias;          // [NT*16] folded BatchNorm shift (zero padded)
     const uint16_t *res0, *res1;// residual volumes in the output's geometry, or null
+    int res_bcast;              // res0 holds ONE slice per sample (B,1,Ho,Wo,Cout) and is added to every output slice
     uint16_t *out;              // output volume, or null
     uint16_t *out_pre;          // optional second output: value before the residual add
     float *outf;                // fp32 planar output (B,outf_ch,No,Ho,Wo) instead of an activation volume, or null
@@ -72,8 +73,10 @@ hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, c
 hipError_t launch_splitk_finish(int prec, const float *partial, int ksplit, int64_t stride, int64_t M, int cpad, int Cout,
                                 const float *bias, const uint16_t *res0, int relu, uint16_t *out, hipStream_t s);
 hipError_t launch_from_ncdhw_pad(int prec, const float *x, uint16_t *out, int B, int Cs, int C, int N, int H, int W, hipStream_t s);
+// mode 0: [warp(fe)[last slice] | warp(fe)[slice n] | flow | pad] (2C+8 channels, N slices); mode 1: [warp(fe)[slice n] | flow | pad]
+// (C+8 channels, N slices); mode 2: warp(fe)[last slice] alone (C channels, ONE slice per sample)
 hipError_t launch_flow_volume(int prec, const uint16_t *fe, uint16_t *out, const float *alpha, const float *fov, int B, int N,
-                              int H, int W, int C, hipStream_t s);
+                              int H, int W, int C, int mode, hipStream_t s);
 hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B, int N, int64_t hw, hipStream_t s);
 hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,
                            int H, int W, int alpha_from_sample0, hipStream_t s);

@@ -588,10 +588,13 @@ hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov,
 template <int PREC>
 __global__ __launch_bounds__(256) void flow_volume_kernel(const uint16_t *__restrict__ fe, uint16_t *__restrict__ out,
                                                           const float *__restrict__ alpha, const float *__restrict__ fov, int B,
-                                                          int N, int H, int W, int C) {
+                                                          int N, int H, int W, int C, int mode) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
-    const int CG = C / 8, G = 2 * CG + 1, Cout = G * 8;
-    const int64_t total = (int64_t)B * N * H * W * G;
+    // channel groups of 8 per output pixel: mode 0 [ref | cur | flow], mode 1 [cur | flow], mode 2 [ref] (one slice per sample)
+    const int CG = C / 8;
+    const int G = mode == 0 ? 2 * CG + 1 : (mode == 1 ? CG + 1 : CG), Cout = G * 8;
+    const int No = mode == 2 ? 1 : N;
+    const int64_t total = (int64_t)B * No * H * W * G;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(i % G);
         const int64_t pix = i / G;
@@ -599,17 +602,19 @@ __global__ __launch_bounds__(256) void flow_volume_kernel(const uint16_t *__rest
         int64_t t = pix / W;
         const int yy = (int)(t % H);
         t /= H;
-        const int n = (int)(t % N);
-        const int b = (int)(t / N);
-        const int src = g < CG ? N - 1 : n;   // reference slice for the first C channels, this slice otherwise
+        const int n = mode == 2 ? N - 1 : (int)(t % No);
+        const int b = (int)(t / No);
+        const bool is_flow = mode != 2 && g == G - 1;
+        const bool is_ref = mode == 2 || (mode == 0 && g < CG);
+        const int src = is_ref ? N - 1 : n;   // reference slice for the first C channels, this slice otherwise
         const float f = alpha[(b * 3 + 0) * N + src] + fov[b * N + src];
         const WarpPoint wp = warp_point(xx, yy, H, W, f, alpha[(b * 3 + 1) * N + src], alpha[(b * 3 + 2) * N + src]);
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (g == G - 1) {
+        if (is_flow) {
             v[0] = wp.fx;
             v[1] = wp.fy;
         } else {
-            const int cg = g < CG ? g : g - CG;
+            const int cg = (mode == 0 && g >= CG) ? g - CG : g;
             const float x0f = floorf(wp.sx), y0f = floorf(wp.sy);
             const int x0 = (int)x0f, y0 = (int)y0f;
             const float wx1 = wp.sx - x0f, wy1 = wp.sy - y0f;
@@ -648,9 +653,10 @@ __global__ __launch_bounds__(256) void flow_volume_kernel(const uint16_t *__rest
 }
 
 hipError_t launch_flow_volume(int prec, const uint16_t *fe, uint16_t *out, const float *alpha, const float *fov, int B, int N,
-                              int H, int W, int C, hipStream_t s) {
-    const int64_t total = (int64_t)B * N * H * W * (2 * (C / 8) + 1);
-    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((flow_volume_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, fe, out, alpha, fov, B, N, H, W, C));
+                              int H, int W, int C, int mode, hipStream_t s) {
+    const int G = mode == 0 ? 2 * (C / 8) + 1 : (mode == 1 ? C / 8 + 1 : C / 8);
+    const int64_t total = (int64_t)B * (mode == 2 ? 1 : N) * H * W * G;
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((flow_volume_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, fe, out, alpha, fov, B, N, H, W, C, mode));
     return hipGetLastError();
 }
 

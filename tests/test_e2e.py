@@ -136,12 +136,14 @@ def test_hip_e2e_batch_is_per_sample(lib_built):
 
 
 @pytest.mark.gpu
-def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch):
-    """The gather kernel (no LDS tiles) must give the same result as the tiled kernels on the alignment network."""
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK"])
+def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
+    """The gather kernel (no LDS tiles), the unsplit alignment heads (reference slice carried in every slice's volume
+    instead of entering as a slice-broadcast residual) and the unsplit few-tile launches must give the same result."""
     g, sd, FS, fd, fov = load(GOLDEN[0])
     with torch.no_grad():
         base = _model(sd)(FS.cuda(), fd.cuda(), fov.cuda())
-        monkeypatch.setenv("DFFW_NO_TILE", "1")
+        monkeypatch.setenv(env, "1")
         alt = _model(sd)(FS.cuda(), fd.cuda(), fov.cuda())
     for name, a, b in zip(OUT_NAMES, alt, base):
         assert cpu_ref.rel_l2(a.cpu(), b.cpu()) <= 2e-4, name
