@@ -70,7 +70,7 @@ bool tile_cfg_has_splitk(const TileCfg *c);   // a split-K instantiation of this
 int tile_cfg_count();
 const TileCfg *tile_cfg_at(int i);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
-void conv_tile_kernel_name(int prec, const TileCfg *cfg, char *buf, int n);
+void conv_tile_kernel_name(int prec, const TileCfg *cfg, bool splitk, char *buf, int n);
 
 // persistent warp-specialised variant (dffw_conv_stream.hip); a config matches conv_tile's packing when it
 // has the same (geo, nt, cg) AND the same tile dims (tap offsets depend on the footprint shape)

@@ -580,9 +580,9 @@ const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt) {
     return nullptr;
 }
 
-void conv_tile_kernel_name(int prec, const TileCfg *c, char *buf, int n) {
-    // exactly as rocprofv3 --kernel-trace prints the instantiation (all nine template arguments)
-    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw);
+void conv_tile_kernel_name(int prec, const TileCfg *c, bool splitk, char *buf, int n) {
+    // exactly as rocprofv3 --kernel-trace prints the instantiation (all ten template arguments)
+    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw, splitk ? "true" : "false");
 }
 
 #endif

@@ -887,7 +887,7 @@ struct Run {
             if (e->profiling) {
                 char kn[96];
                 if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
-                else conv_tile_kernel_name(e->prec, cfg, kn, sizeof kn);
+                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1, kn, sizeof kn);
                 const double opx = (double)out.B * No * Ho * Wo;
                 const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
                                      + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
