@@ -1,0 +1,21 @@
+// conv_roll (rolling-window 3x3x3 conv along the slice axis, dffw_conv_roll.hip): host/device declarations.
+#pragma once
+#include "dffw_internal.h"
+
+namespace dffw {
+
+struct RollArgs {
+    const uint16_t *wroll;   // filter in fragment order [dz*5 + k5][part][64 lanes][8] (pack_conv)
+    int tiles_y, tiles_x;    // columns per sample
+    int zsplit;              // a sample's slices are walked by zsplit workgroups (contiguous ranges)
+    int total_tiles;         // B * zsplit * tiles_y * tiles_x
+    int wgs;                 // workgroups to launch (0: two per CU)
+};
+
+constexpr int ROLL_CHUNKS = 15;   // 3 slices x 5 chunks of (2 in-slice taps x 16 channels)
+
+void roll_tile(int *ty, int *tx);   // column footprint of the instantiated kernel
+hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_roll_kernel_name(int prec, bool res, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
+
+}  // namespace dffw

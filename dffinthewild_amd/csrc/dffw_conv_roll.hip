@@ -1,0 +1,352 @@
+// conv_roll: 3x3x3 stride-1 convolution as a 2.5-D rolling window along the focus-slice axis, for gfx950 (MI355X).
+//
+// conv_tile stages a TZ x TY x TX block with its full halo, waits for it, contracts, stores, exits: every workgroup
+// walks fill -> barrier -> MFMA -> stores in sequence and only other resident workgroups cover the gaps.  For the
+// 16-channel layers of the full-resolution hourglass (DEN.py:240-284, `dres4.conv0/conv2`: the heaviest launches of
+// the forward) conv_roll turns the slice axis into a software pipeline instead:
+//   * a workgroup owns a TY x TX column of ONE sample and walks its output slices front to back;
+//   * LDS holds a ring of 4 input slices (footprint (TY+2) x (TX+2), hi and lo planes of the split-bf16 records);
+//     while slice z is contracted out of ring slots z-1, z, z+1 the LDS-DMA of slice z+2 is in flight into the 4th
+//     slot, so a slice is fetched once per column (halo 1.4x in-plane, none along z) and its latency is covered by
+//     the workgroup's own MFMAs;
+//   * the whole filter (27 taps x 16 channels x <= 16 output channels, hi + lo) lives in registers as 15 MFMA
+//     A-fragments per part: the inner loop issues only ds_read_b128 + v_mfma, no weight stream from L1/L2, no tap
+//     table (the contraction is fully unrolled, tap offsets are immediates, only the ring rotation is a register);
+//   * one barrier per slice.
+// K order: [dz][5 chunks of 32] with chunk k5 = in-slice taps 2*k5, 2*k5+1 (tap 9 = zero weights) x 16 channels, so
+// the slice of a chunk (= its ring slot) is wave-uniform.  Epilogue = conv_tile's (dffw_device.h).
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
+
+#include "dffw_conv_roll.h"
+#include "dffw_device.h"
+
+namespace dffw {
+
+// RES: the layer adds a residual volume (its pieces are prefetched by hand, see below); costs 8 VGPRs, paid for with a
+// shallower operand pipeline so that both variants stay at two waves per SIMD
+template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES>
+__global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const RollArgs t) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int CIN = 16, PIXB = CIN * 2;
+    constexpr int FY = TY + 2, FX = TX + 2, FPIX = FY * FX;
+    constexpr int NPIECE = (FPIX * 2 + 63) / 64;          // 1 KiB wave instructions per plane
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    static_assert(RING >= 4 && RING <= 8, "3 slices being read + at least one being filled");
+    constexpr int MTW = TY * TX / 16 / NWAVES;            // 16-pixel operand tiles (= image rows of the column) per wave
+    static_assert(TX == 16, "one operand tile = one 16-pixel row");
+    static_assert(TY % NWAVES == 0, "rows split evenly over the waves");
+    constexpr int NP = PARTS * NPIECE;                    // DMA pieces per slice
+    constexpr int PPW = (NP + NWAVES - 1) / NWAVES;       // pieces per wave per slice
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (the counted vmcnt waits rely on it)");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+
+    // ---- this workgroup's columns.  A "unit" is one column of one sample (or of one of its zsplit slice ranges);
+    // units are numbered x fastest, then y, slice range, sample.  XCD x (= blockIdx % 8) owns a contiguous range of them
+    // and its workgroups take them round-robin, so the workgroups running at the same time on an XCD walk
+    // neighbouring columns and share their halos in that XCD's L2.
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, zbeg, nz, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % t.tiles_x;
+        int tt = u / t.tiles_x;
+        const int tyi = tt % t.tiles_y;
+        tt /= t.tiles_y;
+        const int zp = tt % t.zsplit;
+        c.b = tt / t.zsplit;
+        c.gy0 = tyi * TY;
+        c.gx0 = txi * TX;
+        c.zbeg = zp * a.No / t.zsplit;
+        c.nz = (zp + 1) * a.No / t.zsplit - c.zbeg;
+        return c;
+    };
+
+    // ---- the slice stream.  The units of this workgroup form ONE stream of input slices: unit u contributes its
+    // nz+2 slices (one above, one below the outputs; zero pages outside the volume), then the next unit follows.  The
+    // fill cursor runs RING-1 slices ahead of the window that is being contracted and simply keeps going across unit
+    // boundaries, so only the first unit of a workgroup ever waits for a cold ring.
+    // Per-lane fill state of the unit being fetched: piece p = wave*PPW + k of a slice covers 64 16-byte chunks (pixel,
+    // channel octet) of one plane; its source address inside input slice 0 of the sample is decoded once per unit.
+    const int ps0 = PARTS * a.C0;
+    const int slice_elems = a.Hi * a.Wi * ps0;            // == Hi*Wi*ps1 when a second input exists (C0 == C1, checked by the host)
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0, fslices = 0, fz0 = 0;        // fill cursor: unit, slice inside it, its slice count, first slice
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+        fslices = c.nz + 2;
+        fz0 = c.zbeg - 1;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int ci = i * 64 + lane, pix = ci >> 1, oct = ci & 1;
+            const int fy = pix / FX, fx = pix - fy * FX;
+            const int iy = c.gy0 - 1 + fy, ix = c.gx0 - 1 + fx;
+            const int ch = oct * 8;
+            const bool second = ch >= a.C0;
+            const int cc = second ? ch - a.C0 : ch;
+            const int csrc = second ? a.C1 : a.C0;
+            fok[k] = p < NP && pix < FPIX && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const uint16_t *sp = (second ? a.in1 : a.in0) + (int64_t)c.b * a.Ni * slice_elems;
+            fsrc[k] = sp + (int64_t)(iy * a.Wi + ix) * (PARTS * csrc) + part * csrc + cc;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {   // queue the next slice of the stream into the next ring slot (zero page once the stream is over)
+        const int iz = fz0 + fq;
+        const bool zin = (unsigned)iz < (unsigned)a.Ni && fu < uend;
+        unsigned char *slot = smem + fslot * SLOTB;
+        const int64_t zo = (int64_t)iz * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RING) ? 0 : fslot + 1;
+        if (++fq == fslices && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // ---- per-lane operand addressing: row j of this wave, column r; K-octet g picks (tap parity, channel octet) ----
+    int inoff[5];
+#pragma unroll
+    for (int k5 = 0; k5 < 5; ++k5) {
+        const int tap9 = 2 * k5 + (g >> 1);
+        const int dy = tap9 < 9 ? tap9 / 3 : 0, dx = tap9 < 9 ? tap9 % 3 : 0;
+        inoff[k5] = (dy * FX + dx) * PIXB + (g & 1) * 16;
+    }
+    int pofs[MTW], voff[MTW];
+    const int lanepart = (PARTS == 2) ? (g & 1) * a.Cout + (g >> 1) * 8 : g * 4;
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int ty = wave * MTW + j;
+        pofs[j] = (ty * FX + r) * PIXB;
+        voff[j] = (ty * a.Wo + r) * (PARTS * a.Cout) + lanepart;
+    }
+    const bool packed = (a.Cout == 8 && !a.outf && MTW % 2 == 0);   // two 8-channel result tiles share one epilogue
+
+    // Ring protocol.  Window n of the stream reads slices n, n+1, n+2 (ring slots n, n+1, n+2 mod RING).  The prologue
+    // queues slices 0 .. RING-2; iteration n queues slice n+RING-1 into the slot of slice n-1 (every wave left it
+    // before the barrier of iteration n-1) -- ALWAYS, also past the end of the stream (zero page into a slot nobody
+    // reads again), so the number of DMA pieces issued after any given slice is the same in every iteration.  vmcnt
+    // retires in issue order, so "at most (RING-4)*PPW operations outstanding" means slice n+3 and everything older
+    // (stores and residual loads of earlier iterations included) has landed while the RING-4 youngest slices stay in
+    // flight across the barrier.  The barrier is the raw s_barrier: __syncthreads() would drain the DMA queue.
+    // With a residual (RES) the step's residual pieces are requested right before its slice, so only that one youngest
+    // slice may stay in flight at the wait (the pieces must have arrived: they are consumed right after it).
+    constexpr int INFLIGHT = RES ? (RING > 4 ? PPW : 0) : (RING - 4) * PPW;
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) issue_next();
+
+    // ---- the filter: 15 A-fragments per part, resident for the whole walk --------------------------------------
+    short8 w[15][PARTS];
+    {
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + lane;
+#pragma unroll
+        for (int c = 0; c < 15; ++c)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) w[c][pt] = wp[(c * PARTS + pt) * 64];
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+    // everything queued so far (prologue slices, filter, bias) is waited for with a compiler-visible vmcnt(0): beside
+    // LDS-DMA hipcc cannot count ordinary loads and would otherwise drain the queue at the first MFMA of every step
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    int sidx = 0;   // ring slot of the window's first slice
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        const int64_t obase0 = (((int64_t)U.b * a.No + U.zbeg) * a.Ho + U.gy0) * a.Wo + U.gx0;
+        for (int st = 0; st < U.nz + 2; ++st) {
+            const bool live = st < U.nz;   // windows starting on the unit's last two slices straddle two units: no output
+            const int64_t obase = obase0 + (int64_t)st * a.Ho * a.Wo;
+            const int64_t ubase = obase * (PARTS * a.Cout);
+            // residual pieces of this step's outputs: requested BEFORE this iteration's slice so that the counted wait
+            // below covers them (an ordinary load would make hipcc drain the whole DMA queue at its first use)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 rq[RES ? MTW : 1];
+            if constexpr (RES && PARTS == 2) {
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) rq[j] = u32x4{0, 0, 0, 0};
+            }
+            if (RES && live && PARTS == 2) {
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    if (packed && (j & 1)) continue;
+                    const int vo = (packed && lane >= 32) ? voff[j + (packed ? 1 : 0)] - 8 : voff[j];
+                    const uint16_t *rp = a.res0 + ubase + vo;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[j]) : "v"(rp) : "memory");
+                }
+            }
+            if (!(a.dbg & 1)) issue_next();
+
+            f32x4 acc[MTW];
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) acc[j] = bias4;
+            if (live && !(a.dbg & 2)) {
+                // slot byte offsets of the three slices this window reads
+                int sb[3];
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    int sl = sidx + dz;
+                    if (sl >= RING) sl -= RING;
+                    sb[dz] = sl * SLOTB;
+                }
+                // Software pipeline over the 15 chunks, operand fragments two chunks ahead of the MFMAs.  The LDS reads and
+                // their waits are inline asm: while an LDS-DMA is outstanding hipcc degrades every lgkmcnt wait to
+                // lgkmcnt(0) (it models global_load_lds as a FLAT access that may also return through LGKM), which would
+                // serialise read -> wait -> MFMA.  DS operations retire in order, so "at most (chunks still ahead) * RPC
+                // reads outstanding" is exactly "chunk c has arrived"; the wait is tied to the fragment registers so the
+                // MFMAs stay behind it.
+                constexpr int RPC = MTW * PARTS;   // ds_read_b128 per chunk
+                constexpr int DEPTH = 1;
+                short8 x[DEPTH + 1][MTW][PARTS];
+                auto fetch = [&](int c, short8 (&dst)[MTW][PARTS]) {
+                    const unsigned ko = lds0 + sb[c / 5] + inoff[c % 5];
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        const unsigned ad = ko + pofs[j];
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[j][0]) : "v"(ad));
+                        if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(PLANEB));
+                    }
+                };
+#pragma unroll
+                for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);
+#pragma unroll
+                for (int c = 0; c < 15; ++c) {
+                    if (c + DEPTH < 15) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
+                    auto &xc = x[c % (DEPTH + 1)];
+                    const int ahead = (14 - c < DEPTH ? 14 - c : DEPTH) * RPC;   // compile-time after unrolling
+                    if (ahead == 2 * RPC && DEPTH == 2) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(2 * RPC));
+                    else if (ahead == RPC) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(RPC));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0][0]));
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt)
+                            if (j + pt) asm volatile("" : "+v"(xc[j][pt]));
+                    if constexpr (PARTS == 2) {
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][1], xc[j][0], acc[j]);
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][0], xc[j][1], acc[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][0], xc[j][0], acc[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+
+            // slice n+3 has landed for this wave's pieces (and this step's residual pieces, which are older); after the
+            // barrier for everyone's, and everyone is done reading slice n (its slot is the next DMA target).  The stores
+            // below get a whole iteration to drain.
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            if constexpr (RES && PARTS == 2) {
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) asm volatile("" : "+v"(rq[j]));
+            }
+            sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
+            if (!live) continue;
+            if ((a.dbg & 4) && acc[0][0] != 12345.f) continue;
+
+            // ---- epilogue of output slice zbeg + st (shared with conv_tile / conv_igemm) ----------------------------
+            if (packed) {
+                // 8 output channels occupy lane rows 0-1 only: rows 2-3 take rows 0-1 of the next operand tile
+#pragma unroll
+                for (int j = 0; j + 1 < MTW; j += 2) {
+                    f32x4 q;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i]), __float_as_uint(acc[j + 1][i]), false, false);
+                        q[i] = __uint_as_float(sw[0]);
+                    }
+                    const bool up = lane >= 32;
+                    const int ty = wave * MTW + j + (up ? 1 : 0);
+                    const int64_t opix = obase + (int64_t)ty * a.Wo + r;
+                    const int vo = up ? voff[j + 1] - 8 : voff[j];
+                    float cls = 0.f;
+                    if constexpr (RES && PARTS == 2) epilogue_quad<PREC, true, true, false>(a, q, 0, g & 1, opix, true, cls, make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]), uint4{}, ubase, vo);
+                    else epilogue_quad<PREC, false, true, false>(a, q, 0, g & 1, opix, true, cls, uint4{}, uint4{}, ubase, vo);
+                    epilogue_cls(a, cls, g, opix, true, 2);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    const int64_t opix = obase + (int64_t)(wave * MTW + j) * a.Wo + r;
+                    float cls = 0.f;
+                    if constexpr (RES && PARTS == 2) epilogue_quad<PREC, true, true, false>(a, acc[j], 0, g, opix, true, cls, make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]), uint4{}, ubase, voff[j]);
+                    else epilogue_quad<PREC, false, true, false>(a, acc[j], 0, g, opix, true, cls, uint4{}, uint4{}, ubase, voff[j]);
+                    epilogue_cls(a, cls, g, opix, true);
+                }
+            }
+        }
+    }
+    // the slices queued past the end of the stream are still in flight: a wave must not retire before its LDS-DMA has
+    // landed, or the pieces arrive in the LDS of whichever workgroup is given these bytes next
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+#define DFFW_ROLL_TY 8
+#define DFFW_ROLL_TX 16
+#define DFFW_ROLL_NW 4
+#define DFFW_ROLL_RING 6
+
+void roll_tile(int *ty, int *tx) {
+    *ty = DFFW_ROLL_TY;
+    *tx = DFFW_ROLL_TX;
+}
+
+void conv_roll_kernel_name(int prec, bool res, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll<%d, %d, %d, %d, %d, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, res ? "true" : "false");
+}
+
+hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    // persistent: two resident workgroups per CU (registers allow 2 waves per SIMD) walk the columns
+    const int want = t.wgs > 0 ? t.wgs : 512;
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(DFFW_ROLL_NW * 64);
+    // the hand-prefetched residual exists for the split-bf16 storage only; fp16/bf16 layers with a residual load it in the epilogue
+    const bool res = a.res0 != nullptr && prec == P_BF16X3;
+#define DFFW_ROLL_LAUNCH(P, R) hipLaunchKernelGGL((conv_roll<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R>), grid, block, 0, s, a, t)
+    switch (prec) {
+        case P_BF16X3:
+            if (res) DFFW_ROLL_LAUNCH(P_BF16X3, true);
+            else DFFW_ROLL_LAUNCH(P_BF16X3, false);
+            break;
+        case P_FP16: DFFW_ROLL_LAUNCH(P_FP16, false); break;
+        case P_BF16: DFFW_ROLL_LAUNCH(P_BF16, false); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_ROLL_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace dffw

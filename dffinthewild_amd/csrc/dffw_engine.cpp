@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/dffw.h"
+#include "dffw_conv_roll.h"
 #include "dffw_conv_tile.h"
 #include "dffw_internal.h"
 
@@ -23,6 +24,7 @@ namespace dffw {
 
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static thread_local std::string g_last_kernel;   // dffw_last_conv_kernel()
 static int fail(int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -287,6 +289,7 @@ struct PackedConv {
     std::vector<Variant> variants;
     TilePack tile;
     float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
+    uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
 
@@ -307,6 +310,8 @@ static void free_packed(PackedConv &pc) {
     pc.tile.cfg = nullptr;
     if (pc.w32) (void)hipFree(pc.w32);
     pc.w32 = nullptr;
+    if (pc.wroll) (void)hipFree(pc.wroll);
+    pc.wroll = nullptr;
 }
 
 // weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
@@ -513,6 +518,31 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 HIPCHK(hipMemcpy(tp.wpk[ps], wpk.data(), wpk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             }
         }
+    }
+    // ---- third packing: conv_roll (rolling window along the slices) for the 16-channel 3x3x3 stride-1 layers ------
+    // K order [dz][k5][32]: chunk k5 of a slice = in-slice taps 2*k5 and 2*k5+1 (tap 9 does not exist: zero weights),
+    // lane group g -> tap 2*k5 + (g >> 1), channel octet g & 1
+    if (geo == G3S1 && cin_pad == 16 && pc.nt == 1 && !stem) {
+        std::vector<uint16_t> wr((size_t)ROLL_CHUNKS * parts * 512, 0);
+        for (int dz = 0; dz < 3; ++dz)
+            for (int k5 = 0; k5 < 5; ++k5)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int cout = lane & 15, gq = lane >> 4;
+                        const int tap9 = 2 * k5 + (gq >> 1), cin = (gq & 1) * 8 + j;
+                        float val = 0.f;
+                        if (cout < L.cout && tap9 < 9) {
+                            const int ky = tap9 / 3, kx = tap9 % 3;
+                            val = (float)wval(cout, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
+                        }
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = ((size_t)(dz * 5 + k5) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        if (parts == 2) wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     return DFFW_OK;
 }
@@ -812,6 +842,45 @@ struct Run {
         { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? atoi(d) : 0; }
         const TilePack &tp = pc.tile;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
+        // rolling-window kernel: 16-channel 3x3x3 stride-1 layers whose grid is whole columns and fills the chip
+        {
+            int rty, rtx;
+            roll_tile(&rty, &rtx);
+            const int cols = (Ho / rty) * (Wo / rtx);
+            if (pc.wroll && Ho % rty == 0 && Wo % rtx == 0 && in0.C % 8 == 0 && (!o.in1 || o.in1->C == in0.C) && !o.res_bcast && !o.res1 &&
+                (int64_t)in0.B * cols >= 256 && !getenv_flag("DFFW_NO_ROLL")) {
+                if (dry) return out;
+                a.Ng = No; a.Hg = Ho; a.Wg = Wo;
+                a.M = (int64_t)a.B * No * Ho * Wo;
+                RollArgs t;
+                t.wroll = pc.wroll;
+                t.tiles_y = Ho / rty;
+                t.tiles_x = Wo / rtx;
+                t.zsplit = ((int64_t)in0.B * cols < 1024 && No >= 8) ? 2 : 1;
+                { const char *z = getenv("DFFW_ROLL_ZSPLIT"); if (z && atoi(z) >= 1 && atoi(z) <= No) t.zsplit = atoi(z); }
+                t.total_tiles = in0.B * t.zsplit * cols;
+                t.wgs = 0;
+                { const char *z = getenv("DFFW_ROLL_WGS"); if (z && atoi(z) >= 8) t.wgs = atoi(z); }
+                {
+                    char kn[96];
+                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                    g_last_kernel = kn;
+                }
+                if (e->profiling) {
+                    char kn[96];
+                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                    const double opx = (double)out.B * No * Ho * Wo;
+                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
+                                         + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
+                                         + opx * L.cout * elem_bytes() * ((o.res0 ? 1 : 0) + (o.res1 ? 1 : 0))
+                                         + 27.0 * L.cin * L.cout * elem_bytes();
+                    prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout, bytes);
+                }
+                check(launch_conv_roll(e->prec, a, t, s), name.c_str());
+                prof_end();
+                return out;
+            }
+        }
         const bool use_tile = tp.cfg && !getenv_flag("DFFW_NO_TILE") && gW * 2 >= tp.cfg->tx && gH * 2 >= tp.cfg->ty &&
                               in0.C % 8 == 0 && (!o.in1 || o.in1->C % 8 == 0);
         if (use_tile) {
@@ -884,6 +953,12 @@ struct Run {
             const bool use_stream = scfg && scfg->tz == cfg->tz && scfg->ty == cfg->ty && scfg->tx == cfg->tx &&
                                     t.total_tiles >= 1024 && getenv_flag("DFFW_STREAM");   // opt-in: measured slower than conv_tile
             if (use_stream) t.grid = 256;   // 8 XCDs x 32 CUs, one resident workgroup each
+            {
+                char kn[96];
+                if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
+                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1, kn, sizeof kn);
+                g_last_kernel = kn;
+            }
             if (e->profiling) {
                 char kn[96];
                 if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
@@ -948,6 +1023,11 @@ struct Run {
                 a.ooy = a.oox = 0;
             }
             a.M = (int64_t)a.B * a.Ng * a.Hg * a.Wg;
+            {
+                char kn[64];
+                conv_kernel_name(e->prec, L.cout, kn, sizeof kn);
+                g_last_kernel = kn;
+            }
             if (e->profiling) {
                 char kn[64];
                 conv_kernel_name(e->prec, L.cout, kn, sizeof kn);
@@ -1383,6 +1463,7 @@ extern "C" {
 
 const char *dffw_version(void) { return "dffw 0.1 (gfx950)"; }
 const char *dffw_last_error(void) { return g_err.c_str(); }
+const char *dffw_last_conv_kernel(void) { return g_last_kernel.c_str(); }
 
 int dffw_param_count(int net) {
     if (!known_net(net)) return fail(DFFW_EINVAL, "unknown net %d", net);

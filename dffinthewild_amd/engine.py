@@ -46,6 +46,7 @@ def _load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.dffw_version.restype = c_char_p
     lib.dffw_last_error.restype = c_char_p
+    lib.dffw_last_conv_kernel.restype = c_char_p
     lib.dffw_param_count.argtypes = [c_int]
     lib.dffw_param_info.argtypes = [c_int, c_int, POINTER(c_char_p), POINTER(c_int64), POINTER(c_int), POINTER(c_int)]
     lib.dffw_engine_create.argtypes = [c_int, c_int, POINTER(_Tensor), c_int, c_int, POINTER(c_void_p)]
@@ -80,7 +81,7 @@ ABI_SYMBOLS = (
     "dffw_version", "dffw_last_error", "dffw_param_count", "dffw_param_info", "dffw_engine_create",
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
     "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
-    "dffw_op_fov_warp", "dffw_forward_e2e",
+    "dffw_op_fov_warp", "dffw_forward_e2e", "dffw_last_conv_kernel",
 )
 
 
@@ -265,6 +266,11 @@ def op_conv3d(x, weight, *, stride=1, pad=0, dilation=1, transposed=False, bn=No
                                   c_void_p(res.data_ptr()) if res is not None else None, relu,
                                   c_void_p(y.data_ptr()), _stream_ptr(dev)), "dffw_op_conv3d")
     return y
+
+
+def last_conv_kernel():
+    """Kernel instantiation used by this thread's most recent convolution launch (rocprofv3 spelling)."""
+    return lib.dffw_last_conv_kernel().decode()
 
 
 def op_pool(x, k, mode="max", precision="bf16x3"):

@@ -61,6 +61,9 @@ typedef struct dffw_tap {
 
 const char *dffw_version(void);
 const char *dffw_last_error(void);
+/* Name of the kernel instantiation the calling thread's most recent convolution launch used (as rocprofv3 spells
+ * it, e.g. "dffw::conv_roll<0, 8, 16, 4>"); "" before any.  Parity tests use it to prove which kernel they hit. */
+const char *dffw_last_conv_kernel(void);
 
 /* The weight contract (replaces nn.Module.state_dict() of DEN.py:7-57): number of state-dict
  * entries of network `net`, and entry `index` in the reference's registration order.

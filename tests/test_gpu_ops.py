@@ -74,6 +74,34 @@ def test_conv_families(eng, case, prec):
     assert rel(got, ref) <= TOL[prec], (name, prec, rel(got, ref))
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("cout,N,H,W,zsplit,residual,wgs", [(8, 10, 128, 128, 1, True, 0), (16, 5, 128, 128, 1, False, 24), (8, 1, 64, 256, 1, False, 8),
+                                                             (16, 10, 64, 256, 2, True, 40), (16, 7, 128, 128, 3, False, 0), (8, 2, 128, 128, 2, True, 16)])
+def test_conv_roll_rolling_window(eng, cout, N, H, W, zsplit, residual, wgs, prec, monkeypatch):
+    """conv_roll (dffw_conv_roll.hip): the 16-channel 3x3x3 stride-1 layers of the full-resolution hourglass
+    (DEN.py:240-284, dres4.conv0 / conv2) as a rolling window along the slices; every slice count incl. 1 and 2,
+    a slice range split over 1-3 workgroups, both output widths, with and without the residual + ReLU epilogue,
+    one column per workgroup (wgs=0: the grid covers them) and long streams of columns per workgroup (wgs=8..40).
+    The same case with DFFW_NO_ROLL=1 must take conv_tile and agree."""
+    B, cin = 2, 16
+    x = rnd(B, cin, N, H, W, seed=21)
+    w = rnd(cout, cin, 3, 3, 3, seed=22, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 23)
+    res = rnd(B, cout, N, H, W, seed=24) if residual else None
+    ref = ref_bn(F.conv3d(x, w, None, 1, 1), bn)
+    ref = F.relu(ref + res) if residual else F.relu(ref)
+    monkeypatch.setenv("DFFW_ROLL_ZSPLIT", str(zsplit))
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    got = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll<"), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL[prec], rel(got, ref)
+    monkeypatch.setenv("DFFW_NO_ROLL", "1")
+    alt = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(alt, ref) <= TOL[prec]
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16"])
 @pytest.mark.parametrize("cin,cout,N,H,W", [(16, 8, 3, 8, 8), (64, 32, 2, 8, 16), (128, 64, 2, 4, 4), (32, 32, 1, 8, 8)])
 def test_transposed_conv_phases(eng, cin, cout, N, H, W, prec):
