@@ -34,6 +34,17 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+}  // namespace dffw
+int dffw_fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    dffw::g_err = buf;
+    return code;
+}
+namespace dffw {
 #define HIPCHK(expr)                                                                          \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

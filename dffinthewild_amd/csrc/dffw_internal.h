@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// thread-local error message of the C ABI (dffw_last_error); returns `code`
+int dffw_fail(int code, const char *fmt, ...);
+
 namespace dffw {
 
 // ---- activation storage ---------------------------------------------------------------------

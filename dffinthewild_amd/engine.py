@@ -71,6 +71,14 @@ def _load():
                                      c_void_p, c_void_p, c_void_p]
     lib.dffw_op_regress.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     POINTER(c_int64), c_void_p, c_void_p]
+    c_u8p = POINTER(ctypes.c_uint8)
+    lib.dffw_pack_stack.argtypes = [c_int, c_void_p, c_int, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.dffw_colorize.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]
+    lib.dffw_jet_lut.argtypes = [c_u8p]
+    lib.dffw_metrics_scratch_bytes.argtypes = [c_int]
+    lib.dffw_metrics_scratch_bytes.restype = c_int64
+    lib.dffw_metrics.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                 c_int64, c_void_p]
     return lib
 
 
@@ -82,6 +90,7 @@ ABI_SYMBOLS = (
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
     "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
     "dffw_op_fov_warp", "dffw_forward_e2e", "dffw_last_conv_kernel",
+    "dffw_pack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
 )
 
 

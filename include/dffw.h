@@ -166,6 +166,49 @@ int dffw_op_regress(int device, const float *score, int B, int N, int h, int w, 
 int dffw_op_fov_warp(int device, const float *x, int B, int C, int N, int H, int W, const float *alpha,
                      const float *fovs, int alpha_from_sample0, float *out, float *flow, void *hip_stream);
 
+/* ---- input pipeline ---------------------------------------------------------------
+ * Replaces the NumPy tensor assembly of the reference's loaders: `FS/127.5 - 1.0`, the transpose to (3,N,H,W) and the
+ * bottom/right padding to multiples of 32 with -1 (Depth_Estimation_Test/test_Dataloader.py:36-39 FS6, :80-89 HCI,
+ * :122-141 DDFF, :197-228 Smartphone; End_to_End/Test_dataloader.py:56-75 Real_Scenes).
+ *   raw      device uint8 (DFFW_RAW_U8) or fp32 0..255 (DFFW_RAW_F32) stack in ANY source layout, described by
+ *            element strides {batch, slice, row, col, channel}: (N,H,W,3) hdf5 stacks, (H,W,3,N) / (H,W,N,3) image
+ *            arrays; a crop (test_Dataloader.py:205, Test_dataloader.py:58) is a pointer offset by the caller
+ *   h, w     rows / cols taken from the source;  Hp, Wp  padded size, multiples of 32, >= h, w
+ *   FS       device fp32 (B,3,N,Hp,Wp): exactly the tensor the reference's loader yields (float32 divide, then
+ *            subtract; -1 in the padding).  Enqueue-only on hip_stream. */
+#define DFFW_RAW_U8 0
+#define DFFW_RAW_F32 1
+int dffw_pack_stack(int device, const void *raw, int dtype, const int64_t strides[5], int B, int N, int h, int w,
+                    int Hp, int Wp, float *FS, void *hip_stream);
+
+/* ---- output post-processing -------------------------------------------------------
+ * dffw_colorize replaces the crop + normalise + `cm.get_cmap('jet')` + uint8 pass of Depth_Estimation_Test/test.py:124-133
+ * and End_to_End/test_real_scenes.py:40-52:  rgb[b,y,x,:] = jet((depth[b,y,x] - lo) / (hi - lo)) for y < h, x < w.
+ *   depth    device fp32 (B,H,W) as returned by dffw_forward (pred3)
+ *   mode     DFFW_RANGE_FIXED: lo, hi given (test.py:132, the data set's depth range);
+ *            DFFW_RANGE_MINMAX: each map's own min / max over the whole padded map (test_real_scenes.py:40)
+ *   range    device fp32 (B,2) scratch AND result: the (lo, hi) pair used for every map
+ *   rgb      device uint8 (B,h,w,3), RGB, `(255 * colour).astype(uint8)` truncation (test_real_scenes.py:48-49)
+ * Colour-map semantics are matplotlib's: index = trunc(float32(x * 256)), x == 1 -> 255, x < 0 / x > 1 clamp, NaN -> black.
+ * dffw_jet_lut writes the 256 x 3 uint8 table the kernel uses (host memory) for inspection / tests. */
+#define DFFW_RANGE_FIXED 0
+#define DFFW_RANGE_MINMAX 1
+int dffw_colorize(int device, const float *depth, int B, int H, int W, int h, int w, int mode, float lo, float hi,
+                  float *range, uint8_t *rgb, void *hip_stream);
+int dffw_jet_lut(uint8_t *lut768);
+
+/* dffw_metrics replaces the masked NumPy metrics of Depth_Estimation_Test/metrics.py:90-127 as called from
+ * test.py:144-158: est = pred3 (B,H,W) cropped to (h,w) (test.py:124-126); gt fp32 (B,h,w); mask uint8 (B,h,w)
+ * (non-zero = valid); conf fp32 (B,h,w) or NULL (Smartphone confidence, test.py:145-146).
+ *   out      device fp64 (B, DFFW_N_METRICS): valid pixels, abs_rel, sq_rel, mse, mae, rmse, rmse_log,
+ *            accuracy(1.25), accuracy(1.25^2), accuracy(1.25^3), mse_w_conf, mae_w_conf (the last two NaN without conf)
+ *   scratch  device memory of dffw_metrics_scratch_bytes(B)
+ * Per-pixel terms are float32 like the NumPy expressions; sums are float64 in a fixed order (run-to-run identical). */
+#define DFFW_N_METRICS 12
+int64_t dffw_metrics_scratch_bytes(int B);
+int dffw_metrics(int device, const float *est, int B, int H, int W, const float *gt, const uint8_t *mask,
+                 const float *conf, int h, int w, double *out, void *scratch, int64_t scratch_bytes, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,145 @@
+"""Input assembly and output post-processing around the forward.
+CPU part: the oracle (oracle/pipeline_ref.py) against outputs of matplotlib's own colour map (tests/golden/io_jet.npz)
+and the library's colour table against the same golden.  GPU part (-m gpu): the HIP kernels through the C ABI against
+the oracle, bit-exact for the byte / index work, 1e-6 for the float64 metric means."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_ref as ref
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "io_jet.npz"))
+
+
+def test_oracle_colorize_matches_matplotlib_golden():
+    got = ref.colorize(GOLD["depth"][0], size=tuple(GOLD["crop"]))
+    assert np.array_equal(got, GOLD["rgb_minmax"])                      # test_real_scenes.py:40-52 sequence
+    got = ref.colorize(GOLD["depth_fixed"], vrange=tuple(GOLD["fixed_range"]))
+    assert np.array_equal(got, GOLD["rgb_fixed"])                       # fixed range, under / over / NaN pixels
+
+
+def test_library_colour_table_is_matplotlibs(lib_built):
+    lib = ctypes.CDLL(lib_built)
+    buf = (ctypes.c_uint8 * 768)()
+    assert lib.dffw_jet_lut(buf) == 0
+    assert np.array_equal(np.frombuffer(buf, np.uint8).reshape(256, 3), GOLD["lut_u8"])
+
+
+def test_oracle_pack_stack_layouts_agree():
+    rng = np.random.RandomState(3)
+    nhwc = rng.randint(0, 256, size=(5, 37, 50, 3)).astype(np.uint8)
+    a = ref.pack_stack(nhwc, "NHWC")
+    assert a.shape == (3, 5, 64, 64) and a.dtype == np.float32
+    assert np.array_equal(a, ref.pack_stack(np.transpose(nhwc, (1, 2, 3, 0)), "HWCN"))
+    assert np.array_equal(a, ref.pack_stack(np.transpose(nhwc, (1, 2, 0, 3)), "HWNC"))
+    assert np.all(a[:, :, 37:, :] == -1) and np.all(a[:, :, :, 50:] == -1)
+    assert a[1, 2, 3, 4] == np.float32(nhwc[2, 3, 4, 1]) / np.float32(127.5) - np.float32(1.0)
+
+
+def test_oracle_metrics_known_answers():
+    gt = np.full((4, 4), 2.0, np.float32)
+    est = gt.copy()
+    est[0, 0] = 4.0          # one pixel off by 2x: fails every accuracy threshold (1.25, 1.5625, 1.953)
+    mask = np.ones((4, 4), bool)
+    mask[3, 3] = False
+    m = ref.masked_metrics(est, gt, mask, conf=np.ones((4, 4), np.float32))
+    assert m[0] == 15 and np.isclose(m[1], 1.0 / 15) and np.isclose(m[3], 4.0 / 15) and np.isclose(m[4], 2.0 / 15)
+    assert np.isclose(m[7], 14.0 / 15) and np.isclose(m[8], 14.0 / 15) and np.isclose(m[9], 14.0 / 15) and np.isclose(m[10], m[3])
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def pl(lib_built):
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from dffinthewild_amd import pipeline
+    return pipeline
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["u8", "f32"])
+@pytest.mark.parametrize("layout,shape,crop", [("NHWC", (5, 37, 50, 3), None), ("HWCN", (64, 96, 3, 10), None), ("HWNC", (70, 45, 4, 3), (3, 5, 60, 33)),
+                                               ("NHWC", (1, 32, 32, 3), None), ("HWCN", (130, 100, 3, 10), (10, 8, 108, 84))])
+def test_pack_stack_bit_exact(pl, layout, shape, crop, dtype):
+    rng = np.random.RandomState(11)
+    raw = rng.randint(0, 256, size=shape).astype(np.uint8 if dtype == "u8" else np.float32)
+    want = ref.pack_stack(raw, layout, crop)
+    got = pl.pack_stack(torch.from_numpy(raw).cuda(), layout, crop)
+    assert got.shape == (1,) + want.shape
+    assert np.array_equal(got[0].cpu().numpy(), want)
+    # batch of two different stacks, second one a non-contiguous view
+    big = torch.from_numpy(np.stack([raw, raw[::-1].copy()])).cuda()
+    got2 = pl.pack_stack(big, layout, crop)
+    assert np.array_equal(got2[0].cpu().numpy(), want) and np.array_equal(got2[1].cpu().numpy(), ref.pack_stack(raw[::-1], layout, crop))
+
+
+@pytest.mark.gpu
+def test_pack_stack_rejects_bad_input(pl):
+    with pytest.raises(RuntimeError):
+        pl.pack_stack(torch.zeros(2, 32, 32, 3, dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        pl.pack_stack(torch.zeros(2, 32, 32, 4, dtype=torch.uint8).cuda())
+    with pytest.raises(ValueError):
+        pl.pack_stack(torch.zeros(2, 32, 32, 3, dtype=torch.uint8).cuda(), crop=(0, 0, 40, 8))
+
+
+@pytest.mark.gpu
+def test_colorize_matches_matplotlib_golden_and_oracle(pl):
+    d = torch.from_numpy(GOLD["depth"]).cuda()
+    rgb, rng = pl.colorize(d, size=tuple(int(v) for v in GOLD["crop"]), return_range=True)
+    assert np.array_equal(rgb[0].cpu().numpy(), GOLD["rgb_minmax"])
+    assert float(rng[0, 0]) == float(GOLD["depth"].min()) and float(rng[0, 1]) == float(GOLD["depth"].max())
+    lo, hi = (float(v) for v in GOLD["fixed_range"])
+    got = pl.colorize(torch.from_numpy(GOLD["depth_fixed"]).cuda(), vrange=(lo, hi))
+    assert np.array_equal(got.cpu().numpy(), GOLD["rgb_fixed"])
+    # a batch with different ranges per map, full BASELINE size
+    g = torch.Generator().manual_seed(5)
+    big = torch.rand(3, 256, 256, generator=g) * torch.tensor([1.0, 5.0, 0.01]).reshape(3, 1, 1) + 0.1
+    out = pl.colorize(big.cuda(), size=(250, 231)).cpu().numpy()
+    for b in range(3):
+        assert np.array_equal(out[b], ref.colorize(big[b].numpy(), size=(250, 231)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_conf", [False, True])
+def test_masked_metrics_match_numpy(pl, with_conf):
+    g = torch.Generator().manual_seed(9)
+    B, H, W, h, w = 3, 64, 96, 61, 90
+    est = torch.rand(B, H, W, generator=g) * 1.4 + 0.1
+    gt = torch.rand(B, h, w, generator=g) * 1.4 + 0.1
+    mask = torch.rand(B, h, w, generator=g) > 0.3
+    mask[2] = False
+    mask[2, 5, 7] = True                       # a single valid pixel
+    conf = torch.rand(B, h, w, generator=g) if with_conf else None
+    got = pl.masked_metrics(est.cuda(), gt.cuda(), mask.cuda(), conf.cuda() if with_conf else None).cpu().numpy()
+    again = pl.masked_metrics(est.cuda(), gt.cuda(), mask.cuda(), conf.cuda() if with_conf else None).cpu().numpy()
+    assert np.array_equal(got, again, equal_nan=True)          # fixed reduction order
+    for b in range(B):
+        want = ref.masked_metrics(est[b, :h, :w].numpy(), gt[b].numpy(), mask[b].numpy(), conf[b].numpy() if with_conf else None)
+        n = 12 if with_conf else 10
+        assert np.allclose(got[b, :n], want[:n], rtol=2e-6, atol=0), (b, got[b], want)
+        if not with_conf:
+            assert np.isnan(got[b, 10]) and np.isnan(got[b, 11])
+
+
+@pytest.mark.gpu
+def test_raw_stack_to_colour_map_end_to_end(pl):
+    """uint8 stack -> pack_stack -> Network -> colorize / metrics: equals the reference tensor contract fed by hand."""
+    from dffinthewild_amd import graph, synth
+    from dffinthewild_amd.Depth_Estimation_Network import Network
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 0, "smooth").items()}
+    model = Network()
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    rng = np.random.RandomState(2)
+    raw = rng.randint(0, 256, size=(5, 50, 70, 3)).astype(np.uint8)          # DDFF-like (N,H,W,3), needs padding to 64x96
+    fd = pl.focus_dists(np.linspace(0.1, 1.5, 5), 1)
+    with torch.no_grad():
+        a = model(pl.pack_stack(torch.from_numpy(raw).cuda(), "NHWC"), fd)[3]
+        b = model(torch.from_numpy(ref.pack_stack(raw, "NHWC")).unsqueeze(0).cuda(), fd)[3]
+    assert torch.equal(a, b) and a.shape == (1, 64, 96)
+    rgb = pl.colorize(a, size=(50, 70), vrange=(0.1, 1.5))
+    assert np.array_equal(rgb[0].cpu().numpy(), ref.colorize(a[0].cpu().numpy(), size=(50, 70), vrange=(0.1, 1.5)))
