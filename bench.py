@@ -213,6 +213,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--input", choices=("fp32", "u8"), default="fp32",
+                    help="fp32: the reference's tensor contract (B,3,N,H,W) float32 (default, the headline); u8: the raw uint8 "
+                         "(B,N,H,W,3) stack a loader holds before /127.5-1, normalised inside the stem kernel (Network.forward_raw)")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch profile table to this file")
     args = ap.parse_args()
 
@@ -243,9 +246,16 @@ def main():
         fd = torch.from_numpy(synth.focus_dists(B, N, Hh, Ww)).to(device)  # dense tile, as test_Dataloader.py:24
         inputs = (FS, fd)
 
+    raw_u8 = None
+    if args.input == "u8":
+        if e2e:
+            raise SystemExit("--input u8 is implemented for --workload depth")
+        # same synthetic stack quantised to the loaders' source format: uint8 (B,N,H,W,3)
+        raw_u8 = ((FS + 1.0) * 127.5).round().clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 4, 1).contiguous()
+
     def step():
         with torch.no_grad():
-            outs = model(*inputs)
+            outs = model.forward_raw(raw_u8, fd, "NHWC") if raw_u8 is not None else model(*inputs)
             gathered = ddist.all_gather_depth(outs[3]) if world > 1 else outs[3]
         return outs, gathered
 
@@ -288,10 +298,11 @@ def main():
                                     f"synthetic weights seed 0"),
                        "batch_per_gpu": B, "global_batch": B * world, "slices": N, "height": Hh, "width": Ww,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of pred3" if world > 1 else "single GPU",
-                       "precision": args.precision},
+                       "precision": args.precision, "input": "uint8 (B,N,H,W,3), normalised in the stem kernel" if raw_u8 is not None
+                       else "float32 (B,3,N,H,W), the reference's tensor contract"},
             "forward_tflops_algorithmic": round(value * GFLOP_PER_STACK * scale / 1e3, 2),   # DFF_net's convs only
         }
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and raw_u8 is None:
         roof, per_kernel, rows = roofline_from_profile(model, inputs, device, args.precision)
         result["roofline"] = roof
         result["kernels"] = per_kernel
@@ -300,7 +311,7 @@ def main():
                 f.write("kernel\tlayer\tgflop\talg_MB\tms\ttflops\talg_GBs\n")
                 for k, l, fl, by, ms in rows:
                     f.write(f"{k}\t{l}\t{fl/1e9:.3f}\t{by/1e6:.2f}\t{ms:.4f}\t{fl/(ms*1e-3)/1e12 if ms else 0:.2f}\t{by/(ms*1e-3)/1e9 if ms else 0:.1f}\n")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and (e2e or (N, S) == (10, 256)):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and raw_u8 is None and (e2e or (N, S) == (10, 256)):
         from oracle import cpu_ref
         base, ref = cpu_baseline_e2e(sd, args.cpu_seconds, Hh, Ww) if e2e else cpu_baseline(sd, args.cpu_seconds)
         result["cpu_baseline"] = base

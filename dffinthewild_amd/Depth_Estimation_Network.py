@@ -163,6 +163,38 @@ class Network(nn.Module):
         FS, focus_dists = self._check_inputs(FS, focus_dists)
         return self._engine_on(FS.device).forward(FS, focus_dists)
 
+    def forward_raw(self, raw, focus_dists, layout="NHWC", crop=None):
+        """The same forward fed with the stack as the loaders hold it BEFORE `FS/127.5 - 1.0` (uint8 or float32 0..255
+        CUDA tensor in one of pipeline._LAYOUTS, optional crop (y0,x0,h,w)): normalisation, transpose and the -1
+        padding to multiples of 32 (test_Dataloader.py:122-141) happen inside the stem kernel's loader.  Bit-identical
+        to `self(pipeline.pack_stack(raw, layout, crop), focus_dists)`; output maps have the padded size."""
+        from . import pipeline as _pl
+        if layout not in _pl._LAYOUTS:
+            raise ValueError(f"unknown layout {layout!r}")
+        if self.training:
+            raise RuntimeError("dffinthewild_amd.Network is an inference engine: call model.eval() first, as test.py:85 does")
+        if not (torch.is_tensor(raw) and raw.is_cuda):
+            raise RuntimeError("dffinthewild_amd.Network runs only on a ROCm GPU (HIP kernels, no CPU fallback)")
+        if raw.dtype not in (torch.uint8, torch.float32):
+            raise TypeError(f"raw stack must be uint8 or float32, got {raw.dtype}")
+        if raw.dim() == 4:
+            raw = raw.unsqueeze(0)
+        an, ay, ax, ac = (1 + a for a in _pl._LAYOUTS[layout])
+        if raw.dim() != 5 or raw.shape[ac] != 3:
+            raise ValueError(f"layout {layout}: bad raw stack shape {tuple(raw.shape)}")
+        B, N, Hs, Ws = raw.shape[0], raw.shape[an], raw.shape[ay], raw.shape[ax]
+        y0, x0, h, w = (0, 0, Hs, Ws) if crop is None else crop
+        if y0 < 0 or x0 < 0 or h < 1 or w < 1 or y0 + h > Hs or x0 + w > Ws:
+            raise ValueError(f"crop {crop} does not fit the {Hs}x{Ws} source")
+        H, W = -(-h // 32) * 32, -(-w // 32) * 32
+        _graph.check_stack_shape((B, 3, N, H, W), focus_dists.shape)
+        if focus_dists.device != raw.device:
+            raise RuntimeError(f"raw stack is on {raw.device} but focus_dists on {focus_dists.device}")
+        st = raw.stride()
+        ptr = raw.data_ptr() + (y0 * st[ay] + x0 * st[ax]) * raw.element_size()
+        return self._engine_on(raw.device).forward_raw(ptr, (st[0], st[an], st[ay], st[ax], st[ac]), 0 if raw.dtype == torch.uint8 else 1,
+                                                       h, w, focus_dists.float(), B, N, H, W)
+
     def forward_with_taps(self, FS, focus_dists, names):
         """Debug variant: also returns {name: tensor} for intermediate volumes (V1, V2, V3,
         FS_volume, conf, cost1, cost2, cost3) in the reference's layout."""

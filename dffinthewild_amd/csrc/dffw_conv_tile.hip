@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     const Coord cur = decode(tile);
     // split-K (few-tile layers with a deep contraction, see Run::conv): blockIdx.z owns a contiguous range of the
     // channel-group stages and writes raw fp32 partial sums; splitk_finish adds them up and runs the epilogue
-    const bool splitk = SPLITK && t.ksplit > 1;
+    const bool splitk = SPLITK && GEO != G2D && t.ksplit > 1;
     const int st_lo = splitk ? (int)blockIdx.z * t.nstage / t.ksplit : 0;
     const int st_hi = splitk ? ((int)blockIdx.z + 1) * t.nstage / t.ksplit : t.nstage;
     // pass split (transposed conv, few tiles): the 4 sub-pixel passes write disjoint output phases, so they can be
@@ -202,6 +202,19 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
         const int W = a.Wi - 2;
         const int64_t plane = (int64_t)a.Ni * a.Hi * W;
         const float *src = a.fs32 + (int64_t)c.b * 3 * plane + (int64_t)c.gz0 * a.Hi * W;
+        constexpr bool rawmode = (GEO == G2D) && SPLITK;   // the stem's "SPLITK" instantiation is its raw-source variant (it never splits K)
+        RawStack rs{};
+        if constexpr (rawmode) rs = *reinterpret_cast<const RawStack *>(a.fs32);   // wave-uniform: scalar loads
+        const int64_t rbase = c.b * rs.sb + c.gz0 * rs.sn;
+        // value of colour ch at (row iy, column q) of the padded stack; zero outside it (the conv's padding)
+        auto px = [&](int ch, int iy, int q) -> float {
+            if ((unsigned)q >= (unsigned)W) return 0.f;
+            if constexpr (!rawmode) return src[(int64_t)iy * W + ch * plane + q];
+            if (iy >= rs.h || q >= rs.w) return -1.f;     // the loaders' pad value (test_Dataloader.py:126-137)
+            const int64_t o = rbase + iy * rs.sy + q * rs.sx + ch * rs.sc;
+            const float v = rs.dtype == 0 ? (float)reinterpret_cast<const uint8_t *>(rs.p)[o] : reinterpret_cast<const float *>(rs.p)[o];
+            return __fsub_rn(__fdiv_rn(v, 127.5f), 1.0f);       // float32 divide, then subtract: as dffw_pack_stack / the loaders
+        };
         const int iy0 = c.gy0 + G::MINY, ix0 = c.gx0 + G::MINX;
         constexpr int NIT = (T::FPIX + NWAVES * 64 - 1) / (NWAVES * 64);
 #pragma unroll   // constant trip count: the loads of all iterations can be in flight together
@@ -212,14 +225,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             const int iy = iy0 + fy, q = ix0 + fx;
             short8 h = short8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
             if ((unsigned)iy < (unsigned)a.Hi) {
-                const float *row = src + (int64_t)iy * W;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     uint16_t hi, lo;
-                    Fmt<PREC>::split((unsigned)(q - 2) < (unsigned)W ? row[ch * plane + q - 2] : 0.f, hi, lo);
+                    Fmt<PREC>::split(px(ch, iy, q - 2), hi, lo);
                     h[ch] = (short)hi;
                     l[ch] = (short)lo;
-                    Fmt<PREC>::split((unsigned)q < (unsigned)W ? row[ch * plane + q] : 0.f, hi, lo);
+                    Fmt<PREC>::split(px(ch, iy, q), hi, lo);
                     h[4 + ch] = (short)hi;
                     l[4 + ch] = (short)lo;
                 }
@@ -589,7 +601,7 @@ void conv_tile_kernel_name(int prec, const TileCfg *c, bool splitk, char *buf, i
 
 template <int PREC>
 static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
-    switch (t.ksplit > 1 ? 1000 + cfg->id : cfg->id) {
+    switch (t.ksplit > 1 ? 1000 + cfg->id : ((a.dbg & DFFW_ARGS_RAW) ? 2000 + cfg->id : cfg->id)) {
 #define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
     case ID:                                                                                                        \
         hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : (t.pass_split ? 4 : 1))), dim3(256), 0, s, a, t); \
@@ -608,6 +620,13 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
         break;
         DFFW_TILE_CONFIGS_SPLITK(X_LAUNCHK)
 #undef X_LAUNCHK
+        // the stem reading a raw (uint8 / 0..255) stack: its "SPLITK" instantiations
+        case 2000 + 15:
+            hipLaunchKernelGGL((conv_tile<PREC, G2D, 1, 1, 16, 32, 8, 0, 4, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, 1), dim3(256), 0, s, a, t);
+            break;
+        case 2000 + 31:
+            hipLaunchKernelGGL((conv_tile<PREC, G2D, 1, 1, 32, 32, 8, 0, 8, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, 1), dim3(512), 0, s, a, t);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

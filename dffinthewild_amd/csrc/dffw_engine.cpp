@@ -672,6 +672,7 @@ struct ConvOpt {
     float *outf = nullptr;   // fp32 planar output (B,outf_ch,N,H,W) instead of an activation volume
     int outf_ch = 1;
     const float *fs32 = nullptr;  // stem: read the fp32 focal stack directly (in0 then only carries the geometry)
+    bool raw = false;   // stem: fs32 is a device-side RawStack descriptor (raw uint8 / 0..255 stack, normalised and padded on the fly)
     const char *cls = nullptr;  // name of a 1x1x1 C->1 layer to apply to the final value inside the epilogue
     float *cls_out = nullptr;   // its fp32 score volume
     bool discard = false;       // the activation output itself is not needed (only cls_out / out_pre)
@@ -850,7 +851,8 @@ struct Run {
         a.relu = o.relu;
         if (!dry && e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
-        { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? atoi(d) : 0; }
+        { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 7) : 0; }
+        if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
         const TilePack &tp = pc.tile;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
         // rolling-window kernel: 16-channel 3x3x3 stride-1 layers whose grid is whole columns and fills the chip
@@ -967,13 +969,13 @@ struct Run {
             {
                 char kn[96];
                 if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
-                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1, kn, sizeof kn);
+                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & DFFW_ARGS_RAW), kn, sizeof kn);
                 g_last_kernel = kn;
             }
             if (e->profiling) {
                 char kn[96];
                 if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
-                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1, kn, sizeof kn);
+                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & DFFW_ARGS_RAW), kn, sizeof kn);
                 const double opx = (double)out.B * No * Ho * Wo;
                 const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
                                      + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
@@ -1236,7 +1238,10 @@ static void regress(Run &r, const char *tag, const float *score, int B, int N, i
     r.prof_end();
 }
 
-static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst[4], int B, int N, int H, int W, float *const out[4]) {
+// raw != null: FS is not given; the stem reads the raw stack (or, when the tiled stem kernel does not serve this
+// shape, the stack is first expanded into a temporary fp32 volume from the workspace)
+static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst[4], int B, int N, int H, int W, float *const out[4],
+                     const RawStack *raw = nullptr) {
     const std::string P = "DFF_net";
     const int prec = r.e->prec;
     ConvOpt rl; rl.relu = 1;
@@ -1254,8 +1259,25 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
         geom.B = B; geom.N = N; geom.H = H; geom.W = W + 2; geom.C = 8;
         ConvOpt so = rl;
         so.fs32 = FS;
+        RawStack *rdev = nullptr;
+        if (raw) {
+            rdev = (RawStack *)r.raw(256);
+            if (r.ok() && !r.dry) r.check(launch_set_raw(*raw, rdev, r.s), "set_raw");
+            so.fs32 = (const float *)rdev;
+            so.raw = true;
+        }
         stem = r.conv(stem_name, geom, so);
+        r.drop_raw(rdev);
     } else {
+        float *tmp = nullptr;
+        if (raw) {
+            tmp = (float *)r.raw((int64_t)B * 3 * N * H * W * (int64_t)sizeof(float));
+            if (r.ok() && !r.dry) {
+                const int64_t st[5] = {raw->sb, raw->sn, raw->sy, raw->sx, raw->sc};
+                if (dffw_pack_stack(r.e->device, raw->p, raw->dtype, st, B, N, raw->h, raw->w, H, W, tmp, r.s) != DFFW_OK) r.err = DFFW_EHIP;
+            }
+            FS = tmp;
+        }
         Act in = r.act(B, N, H, W + 2, 8);   // paired-pixel records, see stack_in_kernel
         if (r.ok() && !r.dry) {
             char kn[48];
@@ -1266,6 +1288,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
         }
         stem = r.conv(stem_name, in, rl);
         r.drop(in);
+        r.drop_raw(tmp);
     }
     Act v1p, v2p;   // max-pooled copies written by the attention kernels on the way (EFD's second branch)
     Act v1 = srd(r, P + ".FM_measure.Focus_extraction.2", stem, true, &v1p);
@@ -1626,6 +1649,23 @@ int dffw_forward_taps(dffw_engine *e, const float *FS, const float *focus_dists,
     r.taps = taps;
     r.n_taps = taps ? n_taps : 0;
     return run_depth(r, FS, focus_dists, fd_strides, B, N, H, W, out);
+}
+
+int dffw_forward_raw(dffw_engine *e, const void *raw, int dtype, const int64_t raw_strides[5], int h, int w, const float *focus_dists,
+                     const int64_t fd_strides[4], int B, int N, int H, int W, float *const out[4], void *workspace,
+                     int64_t workspace_bytes, void *hip_stream) {
+    if (!e || !raw || !raw_strides || !focus_dists || !fd_strides || !out) return fail(DFFW_EINVAL, "null argument");
+    if (e->net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "dffw_forward_raw serves DFFW_NET_DEPTH engines");
+    if (dtype != DFFW_RAW_U8 && dtype != DFFW_RAW_F32) return fail(DFFW_EINVAL, "unknown raw dtype %d", dtype);
+    int rc = check_dims(B, N, H, W);
+    if (rc) return rc;
+    if (h < 1 || w < 1 || h > H || w > W) return fail(DFFW_EINVAL, "source %dx%d does not fit the padded stack %dx%d", h, w, H, W);
+    if (!workspace) return fail(DFFW_ENOMEM, "workspace is null");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->profiling) e->clear_recs();
+    Run r(e, (hipStream_t)hip_stream, false, (char *)workspace, workspace_bytes);
+    RawStack rs{raw, dtype, raw_strides[0], raw_strides[1], raw_strides[2], raw_strides[3], raw_strides[4], h, w};
+    return run_depth(r, nullptr, focus_dists, fd_strides, B, N, H, W, out, &rs);
 }
 
 int dffw_forward(dffw_engine *e, const float *FS, const float *focus_dists, const int64_t fd_strides[4], int B, int N, int H,

@@ -31,6 +31,18 @@ static_assert(sizeof(TapEntry) == 16, "TapEntry must be 16 bytes");
 
 #define DFFW_TAP_INVALID (1 << 20)
 
+// A raw focal stack as the reference's loaders hold it before `FS/127.5 - 1.0` (dffw_forward_raw): uint8 or fp32
+// 0..255, any layout, described by element strides; rows >= h / cols >= w of the (padded) stack read as -1.
+struct RawStack {
+    const void *p;                  // null: not used
+    int dtype;                      // DFFW_RAW_U8 / DFFW_RAW_F32
+    int64_t sb, sn, sy, sx, sc;     // element strides: sample, slice, row, col, colour channel
+    int h, w;                       // rows / cols present in the source
+};
+
+#define DFFW_ARGS_RAW 8
+// (ConvArgs must not grow: the register allocation of the lean transposed-conv kernels is sensitive to its size, a
+// 56-byte larger argument block cost them 38 %)
 struct ConvArgs {
     const uint16_t *in0, *in1;  // in1: second half of a virtual channel concat (C1 = 0: none)
     int C0, C1;
@@ -53,7 +65,8 @@ struct ConvArgs {
     const float *cls_w;         // fused 1x1x1 classifier (DEN.py:51-55): Cout fp32 weights applied to the final value, or null
     float *cls_out;             // its fp32 score volume (B,No,Ho,Wo)
     int relu;                   // 0: none   1: relu(acc+res)   2: relu(acc)+res
-    int dbg;                    // ablation switches for profiling (0 in production): 1 no fill, 2 no MFMA loop, 4 no stores
+    int dbg;                    // ablation switches for profiling (0 in production): 1 no fill, 2 no MFMA loop, 4 no stores;
+                                // bit 3 (DFFW_ARGS_RAW): fs32 points to a RawStack in device memory instead of the fp32 stack
     const uint16_t *zero;       // >= 16 zero bytes in device memory (source of out-of-volume LDS-DMA lanes)
     const float *fs32;          // stem only: the fp32 planar focal stack (B,3,N,H,Wi-2); when set the kernel builds its paired-pixel
                                 // records on the fly instead of reading a materialised volume through in0
@@ -65,6 +78,7 @@ struct ConvArgs {
 int conv_nt_for(int cout);  // 16-channel output tiles the conv kernel picked for `cout` iterates over
 hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s);
 void conv_kernel_name(int prec, int cout, char *buf, int n);  // name of the instantiation launch_conv picks
+hipError_t launch_set_raw(const RawStack &rs, RawStack *dst, hipStream_t s);   // writes the descriptor into device memory (enqueue-only)
 hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int N, int H, int W, hipStream_t s);
 hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C, int N, int H, int W, hipStream_t s);

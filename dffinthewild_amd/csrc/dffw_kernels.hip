@@ -773,4 +773,10 @@ hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H,
     return hipGetLastError();
 }
 
+__global__ void set_raw_kernel(RawStack rs, RawStack *dst) { *dst = rs; }
+hipError_t launch_set_raw(const RawStack &rs, RawStack *dst, hipStream_t s) {
+    hipLaunchKernelGGL(set_raw_kernel, dim3(1), dim3(1), 0, s, rs, dst);
+    return hipGetLastError();
+}
+
 }  // namespace dffw

@@ -61,6 +61,8 @@ def _load():
     lib.dffw_forward_taps.argtypes = fwd + [POINTER(_Tap), c_int]
     lib.dffw_forward_e2e.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_int, c_int, c_int, c_int,
                                      POINTER(c_void_p), c_void_p, c_void_p, c_int64, c_void_p, POINTER(_Tap), c_int]
+    lib.dffw_forward_raw.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_int64), c_int, c_int, c_void_p, POINTER(c_int64), c_int, c_int, c_int,
+                                     c_int, POINTER(c_void_p), c_void_p, c_int64, c_void_p]
     lib.dffw_profile_enable.argtypes = [c_void_p, c_int]
     lib.dffw_profile_collect.argtypes = [c_void_p, POINTER(_Prof), c_int]
     lib.dffw_op_conv3d.argtypes = [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int,
@@ -90,7 +92,7 @@ ABI_SYMBOLS = (
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
     "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
     "dffw_op_fov_warp", "dffw_forward_e2e", "dffw_last_conv_kernel",
-    "dffw_pack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
+    "dffw_forward_raw", "dffw_pack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
 )
 
 
@@ -168,11 +170,11 @@ class Engine:
     def workspace_bytes(self, B, N, H, W):
         return _check(lib.dffw_workspace_bytes(self._h, B, N, H, W), "dffw_workspace_bytes")
 
-    def _workspace(self, B, N, H, W):
-        key = (B, N, H, W)
+    def _workspace(self, B, N, H, W, extra=0):
+        key = (B, N, H, W, extra)
         ws = self._ws.get(key)
         if ws is None:
-            nbytes = self.workspace_bytes(B, N, H, W)
+            nbytes = self.workspace_bytes(B, N, H, W) + extra
             self._ws.clear()  # one resident workspace: shapes change rarely (test.py runs one dataset per process)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
@@ -201,6 +203,21 @@ class Engine:
             _check(lib.dffw_forward_taps(*args, tarr, len(bufs)), "dffw_forward_taps")
             return tuple(outs), bufs
 
+
+    def forward_raw(self, raw, strides, dtype, h, w, focus_dists, B, N, H, W):
+        """dffw_forward_raw: the stem normalises and pads the raw (uint8 / 0..255 float32) stack on the fly.
+        raw: tensor whose storage holds the stack; strides: element strides (sample, slice, row, col, channel) and the
+        data pointer already points at the crop origin; H, W: padded sizes."""
+        fd = focus_dists.expand(B, N, H, W)
+        fst = (c_int64 * 4)(*fd.stride())
+        outs = [torch.empty((B, H, W), dtype=torch.float32, device=fd.device) for _ in range(4)]
+        optrs = (c_void_p * 4)(*[o.data_ptr() for o in outs])
+        with self._lock, torch.cuda.device(self.index):
+            ws = self._workspace(B, N, H, W, extra=B * 3 * N * H * W * 4 + 256)
+            _check(lib.dffw_forward_raw(self._h, c_void_p(raw), dtype, (c_int64 * 5)(*strides), h, w, c_void_p(fd.data_ptr()), fst,
+                                        B, N, H, W, optrs, c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index)),
+                   "dffw_forward_raw")
+        return tuple(outs)
 
     def forward_e2e(self, FS, focus_dists, fovs, taps=None):
         """End_to_End.Network.forward: FS (B,3,10,H,W), focus_dists broadcastable to (B,10,H,W), fovs with B*10

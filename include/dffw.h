@@ -181,6 +181,15 @@ int dffw_op_fov_warp(int device, const float *x, int B, int C, int N, int H, int
 int dffw_pack_stack(int device, const void *raw, int dtype, const int64_t strides[5], int B, int N, int h, int w,
                     int Hp, int Wp, float *FS, void *hip_stream);
 
+/* dffw_forward on the raw stack: the stem kernel's loader applies `x/127.5 - 1` and the -1 padding while it stages its
+ * tiles, so the normalised fp32 stack (4x the bytes of a uint8 source) is never written or read.  Bit-identical to
+ * dffw_pack_stack followed by dffw_forward.  raw / dtype / raw_strides / h / w as for dffw_pack_stack; H, W are the
+ * padded sizes (multiples of 32, >= h, w).  DFFW_NET_DEPTH engines.  Workspace: dffw_workspace_bytes(B,N,H,W) plus
+ * B*3*N*H*W*4 bytes (used only when the shape is too small for the tiled stem kernel and the stack is expanded first). */
+int dffw_forward_raw(dffw_engine *e, const void *raw, int dtype, const int64_t raw_strides[5], int h, int w,
+                     const float *focus_dists, const int64_t fd_strides[4], int B, int N, int H, int W,
+                     float *const out[4], void *workspace, int64_t workspace_bytes, void *hip_stream);
+
 /* ---- output post-processing -------------------------------------------------------
  * dffw_colorize replaces the crop + normalise + `cm.get_cmap('jet')` + uint8 pass of Depth_Estimation_Test/test.py:124-133
  * and End_to_End/test_real_scenes.py:40-52:  rgb[b,y,x,:] = jet((depth[b,y,x] - lo) / (hi - lo)) for y < h, x < w.

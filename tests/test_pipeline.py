@@ -143,3 +143,27 @@ def test_raw_stack_to_colour_map_end_to_end(pl):
     assert torch.equal(a, b) and a.shape == (1, 64, 96)
     rgb = pl.colorize(a, size=(50, 70), vrange=(0.1, 1.5))
     assert np.array_equal(rgb[0].cpu().numpy(), ref.colorize(a[0].cpu().numpy(), size=(50, 70), vrange=(0.1, 1.5)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,shape,crop", [("NHWC", (10, 250, 231, 3), None), ("HWCN", (300, 280, 3, 5), (20, 17, 256, 256)), ("HWNC", (50, 70, 4, 3), None)])
+@pytest.mark.parametrize("dtype", ["u8", "f32"])
+def test_forward_raw_is_bit_identical_to_pack_then_forward(pl, layout, shape, crop, dtype):
+    """dffw_forward_raw: the stem's loader normalises / pads the raw stack itself (tiled stem kernel for the two large
+    shapes, the expand-first fallback for the small one); results must equal pack_stack + forward bit for bit."""
+    from dffinthewild_amd import graph, synth
+    from dffinthewild_amd.Depth_Estimation_Network import Network
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 0, "smooth").items()}
+    model = Network()
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    rng = np.random.RandomState(4)
+    raw = torch.from_numpy(np.stack([rng.randint(0, 256, size=shape) for _ in range(2)]).astype(np.uint8 if dtype == "u8" else np.float32)).cuda()
+    N = shape[{"NHWC": 0, "HWCN": 3, "HWNC": 2}[layout]]
+    fd = pl.focus_dists(np.linspace(0.1, 1.5, N), 2)
+    with torch.no_grad():
+        a = model.forward_raw(raw, fd, layout, crop)
+        b = model(pl.pack_stack(raw, layout, crop), fd)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
