@@ -10,12 +10,14 @@ struct RollArgs {
     int zsplit;              // a sample's slices are walked by zsplit workgroups (contiguous ranges)
     int total_tiles;         // B * zsplit * tiles_y * tiles_x
     int wgs;                 // workgroups to launch (0: two per CU)
+    int pair;                // filter packed for the pixel-pair kernel (<= 8 output channels)
 };
 
-constexpr int ROLL_CHUNKS = 15;   // 3 slices x 5 chunks of (2 in-slice taps x 16 channels)
+constexpr int ROLL_CHUNKS = 15;        // 3 slices x 5 chunks of (2 in-slice taps x 16 channels)
+constexpr int ROLL_CHUNKS_PAIR = 18;   // pixel-pair form: 3 slices x 3 filter rows x 2 halves of (2 input columns x 16 channels)
 
 void roll_tile(int *ty, int *tx);   // column footprint of the instantiated kernel
 hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_kernel_name(int prec, bool res, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
+void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
 
 }  // namespace dffw

@@ -26,7 +26,13 @@ namespace dffw {
 
 // RES: the layer adds a residual volume (its pieces are prefetched by hand, see below); costs 8 VGPRs, paid for with a
 // shallower operand pipeline so that both variants stay at two waves per SIMD
-template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES>
+// PAIR: layers with <= 8 output channels.  A plain 16-row MFMA result tile would carry 8 dead rows; instead a GEMM
+// column is a PAIR of horizontally adjacent pixels: result rows 0-7 are the 8 channels of the even pixel, rows 8-15
+// those of the odd one, and the contraction runs over the 4 input columns the pair touches (K per slice and filter
+// row = 4 x 16 = 64 = two chunks, the filter's unused corner entries are zeros): 18 chunks per 32 pixels instead of
+// 2 x 15, i.e. 1.67x fewer MFMAs.  LDS rows are stored even columns first, odd columns second, so that the 8 pairs of
+// an operand read stay on consecutive addresses; a wave's tile is 2 rows x 8 pairs.
+template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES, bool PAIR>
 __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const RollArgs t) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
@@ -36,7 +42,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
     constexpr int PLANEB = NPIECE * 1024;
     constexpr int SLOTB = PARTS * PLANEB;
     static_assert(RING >= 4 && RING <= 8, "3 slices being read + at least one being filled");
-    constexpr int MTW = TY * TX / 16 / NWAVES;            // 16-pixel operand tiles (= image rows of the column) per wave
+    constexpr int MTW = TY * TX / (PAIR ? 32 : 16) / NWAVES;   // operand tiles per wave: one 16-pixel row, or (PAIR) 2 rows x 8 pixel pairs
+    constexpr int NCH = PAIR ? 18 : 15;                      // 32-deep contraction chunks
+    static_assert(!PAIR || (MTW == 1 && FX % 2 == 0), "pair layout: one tile of two rows per wave, even row length");
     static_assert(TX == 16, "one operand tile = one 16-pixel row");
     static_assert(TY % NWAVES == 0, "rows split evenly over the waves");
     constexpr int NP = PARTS * NPIECE;                    // DMA pieces per slice
@@ -98,7 +106,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
             const int p = wave * PPW + k;
             const int part = p / NPIECE, i = p % NPIECE;
             const int ci = i * 64 + lane, pix = ci >> 1, oct = ci & 1;
-            const int fy = pix / FX, fx = pix - fy * FX;
+            const int fy = pix / FX, sx = pix - fy * FX;
+            const int fx = PAIR ? (sx < FX / 2 ? 2 * sx : 2 * (sx - FX / 2) + 1) : sx;   // PAIR: even columns first, then odd
             const int iy = c.gy0 - 1 + fy, ix = c.gx0 - 1 + fx;
             const int ch = oct * 8;
             const bool second = ch >= a.C0;
@@ -149,7 +158,17 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
         pofs[j] = (ty * FX + r) * PIXB;
         voff[j] = (ty * a.Wo + r) * (PARTS * a.Cout) + lanepart;
     }
-    const bool packed = (a.Cout == 8 && !a.outf && MTW % 2 == 0);   // two 8-channel result tiles share one epilogue
+    // PAIR: column r of the wave's tile = pair (r & 7) of row 2*wave + (r >> 3); lane group g reads input column
+    // 2*pair + 2*half + (g >> 1) (even ones in the first half of the LDS row, odd ones in the second), channel octet
+    // g & 1, and ends up with channels (g & 1)*4.. of pixel 2*pair + (g >> 1): everything below is that one pixel's
+    int prow = 0, pcol = 0;
+    if constexpr (PAIR) {
+        prow = wave * 2 + (r >> 3);
+        pcol = 2 * (r & 7) + (g >> 1);
+        pofs[0] = (prow * FX + ((g >> 1) ? FX / 2 : 0) + (r & 7)) * PIXB + (g & 1) * 16;
+        voff[0] = (prow * a.Wo + pcol) * (PARTS * 8) + ((PARTS == 2) ? (g & 1) * 8 : (g & 1) * 4);
+    }
+    const bool packed = !PAIR && (a.Cout == 8 && !a.outf && MTW % 2 == 0);   // two 8-channel result tiles share one epilogue
 
     // Ring protocol.  Window n of the stream reads slices n, n+1, n+2 (ring slots n, n+1, n+2 mod RING).  The prologue
     // queues slices 0 .. RING-2; iteration n queues slice n+RING-1 into the slot of slice n-1 (every wave left it
@@ -165,15 +184,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
     for (int q = 0; q < RING - 1; ++q) issue_next();
 
     // ---- the filter: 15 A-fragments per part, resident for the whole walk --------------------------------------
-    short8 w[15][PARTS];
+    short8 w[NCH][PARTS];
     {
         const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + lane;
 #pragma unroll
-        for (int c = 0; c < 15; ++c)
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int pt = 0; pt < PARTS; ++pt) w[c][pt] = wp[(c * PARTS + pt) * 64];
     }
-    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + (PAIR ? (g & 1) : g) * 4);
     // everything queued so far (prologue slices, filter, bias) is waited for with a compiler-visible vmcnt(0): beside
     // LDS-DMA hipcc cannot count ordinary loads and would otherwise drain the queue at the first MFMA of every step
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
 #pragma unroll
                 for (int j = 0; j < MTW; ++j) {
                     if (packed && (j & 1)) continue;
-                    const int vo = (packed && lane >= 32) ? voff[j + (packed ? 1 : 0)] - 8 : voff[j];
+                    const int vo = (packed && lane >= 32) ? voff[(j + 1) % MTW] - 8 : voff[j];
                     const uint16_t *rp = a.res0 + ubase + vo;
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[j]) : "v"(rp) : "memory");
                 }
@@ -226,24 +245,44 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
                 // reads outstanding" is exactly "chunk c has arrived"; the wait is tied to the fragment registers so the
                 // MFMAs stay behind it.
                 constexpr int RPC = MTW * PARTS;   // ds_read_b128 per chunk
-                constexpr int DEPTH = 1;
+                constexpr int DEPTH = PAIR ? 2 : 1;
                 short8 x[DEPTH + 1][MTW][PARTS];
                 auto fetch = [&](int c, short8 (&dst)[MTW][PARTS]) {
-                    const unsigned ko = lds0 + sb[c / 5] + inoff[c % 5];
+                    if constexpr (PAIR) {
+                        // chunk c = (slice c/6, filter row (c%6)/2, half c%2): a compile-time offset from the lane's base
+                        const unsigned ad = lds0 + sb[c / 6] + pofs[0];
+                        const int imm = (((c % 6) / 2) * FX + (c % 2)) * PIXB;
+                        switch (imm) {   // the offset must be an immediate: one case per (filter row, half)
+#define DFFW_PAIR_RD(I)                                                                                                  \
+    case I:                                                                                                              \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0][0]) : "v"(ad), "n"(I));                              \
+        if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0][1]) : "v"(ad), "n"(I + PLANEB)); \
+        break;
+                            DFFW_PAIR_RD(0)
+                            DFFW_PAIR_RD(PIXB)
+                            DFFW_PAIR_RD(FX * PIXB)
+                            DFFW_PAIR_RD(FX * PIXB + PIXB)
+                            DFFW_PAIR_RD(2 * FX * PIXB)
+                            DFFW_PAIR_RD(2 * FX * PIXB + PIXB)
+#undef DFFW_PAIR_RD
+                        }
+                    } else {
+                        const unsigned ko = lds0 + sb[c / 5] + inoff[c % 5];
 #pragma unroll
-                    for (int j = 0; j < MTW; ++j) {
-                        const unsigned ad = ko + pofs[j];
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[j][0]) : "v"(ad));
-                        if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(PLANEB));
+                        for (int j = 0; j < MTW; ++j) {
+                            const unsigned ad = ko + pofs[j];
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(dst[j][0]) : "v"(ad));
+                            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(PLANEB));
+                        }
                     }
                 };
 #pragma unroll
                 for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);
 #pragma unroll
-                for (int c = 0; c < 15; ++c) {
-                    if (c + DEPTH < 15) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + DEPTH < NCH) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
                     auto &xc = x[c % (DEPTH + 1)];
-                    const int ahead = (14 - c < DEPTH ? 14 - c : DEPTH) * RPC;   // compile-time after unrolling
+                    const int ahead = (NCH - 1 - c < DEPTH ? NCH - 1 - c : DEPTH) * RPC;   // compile-time after unrolling
                     if (ahead == 2 * RPC && DEPTH == 2) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(2 * RPC));
                     else if (ahead == RPC) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(RPC));
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0][0]));
@@ -277,7 +316,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
             if ((a.dbg & 4) && acc[0][0] != 12345.f) continue;
 
             // ---- epilogue of output slice zbeg + st (shared with conv_tile / conv_igemm) ----------------------------
-            if (packed) {
+            if constexpr (PAIR) {
+                // lane rows 0-1 hold the even pixel's 8 channels, rows 2-3 the odd pixel's: both are "rows g & 1" of their
+                // own pixel record, exactly the packed form of the 8-channel epilogue (no register shuffling needed)
+                const int64_t opix = obase + (int64_t)prow * a.Wo + pcol;
+                float cls = 0.f;
+                if constexpr (RES && PARTS == 2) epilogue_quad<PREC, true, true, false>(a, acc[0], 0, g & 1, opix, true, cls, make_uint4(rq[0][0], rq[0][1], rq[0][2], rq[0][3]), uint4{}, ubase, voff[0]);
+                else epilogue_quad<PREC, false, true, false>(a, acc[0], 0, g & 1, opix, true, cls, uint4{}, uint4{}, ubase, voff[0]);
+                epilogue_cls(a, cls, g, opix, true, 2);
+            } else if (packed) {
                 // 8 output channels occupy lane rows 0-1 only: rows 2-3 take rows 0-1 of the next operand tile
 #pragma unroll
                 for (int j = 0; j + 1 < MTW; j += 2) {
@@ -324,8 +371,8 @@ void roll_tile(int *ty, int *tx) {
     *tx = DFFW_ROLL_TX;
 }
 
-void conv_roll_kernel_name(int prec, bool res, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_roll<%d, %d, %d, %d, %d, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, res ? "true" : "false");
+void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll<%d, %d, %d, %d, %d, %s, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, res ? "true" : "false", pair ? "true" : "false");
 }
 
 hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
@@ -335,16 +382,22 @@ hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipS
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(DFFW_ROLL_NW * 64);
     // the hand-prefetched residual exists for the split-bf16 storage only; fp16/bf16 layers with a residual load it in the epilogue
     const bool res = a.res0 != nullptr && prec == P_BF16X3;
-#define DFFW_ROLL_LAUNCH(P, R) hipLaunchKernelGGL((conv_roll<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R>), grid, block, 0, s, a, t)
+#define DFFW_ROLL_LAUNCH(P, R, Q) hipLaunchKernelGGL((conv_roll<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R, Q>), grid, block, 0, s, a, t)
+#define DFFW_ROLL_LAUNCH_Q(P, R)        \
+    do {                                \
+        if (t.pair) DFFW_ROLL_LAUNCH(P, R, true);  \
+        else DFFW_ROLL_LAUNCH(P, R, false);        \
+    } while (0)
     switch (prec) {
         case P_BF16X3:
-            if (res) DFFW_ROLL_LAUNCH(P_BF16X3, true);
-            else DFFW_ROLL_LAUNCH(P_BF16X3, false);
+            if (res) DFFW_ROLL_LAUNCH_Q(P_BF16X3, true);
+            else DFFW_ROLL_LAUNCH_Q(P_BF16X3, false);
             break;
-        case P_FP16: DFFW_ROLL_LAUNCH(P_FP16, false); break;
-        case P_BF16: DFFW_ROLL_LAUNCH(P_BF16, false); break;
+        case P_FP16: DFFW_ROLL_LAUNCH_Q(P_FP16, false); break;
+        case P_BF16: DFFW_ROLL_LAUNCH_Q(P_BF16, false); break;
         default: return hipErrorInvalidValue;
     }
+#undef DFFW_ROLL_LAUNCH_Q
 #undef DFFW_ROLL_LAUNCH
     return hipGetLastError();
 }

@@ -301,6 +301,7 @@ struct PackedConv {
     TilePack tile;
     float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
+    bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
 
@@ -534,24 +535,37 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // K order [dz][k5][32]: chunk k5 of a slice = in-slice taps 2*k5 and 2*k5+1 (tap 9 does not exist: zero weights),
     // lane group g -> tap 2*k5 + (g >> 1), channel octet g & 1
     if (geo == G3S1 && cin_pad == 16 && pc.nt == 1 && !stem) {
-        std::vector<uint16_t> wr((size_t)ROLL_CHUNKS * parts * 512, 0);
-        for (int dz = 0; dz < 3; ++dz)
-            for (int k5 = 0; k5 < 5; ++k5)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int cout = lane & 15, gq = lane >> 4;
-                        const int tap9 = 2 * k5 + (gq >> 1), cin = (gq & 1) * 8 + j;
-                        float val = 0.f;
-                        if (cout < L.cout && tap9 < 9) {
+        pc.roll_pair = L.cout == 8 && !getenv("DFFW_NO_ROLL_PAIR");
+        const int nch = pc.roll_pair ? ROLL_CHUNKS_PAIR : ROLL_CHUNKS;
+        std::vector<uint16_t> wr((size_t)nch * parts * 512, 0);
+        for (int c = 0; c < nch; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = lane & 15, gq = lane >> 4;
+                    const int cin = (gq & 1) * 8 + j;
+                    float val = 0.f;
+                    if (!pc.roll_pair) {
+                        const int dz = c / 5, k5 = c % 5;
+                        const int tap9 = 2 * k5 + (gq >> 1);
+                        if (row < L.cout && tap9 < 9) {
                             const int ky = tap9 / 3, kx = tap9 % 3;
-                            val = (float)wval(cout, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
+                            val = (float)wval(row, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
                         }
-                        uint16_t hi, lo;
-                        host_split(prec, val, hi, lo);
-                        const size_t base = ((size_t)(dz * 5 + k5) * parts) * 512 + (size_t)lane * 8 + j;
-                        wr[base] = hi;
-                        if (parts == 2) wr[base + 512] = lo;
+                    } else {
+                        // pixel pairs: result rows 0-7 = channels of the even pixel, 8-15 = of the odd one; chunk
+                        // (dz, ky, half) contracts input columns ix = 2*half + (gq >> 1) of the 4 the pair touches:
+                        // the even pixel sees ix as filter column kx = ix, the odd pixel as kx = ix - 1
+                        const int dz = c / 6, ky = (c % 6) / 2, half = c % 2;
+                        const int ix = 2 * half + (gq >> 1);
+                        const int cout = row & 7, kx = ix - (row >> 3);
+                        if (cout < L.cout && kx >= 0 && kx <= 2) val = (float)wval(cout, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
                     }
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
         HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
@@ -873,15 +887,16 @@ struct Run {
                 { const char *z = getenv("DFFW_ROLL_ZSPLIT"); if (z && atoi(z) >= 1 && atoi(z) <= No) t.zsplit = atoi(z); }
                 t.total_tiles = in0.B * t.zsplit * cols;
                 t.wgs = 0;
+                t.pair = pc.roll_pair ? 1 : 0;
                 { const char *z = getenv("DFFW_ROLL_WGS"); if (z && atoi(z) >= 8) t.wgs = atoi(z); }
                 {
                     char kn[96];
-                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, pc.roll_pair, kn, sizeof kn);
                     g_last_kernel = kn;
                 }
                 if (e->profiling) {
                     char kn[96];
-                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, pc.roll_pair, kn, sizeof kn);
                     const double opx = (double)out.B * No * Ho * Wo;
                     const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
                                          + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
