@@ -10,6 +10,7 @@ for p in fp16 bf16; do python bench.py --precision $p --steps 5 --warmup 2 --no-
 python bench.py --batch 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline > $out/bench_b1_10x256.json 2>/dev/null
 python bench.py --batch 1 --slices 5 --size 224 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline > $out/bench_b1_5x224.json 2>/dev/null
 python bench.py --batch 8 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $out/bench_b8.json 2>/dev/null
+python bench.py --input u8 --steps 10 --warmup 3 > $out/bench_u8.json 2>/dev/null
 python bench.py --workload e2e --dump-layers $out/layers_e2e.tsv > $out/bench_e2e.json 2>/dev/null
 python bench.py --workload e2e --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > $out/bench_e2e_b1.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/rocprof_bench.json 2> $out/rocprof.err
