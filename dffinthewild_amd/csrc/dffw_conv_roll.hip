@@ -158,14 +158,19 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
         pofs[j] = (ty * FX + r) * PIXB;
         voff[j] = (ty * a.Wo + r) * (PARTS * a.Cout) + lanepart;
     }
-    // PAIR: column r of the wave's tile = pair (r & 7) of row 2*wave + (r >> 3); lane group g reads input column
+    // PAIR: column r of the wave's tile = pair pp of row 2*wave + rr; lane group g reads input column
     // 2*pair + 2*half + (g >> 1) (even ones in the first half of the LDS row, odd ones in the second), channel octet
-    // g & 1, and ends up with channels (g & 1)*4.. of pixel 2*pair + (g >> 1): everything below is that one pixel's
+    // g & 1, and ends up with channels (g & 1)*4.. of pixel 2*pair + (g >> 1): everything below is that one pixel's.
+    // The bits of r are dealt to (row, pair) so that the 16 lanes of every ds_read_b128 service group land on 16
+    // distinct 16-byte bank groups with the 576-byte row pitch (rr = r & 1, pair = r bits 2,3,1: found by enumeration;
+    // the natural r = row*8 + pair order measured 50 % of all LDS cycles as bank conflicts)
     int prow = 0, pcol = 0;
     if constexpr (PAIR) {
-        prow = wave * 2 + (r >> 3);
-        pcol = 2 * (r & 7) + (g >> 1);
-        pofs[0] = (prow * FX + ((g >> 1) ? FX / 2 : 0) + (r & 7)) * PIXB + (g & 1) * 16;
+        static_assert(FX * PIXB == 576, "the conflict-free lane order was derived for this row pitch");
+        const int rr = r & 1, pp = ((r >> 2) & 3) | (((r >> 1) & 1) << 2);
+        prow = wave * 2 + rr;
+        pcol = 2 * pp + (g >> 1);
+        pofs[0] = (prow * FX + ((g >> 1) ? FX / 2 : 0) + pp) * PIXB + (g & 1) * 16;
         voff[0] = (prow * a.Wo + pcol) * (PARTS * 8) + ((PARTS == 2) ? (g & 1) * 8 : (g & 1) * 4);
     }
     const bool packed = !PAIR && (a.Cout == 8 && !a.outf && MTW % 2 == 0);   // two 8-channel result tiles share one epilogue
