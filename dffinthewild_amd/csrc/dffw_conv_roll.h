@@ -18,6 +18,10 @@ constexpr int ROLL_CHUNKS_PAIR = 18;   // pixel-pair form: 3 slices x 3 filter r
 
 void roll_tile(int *ty, int *tx);   // column footprint of the instantiated kernel
 hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
+void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n);
+// transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
+constexpr int ROLL_CHUNKS_T = 9;
+hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_roll_t_kernel_name(int prec, bool res, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
 
 }  // namespace dffw

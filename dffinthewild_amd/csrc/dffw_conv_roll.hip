@@ -365,6 +365,253 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- conv_roll_t: the same rolling window for the transposed 3x3x3 conv (stride (1,2,2), 16 -> 8 channels: `deconv_3`,
+// `dres4.conv6`, DEN.py:41-48, 262-264) ---------------------------------------------------------------------------------
+// out[oz, 2y+py, 2x+px] = sum over the taps of sub-pixel phase (py, px) (pack_conv: phase 0 along an axis uses filter index
+// 1 at input i, phase 1 uses index 2 at input i and index 0 at input i+1).  conv_tile runs the four phases as four passes
+// with 8 dead result rows each; here the two x phases of an input column ARE the two halves of the result tile: rows 0-7 =
+// the 8 channels of output pixel 2x, rows 8-15 = of pixel 2x+1, contracting over input columns x and x+1 (32 = one chunk
+// per slice and row tap).  9 chunks per input pixel instead of 14, no dead rows, and a lane pair writes 64 contiguous bytes
+// (two adjacent output pixels), a wave 2 full rows of 1 KiB.  Two passes (py = 0, 1) per input slice, each with its own
+// epilogue.  Streaming skeleton (column stream, ring of LDS slices, counted waits, inline-asm operand reads, residual
+// prefetch) as in conv_roll above; the input footprint needs one extra row / column on the high side only.
+template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES>
+__global__ __launch_bounds__(NWAVES * 64) void conv_roll_t(const ConvArgs a, const RollArgs t) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int PIXB = 32;
+    constexpr int FY = TY + 1, FX = TX + 1, FPIX = FY * FX;
+    constexpr int NPIECE = 6;                              // 1 KiB wave instructions per plane (5 would do: 6 keeps 3 per wave)
+    static_assert(NPIECE * 64 >= FPIX * 2, "plane holds the footprint");
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    constexpr int MTW = TY / NWAVES;                       // input rows (16-column operand tiles) per wave
+    constexpr int NCH = 9;                                 // chunks: py = 0: 3 slices; py = 1: 3 slices x 2 row taps
+    static_assert(TX == 16 && TY % NWAVES == 0, "one operand tile = one 16-pixel input row");
+    constexpr int NP = PARTS * NPIECE;
+    constexpr int PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (the counted vmcnt waits rely on it)");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, zbeg, nz, gy0, gx0;
+    };
+    auto decode = [&](int u) {   // units = columns of the INPUT grid
+        Unit c;
+        const int txi = u % t.tiles_x;
+        int tt = u / t.tiles_x;
+        const int tyi = tt % t.tiles_y;
+        tt /= t.tiles_y;
+        const int zp = tt % t.zsplit;
+        c.b = tt / t.zsplit;
+        c.gy0 = tyi * TY;
+        c.gx0 = txi * TX;
+        c.zbeg = zp * a.No / t.zsplit;
+        c.nz = (zp + 1) * a.No / t.zsplit - c.zbeg;
+        return c;
+    };
+
+    const int ps0 = PARTS * a.C0;
+    const int slice_elems = a.Hi * a.Wi * ps0;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0, fslices = 0, fz0 = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+        fslices = c.nz + 2;
+        fz0 = c.zbeg - 1;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int ci = i * 64 + lane, pix = ci >> 1, oct = ci & 1;
+            const int fy = pix / FX, fx = pix - fy * FX;
+            const int iy = c.gy0 + fy, ix = c.gx0 + fx;          // halo on the high side only
+            fok[k] = p < NP && pix < FPIX && iy < a.Hi && ix < a.Wi;
+            const uint16_t *sp = a.in0 + (int64_t)c.b * a.Ni * slice_elems;
+            fsrc[k] = sp + (int64_t)(iy * a.Wi + ix) * ps0 + part * a.C0 + oct * 8;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const int iz = fz0 + fq;
+        const bool zin = (unsigned)iz < (unsigned)a.Ni && fu < uend;
+        unsigned char *slot = smem + fslot * SLOTB;
+        const int64_t zo = (int64_t)iz * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RING) ? 0 : fslot + 1;
+        if (++fq == fslices && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // operand addressing: row j of this wave, input column r + (g >> 1), channel octet g & 1; the lane ends up with
+    // channels (g & 1)*4.. of output pixel (2*row + py, 2*r + (g >> 1))
+    int pofs[MTW], voff[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int ty = wave * MTW + j;
+        pofs[j] = (ty * FX + r + (g >> 1)) * PIXB + (g & 1) * 16;
+        voff[j] = (2 * ty * a.Wo + 2 * r + (g >> 1)) * (PARTS * 8) + ((PARTS == 2) ? (g & 1) * 8 : (g & 1) * 4);
+    }
+    const int rowstep = a.Wo * (PARTS * 8);   // elements from output row 2*ty to 2*ty + 1
+
+    constexpr int INFLIGHT = RES ? (RING > 4 ? PPW : 0) : (RING - 4) * PPW;
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) issue_next();
+
+    short8 w[NCH][PARTS];
+    {
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) w[c][pt] = wp[(c * PARTS + pt) * 64];
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + (g & 1) * 4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    int sidx = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        const int64_t obase0 = (((int64_t)U.b * a.No + U.zbeg) * a.Ho + 2 * U.gy0) * a.Wo + 2 * U.gx0;
+        for (int st = 0; st < U.nz + 2; ++st) {
+            const bool live = st < U.nz;
+            const int64_t obase = obase0 + (int64_t)st * a.Ho * a.Wo;
+            const int64_t ubase = obase * (PARTS * 8);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 rq[RES ? 2 * MTW : 1];
+            if constexpr (RES && PARTS == 2) {
+#pragma unroll
+                for (int k = 0; k < 2 * MTW; ++k) rq[k] = u32x4{0, 0, 0, 0};
+            }
+            if (RES && live && PARTS == 2) {
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        const uint16_t *rp = a.res0 + ubase + voff[j] + py * rowstep;
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[py * MTW + j]) : "v"(rp) : "memory");
+                    }
+            }
+            if (!(a.dbg & 1)) issue_next();
+
+            f32x4 acc[2][MTW];
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) acc[py][j] = bias4;
+            if (live && !(a.dbg & 2)) {
+                int sb[3];
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    int sl = sidx + dz;
+                    if (sl >= RING) sl -= RING;
+                    sb[dz] = sl * SLOTB;
+                }
+                constexpr int RPC = MTW * PARTS;
+                constexpr int DEPTH = 2;
+                short8 x[DEPTH + 1][MTW][PARTS];
+                // chunk c: c < 3: py = 0, slice c, input row y; c >= 3: py = 1, slice (c-3)/2, input row y + (c-3)%2
+                auto fetch = [&](int c, short8 (&dst)[MTW][PARTS]) {
+                    const int dz = c < 3 ? c : (c - 3) / 2;
+                    const bool down = c >= 3 && ((c - 3) & 1);
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        const unsigned ad = lds0 + sb[dz] + pofs[j];
+                        if (!down) {
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(dst[j][0]) : "v"(ad));
+                            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(PLANEB));
+                        } else {
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][0]) : "v"(ad), "n"(FX * PIXB));
+                            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(FX * PIXB + PLANEB));
+                        }
+                    }
+                };
+#pragma unroll
+                for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + DEPTH < NCH) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
+                    auto &xc = x[c % (DEPTH + 1)];
+                    const int ahead = (NCH - 1 - c < DEPTH ? NCH - 1 - c : DEPTH) * RPC;
+                    if (ahead == 2 * RPC) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(2 * RPC));
+                    else if (ahead == RPC) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(RPC));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0][0]));
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt)
+                            if (j + pt) asm volatile("" : "+v"(xc[j][pt]));
+                    const int py = c < 3 ? 0 : 1;
+                    if constexpr (PARTS == 2) {
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) acc[py][j] = mma<F16>(w[c][1], xc[j][0], acc[py][j]);
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) acc[py][j] = mma<F16>(w[c][0], xc[j][1], acc[py][j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) acc[py][j] = mma<F16>(w[c][0], xc[j][0], acc[py][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            if constexpr (RES && PARTS == 2) {
+#pragma unroll
+                for (int k = 0; k < 2 * MTW; ++k) asm volatile("" : "+v"(rq[k]));
+            }
+            sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
+            if (!live) continue;
+            if ((a.dbg & 4) && acc[0][0][0] != 12345.f) continue;
+
+            // ---- epilogues: output rows 2*row (py = 0) and 2*row + 1 (py = 1); lane rows 0-1 = pixel 2*r, rows 2-3 = pixel 2*r + 1
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    const int ty = wave * MTW + j;
+                    const int64_t opix = obase + (int64_t)(2 * ty + py) * a.Wo + 2 * r + (g >> 1);
+                    const int vo = voff[j] + py * rowstep;
+                    float cls = 0.f;
+                    if constexpr (RES && PARTS == 2) {
+                        const u32x4 q = rq[py * MTW + j];
+                        epilogue_quad<PREC, true, true, false>(a, acc[py][j], 0, g & 1, opix, true, cls, make_uint4(q[0], q[1], q[2], q[3]), uint4{}, ubase, vo);
+                    } else {
+                        epilogue_quad<PREC, false, true, false>(a, acc[py][j], 0, g & 1, opix, true, cls, uint4{}, uint4{}, ubase, vo);
+                    }
+                    epilogue_cls(a, cls, g, opix, true, 2);
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 #define DFFW_ROLL_TY 8
 #define DFFW_ROLL_TX 16
@@ -378,6 +625,29 @@ void roll_tile(int *ty, int *tx) {
 
 void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n) {
     snprintf(buf, n, "dffw::conv_roll<%d, %d, %d, %d, %d, %s, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, res ? "true" : "false", pair ? "true" : "false");
+}
+
+void conv_roll_t_kernel_name(int prec, bool res, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll_t<%d, %d, %d, %d, %d, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, res ? "true" : "false");
+}
+
+hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    const int want = t.wgs > 0 ? t.wgs : 512;
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(DFFW_ROLL_NW * 64);
+    const bool res = a.res0 != nullptr && prec == P_BF16X3;
+#define DFFW_ROLLT_LAUNCH(P, R) hipLaunchKernelGGL((conv_roll_t<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R>), grid, block, 0, s, a, t)
+    switch (prec) {
+        case P_BF16X3:
+            if (res) DFFW_ROLLT_LAUNCH(P_BF16X3, true);
+            else DFFW_ROLLT_LAUNCH(P_BF16X3, false);
+            break;
+        case P_FP16: DFFW_ROLLT_LAUNCH(P_FP16, false); break;
+        case P_BF16: DFFW_ROLLT_LAUNCH(P_BF16, false); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_ROLLT_LAUNCH
+    return hipGetLastError();
 }
 
 hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {

@@ -302,6 +302,7 @@ struct PackedConv {
     float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
+    uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
 
@@ -324,6 +325,8 @@ static void free_packed(PackedConv &pc) {
     pc.w32 = nullptr;
     if (pc.wroll) (void)hipFree(pc.wroll);
     pc.wroll = nullptr;
+    if (pc.wroll_t) (void)hipFree(pc.wroll_t);
+    pc.wroll_t = nullptr;
 }
 
 // weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
@@ -568,6 +571,35 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 }
         HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- conv_roll_t: transposed 3x3x3 s(1,2,2), 16 -> 8 channels.  Result rows 0-7 = output pixel 2x, rows 8-15 = pixel
+    // 2x+1; chunk c < 3: output row phase py = 0 (filter row 1 at input row y), slice c of the window; c >= 3: py = 1,
+    // slice (c-3)/2, filter row 2 at input row y ((c-3) even) or filter row 0 at input row y+1 (odd).  Lane group g
+    // contracts input column x + (g >> 1), channel octet g & 1: pixel 2x sees only column x (filter column 1), pixel 2x+1
+    // sees column x (filter column 2) and column x+1 (filter column 0).  Window slice d is input slice oz-1+d = filter slice 2-d.
+    if (geo == G3T && cin_pad == 16 && L.cout == 8 && !getenv("DFFW_NO_ROLL_T")) {
+        std::vector<uint16_t> wr((size_t)ROLL_CHUNKS_T * parts * 512, 0);
+        for (int c = 0; c < ROLL_CHUNKS_T; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = lane & 15, gq = lane >> 4;
+                    const int cout = row & 7, px = row >> 3, dx = gq >> 1, cin = (gq & 1) * 8 + j;
+                    const int d = c < 3 ? c : (c - 3) / 2;
+                    const bool down = c >= 3 && ((c - 3) & 1);
+                    const int ky = c < 3 ? 1 : (down ? 0 : 2), dy = down ? 1 : 0;
+                    int kx = -1;
+                    if (px == 0 && dx == 0) kx = 1;
+                    if (px == 1) kx = dx == 0 ? 2 : 0;
+                    float val = 0.f;
+                    if (kx >= 0) val = (float)wval(cout, cin, Tap{d - 1, dy, dx, 2 - d, ky, kx});
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wroll_t, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wroll_t, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     return DFFW_OK;
 }
@@ -867,6 +899,42 @@ struct Run {
         a.zero = e->zero_page;
         { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 7) : 0; }
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
+        // ... and its transposed sibling (16 -> 8 channels), tiled over the input grid
+        {
+            int rty, rtx;
+            roll_tile(&rty, &rtx);
+            const int cols = (in0.H / rty) * (in0.W / rtx);
+            if (pc.wroll_t && in0.H % rty == 0 && in0.W % rtx == 0 && in0.C == 16 && !o.in1 && !o.res_bcast && !o.res1 && !o.outf &&
+                (int64_t)in0.B * cols >= 256 && !getenv_flag("DFFW_NO_ROLL")) {
+                if (dry) return out;
+                a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
+                a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
+                RollArgs t;
+                t.wroll = pc.wroll_t;
+                t.tiles_y = in0.H / rty;
+                t.tiles_x = in0.W / rtx;
+                t.zsplit = ((int64_t)in0.B * cols < 1024 && No >= 8) ? 2 : 1;
+                { const char *z = getenv("DFFW_ROLL_ZSPLIT"); if (z && atoi(z) >= 1 && atoi(z) <= No) t.zsplit = atoi(z); }
+                t.total_tiles = in0.B * t.zsplit * cols;
+                t.wgs = 0;
+                { const char *z = getenv("DFFW_ROLL_WGS"); if (z && atoi(z) >= 8) t.wgs = atoi(z); }
+                t.pair = 1;
+                char kn[96];
+                conv_roll_t_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                g_last_kernel = kn;
+                if (e->profiling) {
+                    const double opx = (double)out.B * No * Ho * Wo;
+                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
+                                         + opx * L.cout * elem_bytes() * ((o.discard ? 0 : 1) + (o.out_pre ? 1 : 0))
+                                         + opx * L.cout * elem_bytes() * (o.res0 ? 1 : 0) + (o.cls ? opx * 4.0 : 0.0)
+                                         + 27.0 * L.cin * L.cout * elem_bytes();
+                    prof_begin(kn, name, 2.0 * (double)a.M * 27.0 * L.cin * L.cout, bytes);
+                }
+                check(launch_conv_roll_t(e->prec, a, t, s), name.c_str());
+                prof_end();
+                return out;
+            }
+        }
         const TilePack &tp = pc.tile;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
         // rolling-window kernel: 16-channel 3x3x3 stride-1 layers whose grid is whole columns and fills the chip

@@ -102,6 +102,34 @@ def test_conv_roll_rolling_window(eng, cout, N, H, W, zsplit, residual, wgs, pre
     assert rel(alt, ref) <= TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("N,H,W,zsplit,residual,wgs", [(10, 64, 256, 1, True, 0), (5, 128, 128, 1, False, 16), (1, 64, 256, 1, True, 8),
+                                                        (7, 64, 256, 3, False, 24), (2, 128, 128, 2, True, 0)])
+def test_conv_roll_transposed(eng, N, H, W, zsplit, residual, wgs, prec, monkeypatch):
+    """conv_roll_t: ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1), 16 -> 8 channels (`deconv_3`, `dres4.conv6`, DEN.py:41-48) as a
+    rolling window over the input slices with the two x phases of an input column in the two halves of the result tile;
+    + BN + residual + ReLU, every slice count incl. 1 and 2, split slice ranges, short and long column streams.  The same
+    case with DFFW_NO_ROLL=1 takes conv_tile's 4-pass form and must agree with the reference operator as well."""
+    B, cin, cout = 2, 16, 8
+    x = rnd(B, cin, N, H, W, seed=31)
+    w = rnd(cin, cout, 3, 3, 3, seed=32, scale=(2.0 / (cin * 27)) ** 0.5 * 3)
+    bn = bn_params(cout, 33)
+    res = rnd(B, cout, N, 2 * H, 2 * W, seed=34) if residual else None
+    ref = ref_bn(F.conv_transpose3d(x, w, None, (1, 2, 2), 1, (0, 1, 1)), bn)
+    ref = F.relu(ref + res) if residual else F.relu(ref)
+    monkeypatch.setenv("DFFW_ROLL_ZSPLIT", str(zsplit))
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_t<"), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL[prec], rel(got, ref)
+    monkeypatch.setenv("DFFW_NO_ROLL", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(alt, ref) <= TOL[prec]
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16"])
 @pytest.mark.parametrize("cin,cout,N,H,W", [(16, 8, 3, 8, 8), (64, 32, 2, 8, 16), (128, 64, 2, 4, 4), (32, 32, 1, 8, 8)])
 def test_transposed_conv_phases(eng, cin, cout, N, H, W, prec):
