@@ -17,6 +17,7 @@
 
 #include "../../include/dffw.h"
 #include "dffw_conv_roll.h"
+#include "dffw_srd_roll.h"
 #include "dffw_conv_tile.h"
 #include "dffw_internal.h"
 
@@ -303,6 +304,7 @@ struct PackedConv {
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
+    uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
 
@@ -327,6 +329,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll = nullptr;
     if (pc.wroll_t) (void)hipFree(pc.wroll_t);
     pc.wroll_t = nullptr;
+    if (pc.wsrd) (void)hipFree(pc.wsrd);
+    pc.wsrd = nullptr;
 }
 
 // weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
@@ -571,6 +575,24 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 }
         HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- srd_roll: the per-slice 1x3x3 8 -> 8 convs of the fused SRD block; chunk k, K octet g = filter tap 4k+g ----------
+    if (geo == G2S1 && cin_pad == 8 && L.cout == 8 && !shortcut_w) {
+        std::vector<uint16_t> wr((size_t)SRD_CHUNKS * parts * 512, 0);
+        for (int c = 0; c < SRD_CHUNKS; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = lane & 15, tap = 4 * c + (lane >> 4);
+                    float val = 0.f;
+                    if (row < L.cout && tap < 9) val = (float)wval(row, j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- conv_roll_t: transposed 3x3x3 s(1,2,2), 16 -> 8 channels.  Result rows 0-7 = output pixel 2x, rows 8-15 = pixel
     // 2x+1; chunk c < 3: output row phase py = 0 (filter row 1 at input row y), slice c of the window; c >= 3: py = 1,
@@ -1182,6 +1204,45 @@ struct Run {
 // pooled (optional): receives max_pool(1,2,2) of the block's output when the fused attention kernel can produce it
 // on the way (else it is left empty and the caller pools separately).
 static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = nullptr) {
+    // the 8-channel block on whole 8 x 16 columns: one fused persistent kernel (dffw_srd_roll.hip)
+    {
+        auto c0 = r.e->convs.find(p + ".Focus_Measure.conv.0.0"), c2 = r.e->convs.find(p + ".Focus_Measure.conv.2.0");
+        auto a3 = r.e->convs.find(p + ".N_ch_attention.0"), a1 = r.e->convs.find(p + ".N_ch_attention.2");
+        int sty, stx;
+        srd_roll_tile(&sty, &stx);
+        const auto end = r.e->convs.end();
+        if (x.C == 8 && c0 != end && c2 != end && a3 != end && a1 != end && c0->second.wsrd && c2->second.wsrd && a3->second.w32 &&
+            a1->second.w32 && x.H % sty == 0 && x.W % stx == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= 256 &&
+            !getenv_flag("DFFW_NO_FUSED_SRD") && !getenv_flag("DFFW_NO_FUSED_ATTENTION") && !getenv_flag("DFFW_NO_TILE")) {
+            Act out = r.act(x.B, x.N, x.H, x.W, x.C);
+            const bool with_pool = pooled && !getenv_flag("DFFW_NO_FUSED_POOL");
+            if (with_pool) *pooled = r.act(x.B, x.N, x.H / 2, x.W / 2, x.C);
+            if (r.ok() && !r.dry) {
+                if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return out; }
+                SrdArgs a;
+                memset(&a, 0, sizeof a);
+                a.x = x.p; a.out = out.p; a.pooled = with_pool ? pooled->p : nullptr;
+                a.w0 = c0->second.wsrd; a.w2 = c2->second.wsrd;
+                a.b0 = c0->second.bias; a.b2 = c2->second.bias;
+                a.w3 = a3->second.w32; a.w1 = a1->second.w32;
+                a.zero = r.e->zero_page;
+                a.B = x.B; a.N = x.N; a.H = x.H; a.W = x.W;
+                a.tiles_y = x.H / sty; a.tiles_x = x.W / stx;
+                a.total_tiles = x.B * a.tiles_y * a.tiles_x;
+                { const char *z = getenv("DFFW_SRD_WGS"); a.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                char kn[64];
+                srd_roll_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
+                g_last_kernel = kn;
+                const double px = (double)x.pixels();
+                // algorithmic: two 1x3x3 8 -> 8 convs + the 3x1x1 and 1x1x1 attention convs; x read once, out (+ pooled) written once
+                r.prof_begin(kn, p, 2.0 * px * (2 * 9 * 8 * 8 + 4 * 8 * 8), (with_pool ? 2.25 : 2.0) * px * x.C * r.elem_bytes());
+                r.check(launch_srd_roll(r.e->prec, a, r.s), "srd_roll");
+                r.prof_end();
+            }
+            if (drop_x) r.drop(x);
+            return out;
+        }
+    }
     ConvOpt o1; o1.relu = 1;
     Act t = r.conv(p + ".Focus_Measure.conv.0.0", x, o1);
     ConvOpt o2; o2.relu = 1; o2.res0 = &x;

@@ -1,0 +1,25 @@
+// srd_roll (fused SRD block of the 8-channel full-resolution stage, dffw_srd_roll.hip): host/device declarations.
+#pragma once
+#include "dffw_internal.h"
+
+namespace dffw {
+
+struct SrdArgs {
+    const uint16_t *x;        // block input (B,N,H,W,8) in storage format
+    uint16_t *out;            // block output, same shape
+    uint16_t *pooled;         // (B,N,H/2,W/2,8) max-pool (1,2,2) of out, or null
+    const uint16_t *w0, *w2;  // conv.0 / conv.2 filters as MFMA A-fragments [3 chunks][part][64 lanes][8] (chunk k, K octet g = tap 4k+g)
+    const float *b0, *b2;     // their BatchNorm shifts (>= 16 floats, zero padded)
+    const float *w3, *w1;     // attention weights fp32 [kz][ci][co] and [ci][co]
+    const uint16_t *zero;     // >= 16 zero bytes (out-of-image LDS-DMA lanes)
+    int B, N, H, W;
+    int tiles_y, tiles_x, total_tiles;   // 8 x 16 columns per sample, B * tiles_y * tiles_x
+    int wgs;                  // workgroups to launch (0: three per CU)
+};
+
+constexpr int SRD_CHUNKS = 3;
+void srd_roll_tile(int *ty, int *tx);
+hipError_t launch_srd_roll(int prec, const SrdArgs &a, hipStream_t s);
+void srd_roll_kernel_name(int prec, bool pool, char *buf, int n);
+
+}  // namespace dffw

@@ -1,0 +1,357 @@
+// srd_roll: the whole SRD block of the 8-channel full-resolution stage (DEN.py:317-330 with resnet_block_2d :295-304,
+// `FM_measure.Focus_extraction.2`) in ONE persistent kernel.
+//
+//     t    = relu(BN(conv1x3x3(x)))                       per slice          (Focus_Measure.conv.0)
+//     feat = relu(x + BN(conv1x3x3(t)))                   per slice          (Focus_Measure.conv.2)
+//     out  = feat + relu(conv1x1x1(relu(conv3x1x1(feat))))  across slices    (N_ch_attention.0 / .2, no BN, no bias)
+//     pooled = maxpool(1,2,2)(out)                        (what the following EFD block reads, DEN.py:310)
+//
+// As three launches every stage is a full pass over the 8-channel volume bound by HBM: x is read twice, t and feat are
+// written and read back (7 volume passes, 4.7 GB at batch 32).  Here a workgroup owns a column of 8 x 16 pixels of one
+// sample and walks its slices; t and feat never leave LDS:
+//   * x slices (12 x 20 footprint: two 3x3 halos) stream through a FIFO of LDS slots by LDS-DMA, several slices ahead
+//     (counted vmcnt, raw s_barrier, as in conv_roll);
+//   * stage A: conv.0 on the 10 x 18 region conv.2 needs -> t as hi/lo records in LDS (zero outside the image: it is
+//     conv.2's padding);  stage B: conv.2 + x + ReLU on the 8 x 16 pixels -> feat in fp32 in a ring of 3 LDS slices;
+//     both on the matrix cores with the two filters (2 x 3 chunks) resident in registers;
+//   * stage C (one slice behind): the attention over feat[z-1], feat[z], feat[z+1] in exact fp32 on the VALU (same
+//     operation order as srd_attention_kernel), result split to the storage format and stored, 2x2 max over DPP quads
+//     for the pooled copy.
+// HBM traffic: x once (halo from L2), out once, pooled once.  feat stays fp32 between stage B and C (the three-launch
+// form rounds it to the storage format in between), t is rounded to hi+lo exactly as before.
+#include <algorithm>
+#include <cstdio>
+
+#include "dffw_device.h"
+#include "dffw_srd_roll.h"
+
+namespace dffw {
+
+template <int PREC, bool POOL>
+__global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const float *__restrict__ w3g, const float *__restrict__ w1g) {
+    // (w3g / w1g = a.w3 / a.w1 as separate read-only parameters: only then does hipcc fetch the attention weights with
+    // scalar loads; through the struct it used vector loads inside the loop, and beside LDS-DMA every use of a vector
+    // load drains the whole DMA queue.  For the same reason the LDS stores below are inline asm: hipcc puts a
+    // vmcnt(0) in front of every ordinary ds_write while an LDS-DMA is in flight.)
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int C = 8, TY = 8, TX = 16, NWAVES = 4;
+    constexpr int XY = TY + 4, XX = TX + 4, XPIX = XY * XX;        // x footprint
+    constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;    // region of t that conv.2 needs
+    constexpr int PIXB = C * 2;                                    // bytes per pixel per plane
+    constexpr int NPIECE = (XPIX + 63) / 64;                       // 1 KiB wave instructions per plane (one 16-byte chunk per pixel)
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    constexpr int RX = 4;                                          // x FIFO depth
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (counted vmcnt waits)");
+    constexpr int TPLANEB = (TPIX * PIXB + 15) / 16 * 16;
+    constexpr int FSLOTB = TY * TX * C * 4;                        // one slice of feat, fp32
+    constexpr int X_OFF = 0, T_OFF = RX * SLOTB, F_OFF = T_OFF + PARTS * TPLANEB;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[F_OFF + 3 * FSLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto lds_store8 = [&](unsigned byte_off, uint32_t v0, uint32_t v1) {
+        const u32x2 d = {v0, v1};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(lds0 + byte_off), "v"(d) : "memory");
+    };
+    auto lds_store16 = [&](unsigned byte_off, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + byte_off), "v"(v) : "memory"); };
+
+    // ---- columns of this workgroup: as conv_roll (XCD-contiguous ranges, round-robin inside the XCD) ----------------
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+
+    // ---- x FIFO: the slices of the workgroup's columns as one stream (N per column) ---------------------------------
+    const int rec = PARTS * C;                                     // 16-bit elements per pixel record
+    const int slice_elems = a.H * a.W * rec;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int pix = i * 64 + lane;
+            const int fy = pix / XX, fx = pix - fy * XX;
+            const int iy = c.gy0 - 2 + fy, ix = c.gx0 - 2 + fx;
+            fok[k] = p < NP && pix < XPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            fsrc[k] = a.x + (int64_t)c.b * a.N * slice_elems + (int64_t)(iy * a.W + ix) * rec + part * C;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const bool zin = fu < uend;
+        unsigned char *slot = smem + X_OFF + fslot * SLOTB;
+        const int64_t zo = (int64_t)fq * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RX) ? 0 : fslot + 1;
+        if (++fq == a.N && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // ---- per-lane constants ------------------------------------------------------------------------------------------
+    // stage A: wave w computes t pixels [w*48, w*48+48) of the 180 (12 operand tiles, the last one partly idle)
+    constexpr int TA = 3;   // tiles per wave
+    int pa[TA], ta_y[TA], ta_x[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        int p = (wave * TA + j) * 16 + r;
+        if (p >= TPIX) p = TPIX - 1;   // idle columns recompute the last pixel, nothing is stored for them
+        ta_y[j] = p / TXT;
+        ta_x[j] = p - ta_y[j] * TXT;
+        pa[j] = (ta_y[j] * XX + ta_x[j]) * PIXB;
+    }
+    // K octet g of chunk k = filter tap 4k+g (taps 9..11 carry zero weights: any valid address)
+    int tapA[3], tapB[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int tap = 4 * k + g;
+        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
+        tapA[k] = (dy * XX + dx) * PIXB;
+        tapB[k] = (dy * TXT + dx) * PIXB;
+    }
+    // stage B: wave w computes rows 2w, 2w+1 of the 8 x 16 pixels
+    constexpr int TB = 2;
+    // the two filters as MFMA A-fragments (3 chunks each) and their BatchNorm shifts
+    short8 w0[3][PARTS], w2[3][PARTS];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) {
+            w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
+            w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
+        }
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);   // zero padded to 16 channels
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
+
+    constexpr int INFLIGHT = (RX - 2) * PPW;   // slices that may stay in flight when the next one is needed
+#pragma unroll
+    for (int q = 0; q < RX - 1; ++q) issue_next();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // compiler-visible vmcnt(0): filters, shifts and the first slices
+    asm volatile("s_barrier" ::: "memory");
+
+    int xslot = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        for (int s = 0; s <= a.N; ++s) {
+            const bool produce = s < a.N;
+            const unsigned fslot_off = F_OFF + (s % 3) * FSLOTB;
+            if (produce) {
+                // (1) this step's x slice has landed (for every wave after the barrier); the previous step's stage C is done
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+                const unsigned char *xs = smem + X_OFF + xslot * SLOTB;
+                if (s == 0) {   // feat[-1] = 0 (padding of the conv over slices): ring slot 2
+                    lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+                // (2) stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image
+#pragma unroll
+                for (int j = 0; j < TA; ++j) {
+                    f32x4 acc = b0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const unsigned char *lp = xs + pa[j] + tapA[k];
+                        const short8 xh = *reinterpret_cast<const short8 *>(lp);
+                        if constexpr (PARTS == 2) {
+                            const short8 xl = *reinterpret_cast<const short8 *>(lp + PLANEB);
+                            acc = mma<F16>(w0[k][1], xh, acc);
+                            acc = mma<F16>(w0[k][0], xl, acc);
+                        }
+                        acc = mma<F16>(w0[k][0], xh, acc);
+                    }
+                    const int p = (wave * TA + j) * 16 + r;
+                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
+                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    if (g < 2 && p < TPIX) {
+                        uint32_t h01, h23, l01, l23;
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                        const unsigned tp = T_OFF + p * PIXB + g * 8;
+                        lds_store8(tp, h01, h23);
+                        if constexpr (PARTS == 2) lds_store8(tp + TPLANEB, l01, l23);
+                    }
+                }
+                // (3) t complete
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // (4) stage B: feat = relu(conv.2(t) + shift + x)
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    const int fy = wave * TB + j;
+                    f32x4 acc = b2;
+                    const unsigned char *tb = smem + T_OFF + (fy * TXT + r) * PIXB;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const unsigned char *lp = tb + tapB[k];
+                        const short8 th = *reinterpret_cast<const short8 *>(lp);
+                        if constexpr (PARTS == 2) {
+                            const short8 tl = *reinterpret_cast<const short8 *>(lp + TPLANEB);
+                            acc = mma<F16>(w2[k][1], th, acc);
+                            acc = mma<F16>(w2[k][0], tl, acc);
+                        }
+                        acc = mma<F16>(w2[k][0], th, acc);
+                    }
+                    if (g < 2) {
+                        // (inline asm: hipcc waits vmcnt(0) before an ordinary read of a DMA-filled slot here)
+                        const unsigned xp = lds0 + X_OFF + xslot * SLOTB + ((fy + 2) * XX + r + 2) * PIXB + g * 8;
+                        u32x2 xh, xl = {0u, 0u};
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
+                        if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
+                        float r0, r1, r2, r3;
+                        Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
+                        Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
+                        f32x4 v;
+                        v[0] = relu_bits(acc[0] + r0);
+                        v[1] = relu_bits(acc[1] + r1);
+                        v[2] = relu_bits(acc[2] + r2);
+                        v[3] = relu_bits(acc[3] + r3);
+                        lds_store16(fslot_off + ((fy * TX + r) * C + g * 4) * 4, v);
+                    }
+                }
+                // (5) feat[s] complete, the x slot is free: queue the slice RX-1 ahead into it
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_next();
+                xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
+            } else {
+                // s == N: feat[N] = 0
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            // (7) stage C: attention for slice z = s-1 out of feat[z-1], feat[z], feat[z+1]
+            if (s >= 1 && tid < TY * TX) {
+                const int z = s - 1;
+                const int q = tid >> 2, qx = q % (TX / 2), qy = q / (TX / 2);
+                const int fy = 2 * qy + ((tid >> 1) & 1), fx = 2 * qx + (tid & 1);
+                const int po = (fy * TX + fx) * C;
+                const float *fpv = reinterpret_cast<const float *>(smem + F_OFF + ((z + 2) % 3) * FSLOTB) + po;   // feat[z-1]
+                const float *fcv = reinterpret_cast<const float *>(smem + F_OFF + (z % 3) * FSLOTB) + po;
+                const float *fnv = reinterpret_cast<const float *>(smem + F_OFF + ((z + 1) % 3) * FSLOTB) + po;
+                float fp[C], fc[C], fn[C];
+#pragma unroll
+                for (int c4 = 0; c4 < C; c4 += 4) {
+                    const f32x4 p4 = *reinterpret_cast<const f32x4 *>(fpv + c4), c4v = *reinterpret_cast<const f32x4 *>(fcv + c4),
+                                n4 = *reinterpret_cast<const f32x4 *>(fnv + c4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        fp[c4 + i] = p4[i];
+                        fc[c4 + i] = c4v[i];
+                        fn[c4 + i] = n4[i];
+                    }
+                }
+                float at[C];
+#pragma unroll
+                for (int co = 0; co < C; ++co) at[co] = 0.f;
+#pragma unroll
+                for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+                    for (int co = 0; co < C; ++co) {
+                        at[co] = fmaf(w3g[(0 * C + ci) * C + co], fp[ci], at[co]);
+                        at[co] = fmaf(w3g[(1 * C + ci) * C + co], fc[ci], at[co]);
+                        at[co] = fmaf(w3g[(2 * C + ci) * C + co], fn[ci], at[co]);
+                    }
+                float o[C];
+#pragma unroll
+                for (int co = 0; co < C; ++co) o[co] = 0.f;
+#pragma unroll
+                for (int ci = 0; ci < C; ++ci) {
+                    const float rr = fmaxf(at[ci], 0.f);
+#pragma unroll
+                    for (int co = 0; co < C; ++co) o[co] = fmaf(w1g[ci * C + co], rr, o[co]);
+                }
+                const int64_t pix = (((int64_t)U.b * a.N + z) * a.H + U.gy0 + fy) * a.W + U.gx0 + fx;
+                uint16_t *wptr = a.out + pix * rec;
+                short8 h, l, ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    uint16_t hi, lo;
+                    Fmt<PREC>::split(fc[j] + fmaxf(o[j], 0.f), hi, lo);
+                    h[j] = (short)hi;
+                    l[j] = (short)lo;
+                    if constexpr (POOL) {   // max over the 2x2 quad of the value as stored
+                        float m = Fmt<PREC>::join(hi, lo);
+                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));
+                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));
+                        Fmt<PREC>::split(m, hi, lo);
+                        ph[j] = (short)hi;
+                        pl[j] = (short)lo;
+                    }
+                }
+                *reinterpret_cast<short8 *>(wptr) = h;
+                if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(wptr + C) = l;
+                if constexpr (POOL) {
+                    if ((tid & 3) == 0) {
+                        const int64_t pp = (((int64_t)U.b * a.N + z) * (a.H / 2) + (U.gy0 / 2 + qy)) * (a.W / 2) + U.gx0 / 2 + qx;
+                        uint16_t *pw = a.pooled + pp * rec;
+                        *reinterpret_cast<short8 *>(pw) = ph;
+                        if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(pw + C) = pl;
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
+}
+
+void srd_roll_tile(int *ty, int *tx) {
+    *ty = 8;
+    *tx = 16;
+}
+
+void srd_roll_kernel_name(int prec, bool pool, char *buf, int n) { snprintf(buf, n, "dffw::srd_roll_kernel<%d, %s>", prec, pool ? "true" : "false"); }
+
+hipError_t launch_srd_roll(int prec, const SrdArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : 768;   // three resident workgroups per CU
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+#define DFFW_SRD_LAUNCH(P)                                                                    \
+    do {                                                                                      \
+        if (a.pooled) hipLaunchKernelGGL((srd_roll_kernel<P, true>), grid, block, 0, s, a, a.w3, a.w1);   \
+        else hipLaunchKernelGGL((srd_roll_kernel<P, false>), grid, block, 0, s, a, a.w3, a.w1);           \
+    } while (0)
+    switch (prec) {
+        case P_BF16X3: DFFW_SRD_LAUNCH(P_BF16X3); break;
+        case P_FP16: DFFW_SRD_LAUNCH(P_FP16); break;
+        case P_BF16: DFFW_SRD_LAUNCH(P_BF16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_SRD_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace dffw

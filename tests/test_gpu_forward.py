@@ -100,6 +100,35 @@ def test_oracle_parity_fresh_inputs_and_batch_independence(lib_built):
     assert cpu_ref.rel_l2(single[3].cpu(), got[3][2:].cpu()) <= 1e-6     # batch independent (bitwise in practice)
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 3, 128, 256, 16), (3, 1, 128, 128, 0), (2, 2, 96, 288, 8)])
+def test_fused_srd_block_matches_three_launch_form(lib_built, B, N, H, W, wgs, prec, monkeypatch):
+    """srd_roll (dffw_srd_roll.hip): conv.0 -> conv.2 (+x) -> attention over slices -> (1,2,2) max-pool of the 8-channel
+    block (DEN.py:317-330) in one persistent kernel, against the three-launch form (conv_tile x 2 + srd_attention_kernel)
+    on the same input: V1 (the block's output) and V2 (fed by the pooled copy) taps.  Every slice count incl. 1 and 2,
+    non-square maps, one column per workgroup and long column streams, all three arithmetics.  The two forms round `feat`
+    differently (fp32 in LDS vs storage format in HBM), hence a tolerance instead of bit equality."""
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 3, "smooth").items()}
+    model = model_for(sd, (3, "smooth"), prec)
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=77)).cuda()
+    fd = torch.from_numpy(synth.focus_dists(B, N, 1, 1)).cuda()
+    if wgs:
+        monkeypatch.setenv("DFFW_SRD_WGS", str(wgs))
+    from dffinthewild_amd import engine
+    with torch.no_grad():
+        outs, taps = model.forward_with_taps(FS, fd, ["V1", "V2"])
+        monkeypatch.setenv("DFFW_NO_FUSED_SRD", "1")
+        outs2, taps2 = model.forward_with_taps(FS, fd, ["V1", "V2"])
+    tol = {"bf16x3": 2e-5, "fp16": 3e-3, "bf16": 3e-2}[prec]
+    for nm in ("V1", "V2"):
+        assert cpu_ref.rel_l2(taps[nm].cpu(), taps2[nm].cpu()) <= tol, (nm, cpu_ref.rel_l2(taps[nm].cpu(), taps2[nm].cpu()))
+    if prec == "bf16x3":
+        with torch.no_grad():
+            ref = cpu_ref.dff_forward(sd, FS.cpu(), fd.cpu())
+        assert cpu_ref.rel_l2(outs[3].cpu(), ref[3]) <= 1e-3
+
+
 def test_reference_call_sequence_dataparallel(lib_built):
     """test.py:30-32,78-86,115-119 verbatim sequence against the drop-in."""
     import torch.nn as nn
@@ -141,7 +170,7 @@ def test_full_size_properties(lib_built):
 
 
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_STREAM", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
-                                 "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK"])
+                                 "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback
