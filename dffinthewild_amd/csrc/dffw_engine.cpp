@@ -576,15 +576,18 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    // ---- srd_roll: the per-slice 1x3x3 8 -> 8 convs of the fused SRD block; chunk k, K octet g = filter tap 4k+g ----------
+    // ---- srd_roll: the per-slice 1x3x3 8 -> 8 convs of the fused SRD block, in pixel-pair form: chunk = filter row ky;
+    // result rows 0-7 = channels of the even pixel of a pair, rows 8-15 = of the odd one; K octet g = input column 2*pair + g,
+    // which the even pixel sees as filter column g and the odd pixel as filter column g - 1
     if (geo == G2S1 && cin_pad == 8 && L.cout == 8 && !shortcut_w) {
         std::vector<uint16_t> wr((size_t)SRD_CHUNKS * parts * 512, 0);
         for (int c = 0; c < SRD_CHUNKS; ++c)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                    const int row = lane & 15, tap = 4 * c + (lane >> 4);
+                    const int row = lane & 15, gq = lane >> 4;
+                    const int cout = row & 7, kx = gq - (row >> 3);
                     float val = 0.f;
-                    if (row < L.cout && tap < 9) val = (float)wval(row, j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                    if (kx >= 0 && kx <= 2) val = (float)wval(cout, j, Tap{0, c - 1, kx - 1, 0, c, kx});
                     uint16_t hi, lo;
                     host_split(prec, val, hi, lo);
                     const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;

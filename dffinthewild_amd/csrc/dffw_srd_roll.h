@@ -8,7 +8,7 @@ struct SrdArgs {
     const uint16_t *x;        // block input (B,N,H,W,8) in storage format
     uint16_t *out;            // block output, same shape
     uint16_t *pooled;         // (B,N,H/2,W/2,8) max-pool (1,2,2) of out, or null
-    const uint16_t *w0, *w2;  // conv.0 / conv.2 filters as MFMA A-fragments [3 chunks][part][64 lanes][8] (chunk k, K octet g = tap 4k+g)
+    const uint16_t *w0, *w2;  // conv.0 / conv.2 filters as MFMA A-fragments [3 chunks][part][64 lanes][8] in pixel-pair form (chunk = filter row, pack_conv)
     const float *b0, *b2;     // their BatchNorm shifts (>= 16 floats, zero padded)
     const float *w3, *w1;     // attention weights fp32 [kz][ci][co] and [ci][co]
     const uint16_t *zero;     // >= 16 zero bytes (out-of-image LDS-DMA lanes)

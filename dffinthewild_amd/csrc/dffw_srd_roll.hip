@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
             const int p = wave * PPW + k;
             const int part = p / NPIECE, i = p % NPIECE;
             const int pix = i * 64 + lane;
-            const int fy = pix / XX, fx = pix - fy * XX;
+            const int fy = pix / XX, sx = pix - fy * XX;
+            const int fx = sx < XX / 2 ? 2 * sx : 2 * (sx - XX / 2) + 1;   // LDS rows hold the even columns first, then the odd ones
             const int iy = c.gy0 - 2 + fy, ix = c.gx0 - 2 + fx;
             fok[k] = p < NP && pix < XPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             fsrc[k] = a.x + (int64_t)c.b * a.N * slice_elems + (int64_t)(iy * a.W + ix) * rec + part * C;
@@ -126,28 +127,34 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
     };
 
     // ---- per-lane constants ------------------------------------------------------------------------------------------
-    // stage A: wave w computes t pixels [w*48, w*48+48) of the 180 (12 operand tiles, the last one partly idle)
-    constexpr int TA = 3;   // tiles per wave
-    int pa[TA], ta_y[TA], ta_x[TA];
+    // Both convs have 8 output channels: a GEMM column is a PAIR of horizontally adjacent pixels (result rows 0-7 = even
+    // pixel, 8-15 = odd pixel) contracting per filter row over the 4 input columns the pair touches (4 x 8 channels = one
+    // 32-deep chunk; K octet g = input column 2*pair + g), as in conv_roll's pair form: no dead rows, half the tiles.
+    // LDS rows (x and t) keep the even columns first, then the odd ones, so the pairs of a tile read consecutive 16-byte slots.
+    // stage A: the 10 x 18 t pixels are 90 pairs = 6 operand tiles (the last one partly idle): waves 2, 3 take two tiles
+    // each, waves 0, 1 one each (those two waves also run stage C of an earlier slice in the same phase)
+    constexpr int TA = 2;
+    const int nA = wave < 2 ? 1 : 2;
+    constexpr int APAIRS = TYT * (TXT / 2);
+    int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
+    bool ta_ok[TA];
 #pragma unroll
     for (int j = 0; j < TA; ++j) {
-        int p = (wave * TA + j) * 16 + r;
-        if (p >= TPIX) p = TPIX - 1;   // idle columns recompute the last pixel, nothing is stored for them
-        ta_y[j] = p / TXT;
-        ta_x[j] = p - ta_y[j] * TXT;
-        pa[j] = (ta_y[j] * XX + ta_x[j]) * PIXB;
+        const int tile = wave < 2 ? 4 + wave : (wave - 2) * 2 + j;
+        int pi = tile * 16 + r;
+        ta_ok[j] = pi < APAIRS;
+        if (pi >= APAIRS) pi = APAIRS - 1;   // idle columns recompute the last pair, nothing is stored for them
+        const int row = pi / (TXT / 2), pc = pi - row * (TXT / 2);
+        ta_y[j] = row;
+        ta_x[j] = 2 * pc + (g >> 1);        // the t pixel this lane ends up with (channels (g & 1)*4 ..)
+        pa[j] = (row * XX + ((g & 1) ? XX / 2 : 0) + pc + (g >> 1)) * PIXB;   // input column 2*pc + g of row `row`
+        ta_st[j] = T_OFF + (row * TXT + ((g >> 1) ? TXT / 2 : 0) + pc) * PIXB + (g & 1) * 8;
     }
-    // K octet g of chunk k = filter tap 4k+g (taps 9..11 carry zero weights: any valid address)
-    int tapA[3], tapB[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int tap = 4 * k + g;
-        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
-        tapA[k] = (dy * XX + dx) * PIXB;
-        tapB[k] = (dy * TXT + dx) * PIXB;
-    }
-    // stage B: wave w computes rows 2w, 2w+1 of the 8 x 16 pixels
-    constexpr int TB = 2;
+    // stage B: the 8 x 16 feat pixels are 64 pairs = 4 tiles, one per wave
+    const int pb_pi = wave * 16 + r, pb_y = pb_pi / (TX / 2), pb_pc = pb_pi % (TX / 2), pb_x = 2 * pb_pc + (g >> 1);
+    const int pbo = (pb_y * TXT + ((g & 1) ? TXT / 2 : 0) + pb_pc + (g >> 1)) * PIXB;
+    const int pb_res = ((pb_y + 2) * XX + (((pb_x + 2) & 1) ? XX / 2 : 0) + ((pb_x + 2) >> 1)) * PIXB + (g & 1) * 8;
+    const int pb_st = ((pb_y * TX + pb_x) * C + (g & 1) * 4) * 4;
     // the two filters as MFMA A-fragments (3 chunks each) and their BatchNorm shifts
     short8 w0[3][PARTS], w2[3][PARTS];
 #pragma unroll
@@ -157,8 +164,32 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
             w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
             w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
         }
-    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);   // zero padded to 16 channels
-    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + (g & 1) * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + (g & 1) * 4);
+    // one operand tile: 3 chunks (filter rows) x hi/lo, read by inline asm (hipcc degrades every lgkmcnt wait to 0 and adds
+    // vmcnt(0) in front of reads of DMA-filled slots while an LDS-DMA is outstanding) and contracted as they arrive
+    auto tile_mma = [&](unsigned base, int rowB, int loB, const short8 (&wf)[3][PARTS], f32x4 acc) {
+        short8 xh[3], xl[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned ad = base + k * rowB;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
+            else xl[k] = xh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xh[0]), "+v"(xl[0]) : "n"(2 * PARTS));
+            else if (k == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xh[1]), "+v"(xl[1]) : "n"(PARTS));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[2]), "+v"(xl[2]));
+            if constexpr (PARTS == 2) {
+                acc = mma<F16>(wf[k][1], xh[k], acc);
+                acc = mma<F16>(wf[k][0], xl[k], acc);
+            }
+            acc = mma<F16>(wf[k][0], xh[k], acc);
+        }
+        return acc;
+    };
 
     constexpr int INFLIGHT = (RX - 2) * PPW;   // slices that may stay in flight when the next one is needed
 #pragma unroll
@@ -169,93 +200,20 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
     int xslot = 0;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
-        for (int s = 0; s <= a.N; ++s) {
+        // Step s of a column: phase 1 = stage A of slice s (t = conv.0) on waves 2-3 (mostly) NEXT TO stage C of slice s-2
+        // (attention out of feat[s-3..s-1]) on waves 0-1; phase 2 = stage B of slice s (feat[s] = conv.2 + x) on all
+        // waves.  feat lives in a ring of 3 fp32 slices: stage B(s) overwrites the slot stage C(s-2) read last.
+        for (int s = 0; s <= a.N + 1; ++s) {
             const bool produce = s < a.N;
             const unsigned fslot_off = F_OFF + (s % 3) * FSLOTB;
-            if (produce) {
-                // (1) this step's x slice has landed (for every wave after the barrier); the previous step's stage C is done
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
-                const unsigned char *xs = smem + X_OFF + xslot * SLOTB;
-                if (s == 0) {   // feat[-1] = 0 (padding of the conv over slices): ring slot 2
-                    lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
-                }
-                // (2) stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image
-#pragma unroll
-                for (int j = 0; j < TA; ++j) {
-                    f32x4 acc = b0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const unsigned char *lp = xs + pa[j] + tapA[k];
-                        const short8 xh = *reinterpret_cast<const short8 *>(lp);
-                        if constexpr (PARTS == 2) {
-                            const short8 xl = *reinterpret_cast<const short8 *>(lp + PLANEB);
-                            acc = mma<F16>(w0[k][1], xh, acc);
-                            acc = mma<F16>(w0[k][0], xl, acc);
-                        }
-                        acc = mma<F16>(w0[k][0], xh, acc);
-                    }
-                    const int p = (wave * TA + j) * 16 + r;
-                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
-                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                    if (g < 2 && p < TPIX) {
-                        uint32_t h01, h23, l01, l23;
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
-                        const unsigned tp = T_OFF + p * PIXB + g * 8;
-                        lds_store8(tp, h01, h23);
-                        if constexpr (PARTS == 2) lds_store8(tp + TPLANEB, l01, l23);
-                    }
-                }
-                // (3) t complete
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                // (4) stage B: feat = relu(conv.2(t) + shift + x)
-#pragma unroll
-                for (int j = 0; j < TB; ++j) {
-                    const int fy = wave * TB + j;
-                    f32x4 acc = b2;
-                    const unsigned char *tb = smem + T_OFF + (fy * TXT + r) * PIXB;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const unsigned char *lp = tb + tapB[k];
-                        const short8 th = *reinterpret_cast<const short8 *>(lp);
-                        if constexpr (PARTS == 2) {
-                            const short8 tl = *reinterpret_cast<const short8 *>(lp + TPLANEB);
-                            acc = mma<F16>(w2[k][1], th, acc);
-                            acc = mma<F16>(w2[k][0], tl, acc);
-                        }
-                        acc = mma<F16>(w2[k][0], th, acc);
-                    }
-                    if (g < 2) {
-                        // (inline asm: hipcc waits vmcnt(0) before an ordinary read of a DMA-filled slot here)
-                        const unsigned xp = lds0 + X_OFF + xslot * SLOTB + ((fy + 2) * XX + r + 2) * PIXB + g * 8;
-                        u32x2 xh, xl = {0u, 0u};
-                        asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
-                        if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
-                        float r0, r1, r2, r3;
-                        Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
-                        Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
-                        f32x4 v;
-                        v[0] = relu_bits(acc[0] + r0);
-                        v[1] = relu_bits(acc[1] + r1);
-                        v[2] = relu_bits(acc[2] + r2);
-                        v[3] = relu_bits(acc[3] + r3);
-                        lds_store16(fslot_off + ((fy * TX + r) * C + g * 4) * 4, v);
-                    }
-                }
-                // (5) feat[s] complete, the x slot is free: queue the slice RX-1 ahead into it
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                issue_next();
-                xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
-            } else {
-                // s == N: feat[N] = 0
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            // (7) stage C: attention for slice z = s-1 out of feat[z-1], feat[z], feat[z+1]
-            if (s >= 1 && tid < TY * TX) {
-                const int z = s - 1;
+            // (1) this step's x slice has landed (for every wave after the barrier); feat[s-1] is complete
+            if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s == 0) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[-1] = 0: ring slot 2
+
+            // ---- stage C (waves 0-1): attention for slice z = s-2 out of feat[z-1], feat[z], feat[z+1] ------------------
+            if (s >= 2 && tid < TY * TX) {
+                const int z = s - 2;
                 const int q = tid >> 2, qx = q % (TX / 2), qy = q / (TX / 2);
                 const int fy = 2 * qy + ((tid >> 1) & 1), fx = 2 * qx + (tid & 1);
                 const int po = (fy * TX + fx) * C;
@@ -322,6 +280,51 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
                         if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(pw + C) = pl;
                     }
                 }
+            }
+            // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ---------------------
+            if (produce) {
+#pragma unroll
+                for (int j = 0; j < TA; ++j) {
+                    if (j >= nA) break;
+                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], XX * PIXB, PLANEB, w0, b0);
+                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
+                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    if (ta_ok[j]) {
+                        uint32_t h01, h23, l01, l23;
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                        lds_store8(ta_st[j], h01, h23);
+                        if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
+                    }
+                }
+            }
+            // (2) t complete, stage C has read its three feat slices
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (produce) {
+                // ---- stage B: feat[s] = relu(conv.2(t) + shift + x) ----------------------------------------------------
+                {
+                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
+                    const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
+                    u32x2 xh, xl = {0u, 0u};
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
+                    if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
+                    float r0, r1, r2, r3;
+                    Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
+                    Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
+                    f32x4 v;
+                    v[0] = relu_bits(acc[0] + r0);
+                    v[1] = relu_bits(acc[1] + r1);
+                    v[2] = relu_bits(acc[2] + r2);
+                    v[3] = relu_bits(acc[3] + r3);
+                    lds_store16(fslot_off + pb_st, v);
+                }
+                // (3) feat[s] complete for everyone's reads of x: the x slot is free, queue the slice RX-1 ahead into it
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_next();
+                xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
+            } else if (s == a.N) {
+                lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[N] = 0
             }
         }
     }
