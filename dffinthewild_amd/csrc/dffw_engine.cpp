@@ -305,6 +305,7 @@ struct PackedConv {
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
+    uint16_t *watt = nullptr;      // device: an 8 -> 8 attention conv (3x1x1 or 1x1x1) as srd_roll's stage-C fragments
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
 
@@ -331,6 +332,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll_t = nullptr;
     if (pc.wsrd) (void)hipFree(pc.wsrd);
     pc.wsrd = nullptr;
+    if (pc.watt) (void)hipFree(pc.watt);
+    pc.watt = nullptr;
 }
 
 // weight: PyTorch layout.  bn: gamma|beta|mean|var (4*cout) or null.  conv_bias: cout or null.
@@ -575,6 +578,40 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 }
         HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- srd_roll stage C: the attention convs of the 8-channel SRD block (DEN.py:322-323) in pixel-pair form.  Result row
+    // m = (pixel m >> 3 of the pair, channel m & 7).  3x1x1: chunk 0 K octet g = (pixel g >> 1, slice g & 1), chunk 1 even g =
+    // (pixel g >> 1, slice 2).  1x1x1: K octet g = (pixel g >> 1, input channels 4*(g & 1)..+3 as [hi x4 | lo x4] of the split
+    // operand): fragment 0 carries w_hi against both halves (w_hi*a_hi + w_hi*a_lo), fragment 1 w_lo against the hi half.
+    if (!L.transposed && L.kh == 1 && L.kw == 1 && L.cin == 8 && L.cout == 8 && !bn && !conv_bias) {
+        const int nfrag = L.kd == 3 ? 2 * parts : parts;
+        std::vector<uint16_t> wr((size_t)nfrag * 512, 0);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int row = lane & 15, gq = lane >> 4, px = row >> 3, co = row & 7;
+                const bool mine = (gq >> 1) == px;
+                if (L.kd == 3) {
+                    for (int c = 0; c < 2; ++c) {
+                        const int sl = c == 0 ? (gq & 1) : ((gq & 1) == 0 ? 2 : -1);
+                        const float val = (mine && sl >= 0) ? (float)wval(co, j, Tap{0, 0, 0, sl, 0, 0}) : 0.f;
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        wr[((size_t)c * parts) * 512 + lane * 8 + j] = hi;
+                        if (parts == 2) wr[((size_t)c * parts + 1) * 512 + lane * 8 + j] = lo;
+                    }
+                } else if (L.kd == 1) {
+                    const int ci = 4 * (gq & 1) + (j & 3);
+                    const float val = mine ? (float)wval(co, ci, Tap{0, 0, 0, 0, 0, 0}) : 0.f;
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    wr[(size_t)lane * 8 + j] = hi;
+                    if (parts == 2 && j < 4) wr[512 + (size_t)lane * 8 + j] = lo;
+                }
+            }
+        if (L.kd == 3 || L.kd == 1) {
+            HIPCHK(hipMalloc((void **)&pc.watt, wr.size() * sizeof(uint16_t)));
+            HIPCHK(hipMemcpy(pc.watt, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
     }
     // ---- srd_roll: the per-slice 1x3x3 8 -> 8 convs of the fused SRD block, in pixel-pair form: chunk = filter row ky;
     // result rows 0-7 = channels of the even pixel of a pair, rows 8-15 = of the odd one; K octet g = input column 2*pair + g,
@@ -1215,7 +1252,7 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
         srd_roll_tile(&sty, &stx);
         const auto end = r.e->convs.end();
         if (x.C == 8 && c0 != end && c2 != end && a3 != end && a1 != end && c0->second.wsrd && c2->second.wsrd && a3->second.w32 &&
-            a1->second.w32 && x.H % sty == 0 && x.W % stx == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= 256 &&
+            a1->second.w32 && a3->second.watt && a1->second.watt && a3->second.def.kd == 3 && a1->second.def.kd == 1 && x.H % sty == 0 && x.W % stx == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= 256 &&
             !getenv_flag("DFFW_NO_FUSED_SRD") && !getenv_flag("DFFW_NO_FUSED_ATTENTION") && !getenv_flag("DFFW_NO_TILE")) {
             Act out = r.act(x.B, x.N, x.H, x.W, x.C);
             const bool with_pool = pooled && !getenv_flag("DFFW_NO_FUSED_POOL");
@@ -1228,6 +1265,7 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
                 a.w0 = c0->second.wsrd; a.w2 = c2->second.wsrd;
                 a.b0 = c0->second.bias; a.b2 = c2->second.bias;
                 a.w3 = a3->second.w32; a.w1 = a1->second.w32;
+                a.w3f = a3->second.watt; a.w1f = a1->second.watt;
                 a.zero = r.e->zero_page;
                 a.B = x.B; a.N = x.N; a.H = x.H; a.W = x.W;
                 a.tiles_y = x.H / sty; a.tiles_x = x.W / stx;

@@ -10,7 +10,8 @@ struct SrdArgs {
     uint16_t *pooled;         // (B,N,H/2,W/2,8) max-pool (1,2,2) of out, or null
     const uint16_t *w0, *w2;  // conv.0 / conv.2 filters as MFMA A-fragments [3 chunks][part][64 lanes][8] in pixel-pair form (chunk = filter row, pack_conv)
     const float *b0, *b2;     // their BatchNorm shifts (>= 16 floats, zero padded)
-    const float *w3, *w1;     // attention weights fp32 [kz][ci][co] and [ci][co]
+    const float *w3, *w1;     // attention weights fp32 [kz][ci][co] and [ci][co] (unused by the MFMA form, kept for reference)
+    const uint16_t *w3f, *w1f;   // the same as MFMA A-fragments: conv3x1x1 [2 chunks][part][64][8], conv1x1x1 [part][64][8] (pack_conv)
     const uint16_t *zero;     // >= 16 zero bytes (out-of-image LDS-DMA lanes)
     int B, N, H, W;
     int tiles_y, tiles_x, total_tiles;   // 8 x 16 columns per sample, B * tiles_y * tiles_x

@@ -14,11 +14,14 @@
 //   * stage A: conv.0 on the 10 x 18 region conv.2 needs -> t as hi/lo records in LDS (zero outside the image: it is
 //     conv.2's padding);  stage B: conv.2 + x + ReLU on the 8 x 16 pixels -> feat in fp32 in a ring of 3 LDS slices;
 //     both on the matrix cores with the two filters (2 x 3 chunks) resident in registers;
-//   * stage C (one slice behind): the attention over feat[z-1], feat[z], feat[z+1] in exact fp32 on the VALU (same
-//     operation order as srd_attention_kernel), result split to the storage format and stored, 2x2 max over DPP quads
-//     for the pooled copy.
-// HBM traffic: x once (halo from L2), out once, pooled once.  feat stays fp32 between stage B and C (the three-launch
-// form rounds it to the storage format in between), t is rounded to hi+lo exactly as before.
+//   * stage C (two slices behind): the attention over feat[z-1], feat[z], feat[z+1] on the matrix cores as well (as 256
+//     fp32 FMAs per pixel on the VALU it was the longest phase of a step): conv3x1x1 = 2 chunks over (pixel of the pair,
+//     slice); its ReLU'd result, split to hi/lo in registers, IS the operand block of conv1x1x1 (K octet = the lane's own
+//     4 channels hi | lo, filter rows [w_hi w_hi] and [w_lo 0]: two MFMAs, no data movement); + feat[z] (kept in fp32
+//     registers by the lane that produced it), split to the storage format, stored; 2x2 max via DPP / permlane for the
+//     pooled copy.
+// HBM traffic: x once (halo from L2), out once, pooled once.  t and feat are rounded to hi+lo (the storage format) as
+// operands, exactly as in the three-launch form.
 #include <algorithm>
 #include <cstdio>
 
@@ -28,7 +31,7 @@
 namespace dffw {
 
 template <int PREC, bool POOL>
-__global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const float *__restrict__ w3g, const float *__restrict__ w1g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void srd_roll_kernel(const SrdArgs a, const float *__restrict__ w3g, const float *__restrict__ w1g) {
     // (w3g / w1g = a.w3 / a.w1 as separate read-only parameters: only then does hipcc fetch the attention weights with
     // scalar loads; through the struct it used vector loads inside the loop, and beside LDS-DMA every use of a vector
     // load drains the whole DMA queue.  For the same reason the LDS stores below are inline asm: hipcc puts a
@@ -46,7 +49,8 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
     constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
     static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (counted vmcnt waits)");
     constexpr int TPLANEB = (TPIX * PIXB + 15) / 16 * 16;
-    constexpr int FSLOTB = TY * TX * C * 4;                        // one slice of feat, fp32
+    constexpr int FPLANEB = TY * TX * PIXB;                        // one slice of feat as records (even pixels of a row first)
+    constexpr int FSLOTB = PARTS * FPLANEB;
     constexpr int X_OFF = 0, T_OFF = RX * SLOTB, F_OFF = T_OFF + PARTS * TPLANEB;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[F_OFF + 3 * FSLOTB];
 
@@ -134,13 +138,13 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
     // stage A: the 10 x 18 t pixels are 90 pairs = 6 operand tiles (the last one partly idle): waves 2, 3 take two tiles
     // each, waves 0, 1 one each (those two waves also run stage C of an earlier slice in the same phase)
     constexpr int TA = 2;
-    const int nA = wave < 2 ? 1 : 2;
+    const int nA = wave < 2 ? 2 : 1;
     constexpr int APAIRS = TYT * (TXT / 2);
     int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
     bool ta_ok[TA];
 #pragma unroll
     for (int j = 0; j < TA; ++j) {
-        const int tile = wave < 2 ? 4 + wave : (wave - 2) * 2 + j;
+        const int tile = j == 0 ? wave : 4 + wave;
         int pi = tile * 16 + r;
         ta_ok[j] = pi < APAIRS;
         if (pi >= APAIRS) pi = APAIRS - 1;   // idle columns recompute the last pair, nothing is stored for them
@@ -154,7 +158,15 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
     const int pb_pi = wave * 16 + r, pb_y = pb_pi / (TX / 2), pb_pc = pb_pi % (TX / 2), pb_x = 2 * pb_pc + (g >> 1);
     const int pbo = (pb_y * TXT + ((g & 1) ? TXT / 2 : 0) + pb_pc + (g >> 1)) * PIXB;
     const int pb_res = ((pb_y + 2) * XX + (((pb_x + 2) & 1) ? XX / 2 : 0) + ((pb_x + 2) >> 1)) * PIXB + (g & 1) * 8;
-    const int pb_st = ((pb_y * TX + pb_x) * C + (g & 1) * 4) * 4;
+    const int pb_f = (pb_y * TX + (g >> 1) * (TX / 2) + pb_pc) * PIXB;   // the lane's pixel inside a feat plane
+    // attention filters as MFMA A-fragments (pack_conv): conv3x1x1 = 2 chunks, conv1x1x1 = [w_hi w_hi] and [w_lo 0]
+    short8 w3f[2][PARTS], w1f[PARTS];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) w3f[k][pt] = reinterpret_cast<const short8 *>(a.w3f)[(k * PARTS + pt) * 64 + lane];
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) w1f[pt] = reinterpret_cast<const short8 *>(a.w1f)[pt * 64 + lane];
     // the two filters as MFMA A-fragments (3 chunks each) and their BatchNorm shifts
     short8 w0[3][PARTS], w2[3][PARTS];
 #pragma unroll
@@ -198,6 +210,7 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
     asm volatile("s_barrier" ::: "memory");
 
     int xslot = 0;
+    f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         // Step s of a column: phase 1 = stage A of slice s (t = conv.0) on waves 2-3 (mostly) NEXT TO stage C of slice s-2
@@ -209,76 +222,79 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
             // (1) this step's x slice has landed (for every wave after the barrier); feat[s-1] is complete
             if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (s == 0) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[-1] = 0: ring slot 2
+            if (s == 0 && tid * 16 < FSLOTB) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[-1] = 0: ring slot 2
 
-            // ---- stage C (waves 0-1): attention for slice z = s-2 out of feat[z-1], feat[z], feat[z+1] ------------------
-            if (s >= 2 && tid < TY * TX) {
+            // ---- stage C: attention for slice z = s-2 out of feat[z-1], feat[z], feat[z+1]; wave w = pairs of rows 2w, 2w+1 ----
+            if (s >= 2) {
                 const int z = s - 2;
-                const int q = tid >> 2, qx = q % (TX / 2), qy = q / (TX / 2);
-                const int fy = 2 * qy + ((tid >> 1) & 1), fx = 2 * qx + (tid & 1);
-                const int po = (fy * TX + fx) * C;
-                const float *fpv = reinterpret_cast<const float *>(smem + F_OFF + ((z + 2) % 3) * FSLOTB) + po;   // feat[z-1]
-                const float *fcv = reinterpret_cast<const float *>(smem + F_OFF + (z % 3) * FSLOTB) + po;
-                const float *fnv = reinterpret_cast<const float *>(smem + F_OFF + ((z + 1) % 3) * FSLOTB) + po;
-                float fp[C], fc[C], fn[C];
+                const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
+                // chunk 0: K octet g = (pixel g >> 1 of the pair, slice z-1 + (g & 1)); chunk 1: (pixel g >> 1, slice z+1) for even g
+                const unsigned ad0 = lds0 + ((g & 1) ? sc : sm) + pb_f, ad1 = lds0 + sp + pb_f;
+                short8 fh0, fl0, fh1, fl1;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fh0) : "v"(ad0));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fh1) : "v"(ad1));
+                if constexpr (PARTS == 2) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl0) : "v"(ad0), "n"(FPLANEB));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl1) : "v"(ad1), "n"(FPLANEB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1), "+v"(fl0), "+v"(fl1));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1));
+                }
+                f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (PARTS == 2) {
+                    at = mma<F16>(w3f[0][1], fh0, at);
+                    at = mma<F16>(w3f[0][0], fl0, at);
+                    at = mma<F16>(w3f[1][1], fh1, at);
+                    at = mma<F16>(w3f[1][0], fl1, at);
+                }
+                at = mma<F16>(w3f[0][0], fh0, at);
+                at = mma<F16>(w3f[1][0], fh1, at);
+                // ReLU, split: {hi of the lane's 4 channels | lo of them} is the lane's K octet of the 1x1x1 conv
+                uint32_t ah01, ah23, al01, al23;
+                Fmt<PREC>::split2(relu_bits(at[0]), relu_bits(at[1]), ah01, al01);
+                Fmt<PREC>::split2(relu_bits(at[2]), relu_bits(at[3]), ah23, al23);
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                const u32x4v bq = {ah01, ah23, al01, al23};
+                const short8 b2op = __builtin_bit_cast(short8, bq);
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (PARTS == 2) o = mma<F16>(w1f[1], b2op, o);
+                o = mma<F16>(w1f[0], b2op, o);
+                f32x4 v;
 #pragma unroll
-                for (int c4 = 0; c4 < C; c4 += 4) {
-                    const f32x4 p4 = *reinterpret_cast<const f32x4 *>(fpv + c4), c4v = *reinterpret_cast<const f32x4 *>(fcv + c4),
-                                n4 = *reinterpret_cast<const f32x4 *>(fnv + c4);
+                for (int i = 0; i < 4; ++i) v[i] = vq1[i] + relu_bits(o[i]);
+                uint32_t h01, h23, l01, l23;
+                Fmt<PREC>::split2(v[0], v[1], h01, l01);
+                Fmt<PREC>::split2(v[2], v[3], h23, l23);
+                const int64_t pix = (((int64_t)U.b * a.N + z) * a.H + U.gy0 + pb_y) * a.W + U.gx0 + pb_x;
+                if constexpr (POOL) {   // max over the 2x2 block of the values as stored: other pixel of the pair = lane rows g ^ 2, other row = column r ^ 8
+                    float m[4];
+                    Fmt<PREC>::join2(h01, l01, m[0], m[1]);
+                    Fmt<PREC>::join2(h23, l23, m[2], m[3]);
+                    uint32_t ph01, ph23, pl01, pl23;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        fp[c4 + i] = p4[i];
-                        fc[c4 + i] = c4v[i];
-                        fn[c4 + i] = n4[i];
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[i]), __float_as_uint(m[i]), false, false);
+                        m[i] = fmaxf(m[i], __uint_as_float(lane < 32 ? sw[1] : sw[0]));
+                        m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m[i]), 0x128, 0xF, 0xF, true)));   // row_ror:8
+                    }
+                    Fmt<PREC>::split2(m[0], m[1], ph01, pl01);
+                    Fmt<PREC>::split2(m[2], m[3], ph23, pl23);
+                    if constexpr (PARTS == 2) {
+                        swap16(ph01, pl01);
+                        swap16(ph23, pl23);
+                    }
+                    if (g < 2 && r < 8) {
+                        const int64_t pp = (((int64_t)U.b * a.N + z) * (a.H / 2) + (U.gy0 / 2 + wave)) * (a.W / 2) + U.gx0 / 2 + pb_pc;
+                        if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(a.pooled + pp * rec + (g & 1) * C) = make_uint4(ph01, ph23, pl01, pl23);
+                        else *reinterpret_cast<uint2 *>(a.pooled + pp * rec + (g & 1) * 4) = make_uint2(ph01, ph23);
                     }
                 }
-                float at[C];
-#pragma unroll
-                for (int co = 0; co < C; ++co) at[co] = 0.f;
-#pragma unroll
-                for (int ci = 0; ci < C; ++ci)
-#pragma unroll
-                    for (int co = 0; co < C; ++co) {
-                        at[co] = fmaf(w3g[(0 * C + ci) * C + co], fp[ci], at[co]);
-                        at[co] = fmaf(w3g[(1 * C + ci) * C + co], fc[ci], at[co]);
-                        at[co] = fmaf(w3g[(2 * C + ci) * C + co], fn[ci], at[co]);
-                    }
-                float o[C];
-#pragma unroll
-                for (int co = 0; co < C; ++co) o[co] = 0.f;
-#pragma unroll
-                for (int ci = 0; ci < C; ++ci) {
-                    const float rr = fmaxf(at[ci], 0.f);
-#pragma unroll
-                    for (int co = 0; co < C; ++co) o[co] = fmaf(w1g[ci * C + co], rr, o[co]);
-                }
-                const int64_t pix = (((int64_t)U.b * a.N + z) * a.H + U.gy0 + fy) * a.W + U.gx0 + fx;
-                uint16_t *wptr = a.out + pix * rec;
-                short8 h, l, ph, pl;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    uint16_t hi, lo;
-                    Fmt<PREC>::split(fc[j] + fmaxf(o[j], 0.f), hi, lo);
-                    h[j] = (short)hi;
-                    l[j] = (short)lo;
-                    if constexpr (POOL) {   // max over the 2x2 quad of the value as stored
-                        float m = Fmt<PREC>::join(hi, lo);
-                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0xB1, 0xF, 0xF, true)));
-                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m), 0x4E, 0xF, 0xF, true)));
-                        Fmt<PREC>::split(m, hi, lo);
-                        ph[j] = (short)hi;
-                        pl[j] = (short)lo;
-                    }
-                }
-                *reinterpret_cast<short8 *>(wptr) = h;
-                if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(wptr + C) = l;
-                if constexpr (POOL) {
-                    if ((tid & 3) == 0) {
-                        const int64_t pp = (((int64_t)U.b * a.N + z) * (a.H / 2) + (U.gy0 / 2 + qy)) * (a.W / 2) + U.gx0 / 2 + qx;
-                        uint16_t *pw = a.pooled + pp * rec;
-                        *reinterpret_cast<short8 *>(pw) = ph;
-                        if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(pw + C) = pl;
-                    }
+                if constexpr (PARTS == 2) {
+                    swap16(h01, l01);
+                    swap16(h23, l23);
+                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C) = make_uint4(h01, h23, l01, l23);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out + pix * rec + (g & 1) * 4) = make_uint2(h01, h23);
                 }
             }
             // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ---------------------
@@ -317,14 +333,23 @@ __global__ __launch_bounds__(256) void srd_roll_kernel(const SrdArgs a, const fl
                     v[1] = relu_bits(acc[1] + r1);
                     v[2] = relu_bits(acc[2] + r2);
                     v[3] = relu_bits(acc[3] + r3);
-                    lds_store16(fslot_off + pb_st, v);
+                    uint32_t fh01, fh23, fl01, fl23;
+                    Fmt<PREC>::split2(v[0], v[1], fh01, fl01);
+                    Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
+                    lds_store8(fslot_off + pb_f + (g & 1) * 8, fh01, fh23);
+                    if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + (g & 1) * 8, fl01, fl23);
+                    vq1 = vq0;   // fp32 feat of this lane's pixel / channels, two steps deep: stage C adds it back
+                    vq0 = v;
                 }
                 // (3) feat[s] complete for everyone's reads of x: the x slot is free, queue the slice RX-1 ahead into it
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue_next();
                 xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
-            } else if (s == a.N) {
-                lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[N] = 0
+            } else {
+                vq1 = vq0;
+            }
+            if (s == a.N) {
+                if (tid * 16 < FSLOTB) lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[N] = 0
             }
         }
     }
