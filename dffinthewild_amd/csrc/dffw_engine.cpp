@@ -613,6 +613,53 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
             HIPCHK(hipMemcpy(pc.watt, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
     }
+    // the same for the 16-channel block (srd_roll16, no pixel pairs: result row = channel).  3x1x1: chunk 0 K octet g =
+    // (slice g >> 1, channel octet g & 1), chunk 1 g < 2 = (slice 2, octet g).  1x1x1: K octet g = input channels 4g..4g+3 as
+    // [hi x4 | lo x4]; fragment 0 = w_hi against both halves, fragment 1 = w_lo against the hi half.
+    if (!L.transposed && L.kh == 1 && L.kw == 1 && L.cin == 16 && L.cout == 16 && !bn && !conv_bias && (L.kd == 3 || L.kd == 1)) {
+        const int nfrag = L.kd == 3 ? 2 * parts : parts;
+        std::vector<uint16_t> wr((size_t)nfrag * 512, 0);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int co = lane & 15, gq = lane >> 4;
+                if (L.kd == 3) {
+                    for (int c = 0; c < 2; ++c) {
+                        const int sl = c == 0 ? (gq >> 1) : (gq < 2 ? 2 : -1);
+                        const float val = sl >= 0 ? (float)wval(co, (gq & 1) * 8 + j, Tap{0, 0, 0, sl, 0, 0}) : 0.f;
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        wr[((size_t)c * parts) * 512 + lane * 8 + j] = hi;
+                        if (parts == 2) wr[((size_t)c * parts + 1) * 512 + lane * 8 + j] = lo;
+                    }
+                } else {
+                    const float val = (float)wval(co, 4 * gq + (j & 3), Tap{0, 0, 0, 0, 0, 0});
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    wr[(size_t)lane * 8 + j] = hi;
+                    if (parts == 2 && j < 4) wr[512 + (size_t)lane * 8 + j] = lo;
+                }
+            }
+        HIPCHK(hipMalloc((void **)&pc.watt, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.watt, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- srd_roll16: the per-slice 1x3x3 16 -> 16 convs: chunk k, K octet g = (filter tap 2k + (g >> 1), channel octet g & 1)
+    if (geo == G2S1 && cin_pad == 16 && L.cout == 16 && !shortcut_w) {
+        std::vector<uint16_t> wr((size_t)SRD16_CHUNKS * parts * 512, 0);
+        for (int c = 0; c < SRD16_CHUNKS; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = lane & 15, gq = lane >> 4, tap = 2 * c + (gq >> 1);
+                    float val = 0.f;
+                    if (tap < 9) val = (float)wval(co, (gq & 1) * 8 + j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     // ---- srd_roll: the per-slice 1x3x3 8 -> 8 convs of the fused SRD block, in pixel-pair form: chunk = filter row ky;
     // result rows 0-7 = channels of the even pixel of a pair, rows 8-15 = of the odd one; K octet g = input column 2*pair + g,
     // which the even pixel sees as filter column g and the odd pixel as filter column g - 1
@@ -1249,10 +1296,13 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
         auto c0 = r.e->convs.find(p + ".Focus_Measure.conv.0.0"), c2 = r.e->convs.find(p + ".Focus_Measure.conv.2.0");
         auto a3 = r.e->convs.find(p + ".N_ch_attention.0"), a1 = r.e->convs.find(p + ".N_ch_attention.2");
         int sty, stx;
-        srd_roll_tile(&sty, &stx);
+        if (x.C == 16) srd_roll16_tile(&sty, &stx);
+        else srd_roll_tile(&sty, &stx);
         const auto end = r.e->convs.end();
-        if (x.C == 8 && c0 != end && c2 != end && a3 != end && a1 != end && c0->second.wsrd && c2->second.wsrd && a3->second.w32 &&
-            a1->second.w32 && a3->second.watt && a1->second.watt && a3->second.def.kd == 3 && a1->second.def.kd == 1 && x.H % sty == 0 && x.W % stx == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= 256 &&
+        if ((x.C == 8 || (x.C == 16 && !getenv_flag("DFFW_NO_FUSED_SRD16"))) && c0 != end && c2 != end && a3 != end && a1 != end &&
+            c0->second.wsrd && c2->second.wsrd && a3->second.w32 &&
+            a1->second.w32 && a3->second.watt && a1->second.watt && a3->second.def.kd == 3 && a1->second.def.kd == 1 &&
+            x.H % sty == 0 && x.W % stx == 0 && x.H % 2 == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= 256 &&
             !getenv_flag("DFFW_NO_FUSED_SRD") && !getenv_flag("DFFW_NO_FUSED_ATTENTION") && !getenv_flag("DFFW_NO_TILE")) {
             Act out = r.act(x.B, x.N, x.H, x.W, x.C);
             const bool with_pool = pooled && !getenv_flag("DFFW_NO_FUSED_POOL");
@@ -1272,12 +1322,13 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
                 a.total_tiles = x.B * a.tiles_y * a.tiles_x;
                 { const char *z = getenv("DFFW_SRD_WGS"); a.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
                 char kn[64];
-                srd_roll_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
+                if (x.C == 16) srd_roll16_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
+                else srd_roll_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
                 g_last_kernel = kn;
                 const double px = (double)x.pixels();
-                // algorithmic: two 1x3x3 8 -> 8 convs + the 3x1x1 and 1x1x1 attention convs; x read once, out (+ pooled) written once
-                r.prof_begin(kn, p, 2.0 * px * (2 * 9 * 8 * 8 + 4 * 8 * 8), (with_pool ? 2.25 : 2.0) * px * x.C * r.elem_bytes());
-                r.check(launch_srd_roll(r.e->prec, a, r.s), "srd_roll");
+                // algorithmic: two 1x3x3 C -> C convs + the 3x1x1 and 1x1x1 attention convs; x read once, out (+ pooled) written once
+                r.prof_begin(kn, p, 2.0 * px * (2 * 9 + 4) * x.C * x.C, (with_pool ? 2.25 : 2.0) * px * x.C * r.elem_bytes());
+                r.check(x.C == 16 ? launch_srd_roll16(r.e->prec, a, r.s) : launch_srd_roll(r.e->prec, a, r.s), "srd_roll");
                 r.prof_end();
             }
             if (drop_x) r.drop(x);

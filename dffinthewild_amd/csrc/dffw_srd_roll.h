@@ -22,5 +22,10 @@ constexpr int SRD_CHUNKS = 3;
 void srd_roll_tile(int *ty, int *tx);
 hipError_t launch_srd_roll(int prec, const SrdArgs &a, hipStream_t s);
 void srd_roll_kernel_name(int prec, bool pool, char *buf, int n);
+// the 16-channel block (columns of 4 x 16 pixels; 1x3x3 filters as 5 chunks of 2 taps x 16 channels)
+constexpr int SRD16_CHUNKS = 5;
+void srd_roll16_tile(int *ty, int *tx);
+hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s);
+void srd_roll16_kernel_name(int prec, bool pool, char *buf, int n);
 
 }  // namespace dffw

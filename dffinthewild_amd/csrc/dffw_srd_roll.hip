@@ -356,12 +356,358 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
 }
 
+// ---- srd_roll16: the same block for the 16-channel half-resolution stage (`FM_conv1.1`) -----------------------------------
+// 16 output channels fill the MFMA result rows, so no pixel pairs: a GEMM column is one pixel, the 1x3x3 convs contract over
+// 5 chunks of (2 taps x 16 channels) (tap 9 = zeros), records are 32 bytes per plane (natural column order).  Columns are
+// 4 x 16 pixels (LDS: 4 x-slices of 8 x 20 pixels + t + the feat ring = 67 KB, two workgroups per CU).  Stage B / C tiles
+// are 2 rows x 8 pixels per wave so that the 2x2 max-pool stays inside a wave.  Streaming skeleton, counted waits, inline-asm
+// LDS access and the MFMA attention (its split result = the 1x1x1 conv's operand in place) as in srd_roll_kernel.
+template <int PREC, bool POOL>
+__global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int C = 16, TY = 4, TX = 16, NWAVES = 4;
+    constexpr int XY = TY + 4, XX = TX + 4, XPIX = XY * XX;
+    constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;
+    constexpr int PIXB = C * 2;
+    constexpr int NPIECE = 6;                                      // 1 KiB wave instructions per plane (5 hold the 160 pixels; 6 keeps 3 per wave)
+    static_assert(NPIECE * 32 >= XPIX, "plane holds the footprint");
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    constexpr int RX = 4;
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (counted vmcnt waits)");
+    constexpr int TPLANEB = TPIX * PIXB;
+    constexpr int FPLANEB = TY * TX * PIXB;
+    constexpr int FSLOTB = PARTS * FPLANEB;
+    constexpr int X_OFF = 0, T_OFF = RX * SLOTB, F_OFF = T_OFF + PARTS * TPLANEB;
+    constexpr int NCH = 5;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[F_OFF + 3 * FSLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto lds_store8 = [&](unsigned byte_off, uint32_t v0, uint32_t v1) {
+        const u32x2 d = {v0, v1};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(lds0 + byte_off), "v"(d) : "memory");
+    };
+    auto lds_store16 = [&](unsigned byte_off, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + byte_off), "v"(v) : "memory"); };
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+
+    const int rec = PARTS * C;
+    const int slice_elems = a.H * a.W * rec;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int ci = i * 64 + lane, pix = ci >> 1, oct = ci & 1;
+            const int fy = pix / XX, fx = pix - fy * XX;
+            const int iy = c.gy0 - 2 + fy, ix = c.gx0 - 2 + fx;
+            fok[k] = p < NP && pix < XPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            fsrc[k] = a.x + (int64_t)c.b * a.N * slice_elems + (int64_t)(iy * a.W + ix) * rec + part * C + oct * 8;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const bool zin = fu < uend;
+        unsigned char *slot = smem + X_OFF + fslot * SLOTB;
+        const int64_t zo = (int64_t)fq * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RX) ? 0 : fslot + 1;
+        if (++fq == a.N && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // stage A: the 6 x 18 t pixels are 7 operand tiles (the last one partly idle): waves 0-2 take two, wave 3 one
+    constexpr int TA = 2;
+    const int nA = wave < 3 ? 2 : 1;
+    int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
+    bool ta_ok[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        const int tile = j == 0 ? wave : 4 + wave;
+        int p = tile * 16 + r;
+        ta_ok[j] = p < TPIX;
+        if (p >= TPIX) p = TPIX - 1;
+        ta_y[j] = p / TXT;
+        ta_x[j] = p - ta_y[j] * TXT;
+        pa[j] = (ta_y[j] * XX + ta_x[j]) * PIXB + (g & 1) * 16;
+        ta_st[j] = T_OFF + p * PIXB + g * 8;
+    }
+    // K octet g of chunk k = (filter tap 2k + (g >> 1), channel octet g & 1); tap 9 carries zero weights
+    int tapA[NCH], tapB[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int tap = 2 * k + (g >> 1);
+        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
+        tapA[k] = (dy * XX + dx) * PIXB;
+        tapB[k] = (dy * TXT + dx) * PIXB;
+    }
+    // stage B / C: wave w = rows 2*(w >> 1), +1 x columns 8*(w & 1) .. +7 (the 2x2 pooling blocks stay inside the wave)
+    const int pb_y = 2 * (wave >> 1) + (r >> 3), pb_x = 8 * (wave & 1) + (r & 7);
+    const int pbo = (pb_y * TXT + pb_x) * PIXB + (g & 1) * 16;
+    const int pb_res = ((pb_y + 2) * XX + pb_x + 2) * PIXB + g * 8;
+    const int pb_f = (pb_y * TX + pb_x) * PIXB;
+    short8 w0[NCH][PARTS], w2[NCH][PARTS], w3f[2][PARTS], w1f[PARTS];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) {
+            w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
+            w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) w3f[k][pt] = reinterpret_cast<const short8 *>(a.w3f)[(k * PARTS + pt) * 64 + lane];
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) w1f[pt] = reinterpret_cast<const short8 *>(a.w1f)[pt * 64 + lane];
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
+    auto tile_mma = [&](unsigned base, const int (&tapo)[NCH], int loB, const short8 (&wf)[NCH][PARTS], f32x4 acc) {
+        short8 xh[NCH], xl[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const unsigned ad = base + tapo[k];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
+            else xl[k] = xh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int left = (NCH - 1 - k) * PARTS;   // reads still allowed in flight (compile-time after unrolling)
+            if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xh[k]), "+v"(xl[k]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[k]), "+v"(xl[k]));
+            if constexpr (PARTS == 2) {
+                acc = mma<F16>(wf[k][1], xh[k], acc);
+                acc = mma<F16>(wf[k][0], xl[k], acc);
+            }
+            acc = mma<F16>(wf[k][0], xh[k], acc);
+        }
+        return acc;
+    };
+
+    constexpr int INFLIGHT = (RX - 2) * PPW;
+#pragma unroll
+    for (int q = 0; q < RX - 1; ++q) issue_next();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    int xslot = 0;
+    f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        for (int s = 0; s <= a.N + 1; ++s) {
+            const bool produce = s < a.N;
+            const unsigned fslot_off = F_OFF + (s % 3) * FSLOTB;
+            if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s == 0 && tid * 16 < FSLOTB) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+
+            // ---- stage C: attention for slice z = s-2 ----------------------------------------------------------------------
+            if (s >= 2) {
+                const int z = s - 2;
+                const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
+                // chunk 0: K octet g = (slice z-1 + (g >> 1), channel octet g & 1); chunk 1: (slice z+1, octet g & 1) for g < 2
+                const unsigned ad0 = lds0 + ((g >> 1) ? sc : sm) + pb_f + (g & 1) * 16, ad1 = lds0 + sp + pb_f + (g & 1) * 16;
+                short8 fh0, fl0, fh1, fl1;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fh0) : "v"(ad0));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fh1) : "v"(ad1));
+                if constexpr (PARTS == 2) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl0) : "v"(ad0), "n"(FPLANEB));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl1) : "v"(ad1), "n"(FPLANEB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1), "+v"(fl0), "+v"(fl1));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1));
+                }
+                f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (PARTS == 2) {
+                    at = mma<F16>(w3f[0][1], fh0, at);
+                    at = mma<F16>(w3f[0][0], fl0, at);
+                    at = mma<F16>(w3f[1][1], fh1, at);
+                    at = mma<F16>(w3f[1][0], fl1, at);
+                }
+                at = mma<F16>(w3f[0][0], fh0, at);
+                at = mma<F16>(w3f[1][0], fh1, at);
+                uint32_t ah01, ah23, al01, al23;
+                Fmt<PREC>::split2(relu_bits(at[0]), relu_bits(at[1]), ah01, al01);
+                Fmt<PREC>::split2(relu_bits(at[2]), relu_bits(at[3]), ah23, al23);
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                const u32x4v bq = {ah01, ah23, al01, al23};
+                const short8 b2op = __builtin_bit_cast(short8, bq);
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (PARTS == 2) o = mma<F16>(w1f[1], b2op, o);
+                o = mma<F16>(w1f[0], b2op, o);
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = vq1[i] + relu_bits(o[i]);
+                uint32_t h01, h23, l01, l23;
+                Fmt<PREC>::split2(v[0], v[1], h01, l01);
+                Fmt<PREC>::split2(v[2], v[3], h23, l23);
+                const int64_t pix = (((int64_t)U.b * a.N + z) * a.H + U.gy0 + pb_y) * a.W + U.gx0 + pb_x;
+                if constexpr (POOL) {   // 2x2 block: column neighbour = lane r ^ 1, row neighbour = lane r ^ 8
+                    float m[4];
+                    Fmt<PREC>::join2(h01, l01, m[0], m[1]);
+                    Fmt<PREC>::join2(h23, l23, m[2], m[3]);
+                    uint32_t ph01, ph23, pl01, pl23;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m[i]), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
+                        m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m[i]), 0x128, 0xF, 0xF, true)));   // row_ror:8
+                    }
+                    Fmt<PREC>::split2(m[0], m[1], ph01, pl01);
+                    Fmt<PREC>::split2(m[2], m[3], ph23, pl23);
+                    if constexpr (PARTS == 2) {
+                        swap16(ph01, pl01);
+                        swap16(ph23, pl23);
+                    }
+                    if ((r & 9) == 0) {
+                        const int64_t pp = (((int64_t)U.b * a.N + z) * (a.H / 2) + (U.gy0 / 2 + (wave >> 1))) * (a.W / 2) + U.gx0 / 2 + 4 * (wave & 1) + ((r & 7) >> 1);
+                        if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(a.pooled + pp * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(ph01, ph23, pl01, pl23);
+                        else *reinterpret_cast<uint2 *>(a.pooled + pp * rec + g * 4) = make_uint2(ph01, ph23);
+                    }
+                }
+                if constexpr (PARTS == 2) {
+                    swap16(h01, l01);
+                    swap16(h23, l23);
+                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+                }
+            }
+            // ---- stage A ---------------------------------------------------------------------------------------------------------
+            if (produce) {
+#pragma unroll
+                for (int j = 0; j < TA; ++j) {
+                    if (j >= nA) break;
+                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], tapA, PLANEB, w0, b0);
+                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
+                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    if (ta_ok[j]) {
+                        uint32_t h01, h23, l01, l23;
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                        lds_store8(ta_st[j], h01, h23);
+                        if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (produce) {
+                // ---- stage B ---------------------------------------------------------------------------------------------------------
+                {
+                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, tapB, TPLANEB, w2, b2);
+                    const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
+                    u32x2 xh, xl = {0u, 0u};
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
+                    if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
+                    float r0, r1, r2, r3;
+                    Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
+                    Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
+                    f32x4 v;
+                    v[0] = relu_bits(acc[0] + r0);
+                    v[1] = relu_bits(acc[1] + r1);
+                    v[2] = relu_bits(acc[2] + r2);
+                    v[3] = relu_bits(acc[3] + r3);
+                    uint32_t fh01, fh23, fl01, fl23;
+                    Fmt<PREC>::split2(v[0], v[1], fh01, fl01);
+                    Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
+                    lds_store8(fslot_off + pb_f + g * 8, fh01, fh23);
+                    if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + g * 8, fl01, fl23);
+                    vq1 = vq0;
+                    vq0 = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_next();
+                xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
+            } else {
+                vq1 = vq0;
+            }
+            if (s == a.N) {
+                if (tid * 16 < FSLOTB) lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 void srd_roll_tile(int *ty, int *tx) {
     *ty = 8;
     *tx = 16;
 }
 
 void srd_roll_kernel_name(int prec, bool pool, char *buf, int n) { snprintf(buf, n, "dffw::srd_roll_kernel<%d, %s>", prec, pool ? "true" : "false"); }
+
+void srd_roll16_tile(int *ty, int *tx) {
+    *ty = 4;
+    *tx = 16;
+}
+
+void srd_roll16_kernel_name(int prec, bool pool, char *buf, int n) { snprintf(buf, n, "dffw::srd_roll16_kernel<%d, %s>", prec, pool ? "true" : "false"); }
+
+hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : 512;   // two resident workgroups per CU
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+#define DFFW_SRD16_LAUNCH(P)                                                                \
+    do {                                                                                    \
+        if (a.pooled) hipLaunchKernelGGL((srd_roll16_kernel<P, true>), grid, block, 0, s, a);  \
+        else hipLaunchKernelGGL((srd_roll16_kernel<P, false>), grid, block, 0, s, a);          \
+    } while (0)
+    switch (prec) {
+        case P_BF16X3: DFFW_SRD16_LAUNCH(P_BF16X3); break;
+        case P_FP16: DFFW_SRD16_LAUNCH(P_FP16); break;
+        case P_BF16: DFFW_SRD16_LAUNCH(P_BF16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_SRD16_LAUNCH
+    return hipGetLastError();
+}
 
 hipError_t launch_srd_roll(int prec, const SrdArgs &a, hipStream_t s) {
     const int want = a.wgs > 0 ? a.wgs : 768;   // three resident workgroups per CU
