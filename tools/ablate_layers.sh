@@ -2,14 +2,14 @@
 # per-layer times of selected layers with parts of the conv kernels switched off (DFFW_DEBUG_FLAGS: 1 no fill, 2 no MFMA loop, 4 no stores)
 # usage: tools/ablate_layers.sh "<grep -E pattern>"
 pat=${1:-"deconv_|conv5|conv6"}
-for f in 0 2 4 6 1 3 7; do
+for f in 0 2 4 6; do
   DFFW_NO_ROLL=${DFFW_NO_ROLL:-0} DFFW_DEBUG_FLAGS=$f python bench.py --no-cpu-baseline --steps 2 --warmup 1 --dump-layers gpurun_out/abl_$f.tsv > /dev/null 2>&1
 done
 python - "$pat" <<'PY'
 import csv, re, sys
 pat = re.compile(sys.argv[1])
 tabs = {}
-for f in (0, 2, 4, 6, 1, 3, 7):
+for f in (0, 2, 4, 6):
     try:
         tabs[f] = {r[1]: float(r[4]) for r in list(csv.reader(open(f"gpurun_out/abl_{f}.tsv"), delimiter="\t"))[1:]}
     except Exception as e:
