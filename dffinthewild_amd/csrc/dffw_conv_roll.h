@@ -11,6 +11,8 @@ struct RollArgs {
     int total_tiles;         // B * zsplit * tiles_y * tiles_x
     int wgs;                 // workgroups to launch (0: two per CU)
     int pair;                // filter packed for the pixel-pair kernel (<= 8 output channels)
+    const uint16_t *wroll2;  // conv_roll_efd: the pooled branch's filter (null: plain strided conv)
+    const float *bias2;      // ... and its BatchNorm shift (added to a.bias in the accumulator init)
 };
 
 constexpr int ROLL_CHUNKS = 15;        // 3 slices x 5 chunks of (2 in-slice taps x 16 channels)
@@ -21,6 +23,12 @@ hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipS
 void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
+// fused EFD block / strided 3x3x3 conv, 8 -> 16 channels (tiles are 4 x 16 columns of the OUTPUT grid); both filters packed as
+// ROLL_CHUNKS_8 chunks [dz][3 chunks of 4 taps x 8 channels]
+constexpr int ROLL_CHUNKS_8 = 9;
+void efd_roll_tile(int *ty, int *tx);
+hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_roll_efd_kernel_name(int prec, bool dual, char *buf, int n);
 hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_roll_t_kernel_name(int prec, bool res, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
 

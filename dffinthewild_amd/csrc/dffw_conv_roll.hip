@@ -612,6 +612,215 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll_t(const ConvArgs a, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
 }
 
+// ---- conv_roll_efd: the EFD block of the 8-channel stage (DEN.py:306-315, `FM_conv1.0`) as one rolling kernel ------------
+//     out = relu( BN(conv3x3x3 stride (1,2,2) (x)) + BN(conv3x3x3 (maxpool(1,2,2)(x))) ),   8 -> 16 channels, half resolution
+// As two launches the strided branch writes its 16-channel result and the pooled branch reads it back as a residual.  Both
+// contractions feed the SAME accumulators here (the two BatchNorm shifts add up in the accumulator init): a ring slot holds
+// the footprints of one slice of x (9 x 33 pixels for a 4 x 16 output tile, even columns first so that the stride-2 operand
+// reads stay contiguous) and of the pooled volume (6 x 18), K = [x: 3 slices x 3 chunks of 4 taps x 8 channels | pooled: same].
+// With DUAL = false it is the plain strided conv (dres4.conv1).  Streaming skeleton as conv_roll.
+template <int PREC, int RING, bool DUAL>
+__global__ __launch_bounds__(256) void conv_roll_efd(const ConvArgs a, const RollArgs t) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int TY = 4, TX = 16, NWAVES = 4, PIXB = 16;
+    constexpr int XY = 2 * TY + 1, XX = 2 * TX + 1, XPIX = XY * XX, XEV = TX + 1;   // x footprint, XEV even columns per row
+    constexpr int PY = TY + 2, PX = TX + 2, PPIX = PY * PX;                         // pooled footprint
+    constexpr int XPIECES = 6, PPIECES = DUAL ? 2 : 0;                               // 1 KiB wave instructions per plane
+    static_assert(XPIECES * 64 >= XPIX && (!DUAL || PPIECES * 64 >= PPIX), "plane holds the footprints");
+    constexpr int NPIECE = XPIECES + PPIECES, PLANEB = NPIECE * 1024, SLOTB = PARTS * PLANEB, POFF = XPIECES * 1024;
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (the counted vmcnt waits rely on it)");
+    constexpr int NCH = DUAL ? 18 : 9;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, zbeg, nz, gy0, gx0;
+    };
+    auto decode = [&](int u) {   // columns of the OUTPUT grid
+        Unit c;
+        const int txi = u % t.tiles_x;
+        int tt = u / t.tiles_x;
+        const int tyi = tt % t.tiles_y;
+        tt /= t.tiles_y;
+        const int zp = tt % t.zsplit;
+        c.b = tt / t.zsplit;
+        c.gy0 = tyi * TY;
+        c.gx0 = txi * TX;
+        c.zbeg = zp * a.No / t.zsplit;
+        c.nz = (zp + 1) * a.No / t.zsplit - c.zbeg;
+        return c;
+    };
+
+    const int rec = PARTS * 8;
+    const int xslice = a.Hi * a.Wi * rec, pslice = a.Ho * a.Wo * rec;
+    const uint16_t *fsrc[PPW];
+    int fstride[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0, fslices = 0, fz0 = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+        fslices = c.nz + 2;
+        fz0 = c.zbeg - 1;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            if (i < XPIECES) {
+                const int sl = i * 64 + lane;
+                const int fy = sl / XX, pos = sl - fy * XX;
+                const int cx = pos < XEV ? 2 * pos : 2 * (pos - XEV) + 1;   // even columns first, then the odd ones
+                const int iy = 2 * c.gy0 - 1 + fy, ix = 2 * c.gx0 - 1 + cx;
+                fok[k] = p < NP && sl < XPIX && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                fsrc[k] = a.in0 + (int64_t)c.b * a.Ni * xslice + (int64_t)(iy * a.Wi + ix) * rec + part * 8;
+                fstride[k] = xslice;
+            } else {
+                const int sl = (i - XPIECES) * 64 + lane;
+                const int fy = sl / PX, fx = sl - fy * PX;
+                const int iy = c.gy0 - 1 + fy, ix = c.gx0 - 1 + fx;
+                fok[k] = p < NP && sl < PPIX && (unsigned)iy < (unsigned)a.Ho && (unsigned)ix < (unsigned)a.Wo;
+                fsrc[k] = a.in1 + (int64_t)c.b * a.Ni * pslice + (int64_t)(iy * a.Wo + ix) * rec + part * 8;
+                fstride[k] = pslice;
+            }
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const int iz = fz0 + fq;
+        const bool zin = (unsigned)iz < (unsigned)a.Ni && fu < uend;
+        unsigned char *slot = smem + fslot * SLOTB;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + (int64_t)iz * fstride[k] : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RING) ? 0 : fslot + 1;
+        if (++fq == fslices && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // operand addressing: wave w = output row w of the column, lane column r; K octet g of chunk k3 = filter tap 4*k3 + g
+    // (taps 9..11 carry zero weights).  x branch: input pixel (2*row + ky, 2*r + kx); pooled branch: (row + ky, r + kx).
+    int tapX[3], tapP[3];
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+        const int tap = 4 * k3 + g;
+        const int ky = tap < 9 ? tap / 3 : 0, kx = tap < 9 ? tap % 3 : 0;
+        tapX[k3] = (ky * XX + (kx == 1 ? XEV : (kx == 2 ? 1 : 0))) * PIXB;
+        tapP[k3] = (ky * PX + kx) * PIXB;
+    }
+    const int baseX = (2 * wave * XX + r) * PIXB, baseP = POFF + (wave * PX + r) * PIXB;
+    const int lanepart = (PARTS == 2) ? (g & 1) * 16 + (g >> 1) * 8 : g * 4;
+    const int voff = (wave * a.Wo + r) * (PARTS * 16) + lanepart;
+
+    constexpr int INFLIGHT = (RING - 4) * PPW;
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) issue_next();
+
+    short8 w[NCH][PARTS];
+    {
+        const short8 *wa = reinterpret_cast<const short8 *>(t.wroll) + lane;
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) w[c][pt] = wa[(c * PARTS + pt) * 64];
+        if constexpr (DUAL) {
+            const short8 *wb = reinterpret_cast<const short8 *>(t.wroll2) + lane;
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+#pragma unroll
+                for (int pt = 0; pt < PARTS; ++pt) w[9 + c][pt] = wb[(c * PARTS + pt) * 64];
+        }
+    }
+    f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+    if constexpr (DUAL) {
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(t.bias2 + g * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] += bb[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    int sidx = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        const int64_t obase0 = (((int64_t)U.b * a.No + U.zbeg) * a.Ho + U.gy0) * a.Wo + U.gx0;
+        for (int st = 0; st < U.nz + 2; ++st) {
+            const bool live = st < U.nz;
+            const int64_t obase = obase0 + (int64_t)st * a.Ho * a.Wo;
+            const int64_t ubase = obase * (PARTS * 16);
+            if (!(a.dbg & 1)) issue_next();
+
+            f32x4 acc = bias4;
+            if (live && !(a.dbg & 2)) {
+                int sb[3];
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    int sl = sidx + dz;
+                    if (sl >= RING) sl -= RING;
+                    sb[dz] = sl * SLOTB;
+                }
+                constexpr int DEPTH = 2;
+                short8 x[DEPTH + 1][PARTS];
+                auto fetch = [&](int c, short8 (&dst)[PARTS]) {
+                    const int cc = c % 9, dz = cc / 3, k3 = cc % 3;
+                    const unsigned ad = lds0 + sb[dz] + (c < 9 ? baseX + tapX[k3] : baseP + tapP[k3]);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
+                    if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "n"(PLANEB));
+                };
+#pragma unroll
+                for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + DEPTH < NCH) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
+                    auto &xc = x[c % (DEPTH + 1)];
+                    const int ahead = (NCH - 1 - c < DEPTH ? NCH - 1 - c : DEPTH) * PARTS;
+                    if (ahead == 2 * PARTS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0]) : "n"(2 * PARTS));
+                    else if (ahead == PARTS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0]) : "n"(PARTS));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0]));
+                    if constexpr (PARTS == 2) {
+                        asm volatile("" : "+v"(xc[1]));
+                        acc = mma<F16>(w[c][1], xc[0], acc);
+                        acc = mma<F16>(w[c][0], xc[1], acc);
+                    }
+                    acc = mma<F16>(w[c][0], xc[0], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
+            if (!live) continue;
+            if ((a.dbg & 4) && acc[0] != 12345.f) continue;
+            const int64_t opix = obase + (int64_t)wave * a.Wo + r;
+            float cls = 0.f;
+            epilogue_quad<PREC, false, true, false>(a, acc, 0, g, opix, true, cls, uint4{}, uint4{}, ubase, voff);
+            epilogue_cls(a, cls, g, opix, true);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 #define DFFW_ROLL_TY 8
 #define DFFW_ROLL_TX 16
@@ -647,6 +856,35 @@ hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hi
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_ROLLT_LAUNCH
+    return hipGetLastError();
+}
+
+void efd_roll_tile(int *ty, int *tx) {
+    *ty = 4;
+    *tx = 16;
+}
+
+void conv_roll_efd_kernel_name(int prec, bool dual, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll_efd<%d, %d, %s>", prec, 5, dual ? "true" : "false");
+}
+
+hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    const int want = t.wgs > 0 ? t.wgs : 512;
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    const bool dual = t.wroll2 != nullptr;
+#define DFFW_EFD_LAUNCH(P)                                                                       \
+    do {                                                                                         \
+        if (dual) hipLaunchKernelGGL((conv_roll_efd<P, 5, true>), grid, block, 0, s, a, t);     \
+        else hipLaunchKernelGGL((conv_roll_efd<P, 5, false>), grid, block, 0, s, a, t);         \
+    } while (0)
+    switch (prec) {
+        case P_BF16X3: DFFW_EFD_LAUNCH(P_BF16X3); break;
+        case P_FP16: DFFW_EFD_LAUNCH(P_FP16); break;
+        case P_BF16: DFFW_EFD_LAUNCH(P_BF16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_EFD_LAUNCH
     return hipGetLastError();
 }
 

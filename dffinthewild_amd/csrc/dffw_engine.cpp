@@ -304,6 +304,7 @@ struct PackedConv {
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
+    uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
     uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
     uint16_t *watt = nullptr;      // device: an 8 -> 8 attention conv (3x1x1 or 1x1x1) as srd_roll's stage-C fragments
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
@@ -330,6 +331,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll = nullptr;
     if (pc.wroll_t) (void)hipFree(pc.wroll_t);
     pc.wroll_t = nullptr;
+    if (pc.wroll8) (void)hipFree(pc.wroll8);
+    pc.wroll8 = nullptr;
     if (pc.wsrd) (void)hipFree(pc.wsrd);
     pc.wsrd = nullptr;
     if (pc.watt) (void)hipFree(pc.watt);
@@ -681,6 +684,24 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    // ---- conv_roll_efd: 3x3x3 8 -> 16 (stride 1 on the pooled volume, or stride (1,2,2)): chunk (dz, k3), K octet g = tap 4*k3 + g
+    if ((geo == G3S1 || geo == G3S2) && cin_pad == 8 && L.cout == 16 && !shortcut_w) {
+        std::vector<uint16_t> wr((size_t)ROLL_CHUNKS_8 * parts * 512, 0);
+        for (int c = 0; c < ROLL_CHUNKS_8; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = lane & 15, tap = 4 * (c % 3) + (lane >> 4), dz = c / 3;
+                    float val = 0.f;
+                    if (tap < 9) val = (float)wval(co, j, Tap{dz - 1, tap / 3 - 1, tap % 3 - 1, dz, tap / 3, tap % 3});
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wroll8, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wroll8, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     // ---- conv_roll_t: transposed 3x3x3 s(1,2,2), 16 -> 8 channels.  Result rows 0-7 = output pixel 2x, rows 8-15 = pixel
     // 2x+1; chunk c < 3: output row phase py = 0 (filter row 1 at input row y), slice c of the window; c >= 3: py = 1,
     // slice (c-3)/2, filter row 2 at input row y ((c-3) even) or filter row 0 at input row y+1 (odd).  Lane group g
@@ -1008,6 +1029,38 @@ struct Run {
         a.zero = e->zero_page;
         { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 7) : 0; }
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
+        // strided 3x3x3 8 -> 16 (dres4.conv1): the single-branch form of conv_roll_efd
+        {
+            int ety, etx;
+            efd_roll_tile(&ety, &etx);
+            if (pc.wroll8 && !L.transposed && L.sh == 2 && in0.C == 8 && !o.in1 && !o.res0 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre &&
+                !o.cls && Ho % ety == 0 && Wo % etx == 0 && (int64_t)in0.B * (Ho / ety) * (Wo / etx) >= 256 && !getenv_flag("DFFW_NO_ROLL") &&
+                !getenv_flag("DFFW_NO_ROLL_S2")) {
+                if (dry) return out;
+                a.Ng = No; a.Hg = Ho; a.Wg = Wo;
+                a.M = (int64_t)a.B * No * Ho * Wo;
+                a.dbg &= 6;
+                RollArgs t;
+                memset(&t, 0, sizeof t);
+                t.wroll = pc.wroll8;
+                t.tiles_y = Ho / ety;
+                t.tiles_x = Wo / etx;
+                t.zsplit = 1;
+                t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
+                { const char *z = getenv("DFFW_ROLL_WGS"); t.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                char kn[96];
+                conv_roll_efd_kernel_name(e->prec, false, kn, sizeof kn);
+                g_last_kernel = kn;
+                if (e->profiling) {
+                    const double opx = (double)out.B * No * Ho * Wo;
+                    prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout,
+                               ((double)in0.pixels() * L.cin + opx * L.cout) * elem_bytes() + 27.0 * L.cin * L.cout * elem_bytes());
+                }
+                check(launch_conv_roll_efd(e->prec, a, t, s), name.c_str());
+                prof_end();
+                return out;
+            }
+        }
         // ... and its transposed sibling (16 -> 8 channels), tiled over the input grid
         {
             int rty, rtx;
@@ -1019,6 +1072,7 @@ struct Run {
                 a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
                 a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
                 RollArgs t;
+                memset(&t, 0, sizeof t);
                 t.wroll = pc.wroll_t;
                 t.tiles_y = in0.H / rty;
                 t.tiles_x = in0.W / rtx;
@@ -1057,6 +1111,7 @@ struct Run {
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
                 RollArgs t;
+                memset(&t, 0, sizeof t);
                 t.wroll = pc.wroll;
                 t.tiles_y = Ho / rty;
                 t.tiles_x = Wo / rtx;
@@ -1371,6 +1426,54 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
 
 // EFD block (DEN.py:306-315)
 static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr) {
+    // the 8 -> 16 channel block with its pooled input at hand: both branches in one rolling kernel (conv_roll_efd)
+    {
+        auto ca = r.e->convs.find(p + ".stride_conv.0"), cb = r.e->convs.find(p + ".max_pooling.1.0");
+        int ty, tx;
+        efd_roll_tile(&ty, &tx);
+        const int Ho = x.H / 2, Wo = x.W / 2;
+        const auto end = r.e->convs.end();
+        if (x.C == 8 && pooled && pooled->p && ca != end && cb != end && ca->second.wroll8 && cb->second.wroll8 && x.H % 2 == 0 && x.W % 2 == 0 &&
+            Ho % ty == 0 && Wo % tx == 0 && (int64_t)x.B * (Ho / ty) * (Wo / tx) >= 256 && !getenv_flag("DFFW_NO_ROLL") &&
+            !getenv_flag("DFFW_NO_FUSED_EFD") && !getenv_flag("DFFW_NO_TILE")) {
+            Act out = r.act(x.B, x.N, Ho, Wo, 16);
+            if (r.ok() && !r.dry) {
+                if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return out; }
+                ConvArgs a;
+                memset(&a, 0, sizeof a);
+                a.in0 = x.p; a.C0 = 8;
+                a.in1 = pooled->p; a.C1 = 8;
+                a.B = x.B; a.Ni = x.N; a.Hi = x.H; a.Wi = x.W;
+                a.Ng = x.N; a.Hg = Ho; a.Wg = Wo;
+                a.No = x.N; a.Ho = Ho; a.Wo = Wo;
+                a.Cout = 16;
+                a.bias = ca->second.bias;
+                a.out = out.p;
+                a.relu = 1;
+                a.zero = r.e->zero_page;
+                a.M = (int64_t)x.B * x.N * Ho * Wo;
+                { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 6) : 0; }
+                RollArgs t;
+                memset(&t, 0, sizeof t);
+                t.wroll = ca->second.wroll8;
+                t.wroll2 = cb->second.wroll8;
+                t.bias2 = cb->second.bias;
+                t.tiles_y = Ho / ty; t.tiles_x = Wo / tx;
+                t.zsplit = 1;
+                t.total_tiles = x.B * t.tiles_y * t.tiles_x;
+                { const char *z = getenv("DFFW_ROLL_WGS"); t.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                char kn[64];
+                conv_roll_efd_kernel_name(r.e->prec, true, kn, sizeof kn);
+                g_last_kernel = kn;
+                const double opx = (double)x.B * x.N * Ho * Wo;
+                r.prof_begin(kn, p, 2.0 * opx * 27.0 * 8 * 16 * 2, ((double)x.pixels() * 8 + opx * 8 + opx * 16) * r.elem_bytes());
+                r.check(launch_conv_roll_efd(r.e->prec, a, t, r.s), "conv_roll_efd");
+                r.prof_end();
+            }
+            r.drop(*pooled);
+            return out;
+        }
+    }
     Act a = r.conv(p + ".stride_conv.0", x);
     Act m = (pooled && pooled->p) ? *pooled : r.pool(x, 0, 2);
     ConvOpt o; o.relu = 1; o.res0 = &a;

@@ -129,6 +129,33 @@ def test_fused_srd_block_matches_three_launch_form(lib_built, B, N, H, W, wgs, p
         assert cpu_ref.rel_l2(outs[3].cpu(), ref[3]) <= 1e-3
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 3, 128, 256, 16), (4, 1, 128, 128, 0), (2, 2, 128, 256, 8)])
+def test_fused_efd_block_matches_two_launch_form(lib_built, B, N, H, W, wgs, prec, monkeypatch):
+    """conv_roll_efd (dffw_conv_roll.hip): the EFD block relu(BN(conv s(1,2,2)(x)) + BN(conv(maxpool(x)))) of the 8-channel
+    stage (DEN.py:306-315, FM_conv1.0) with both contractions in one rolling kernel, against the two-launch form (strided
+    conv, then pooled conv with the first as a residual): V2 = the following SRD block's output.  Slice counts 1, 2, 3, 10,
+    short and long column streams, three arithmetics."""
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 4, "smooth").items()}
+    model = model_for(sd, (4, "smooth"), prec)
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=78)).cuda()
+    fd = torch.from_numpy(synth.focus_dists(B, N, 1, 1)).cuda()
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    with torch.no_grad():
+        outs, taps = model.forward_with_taps(FS, fd, ["V2"])
+        monkeypatch.setenv("DFFW_NO_FUSED_EFD", "1")
+        outs2, taps2 = model.forward_with_taps(FS, fd, ["V2"])
+    tol = {"bf16x3": 2e-5, "fp16": 3e-3, "bf16": 3e-2}[prec]
+    err = cpu_ref.rel_l2(taps["V2"].cpu(), taps2["V2"].cpu())
+    assert 0 < err <= tol, err      # 0 would mean both runs took the same path
+    if prec == "bf16x3":
+        with torch.no_grad():
+            ref = cpu_ref.dff_forward(sd, FS.cpu(), fd.cpu())
+        assert cpu_ref.rel_l2(outs[3].cpu(), ref[3]) <= 1e-3
+
+
 def test_reference_call_sequence_dataparallel(lib_built):
     """test.py:30-32,78-86,115-119 verbatim sequence against the drop-in."""
     import torch.nn as nn
@@ -170,7 +197,7 @@ def test_full_size_properties(lib_built):
 
 
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_STREAM", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
-                                 "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD"])
+                                 "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback

@@ -130,6 +130,27 @@ def test_conv_roll_transposed(eng, N, H, W, zsplit, residual, wgs, prec, monkeyp
     assert rel(alt, ref) <= TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("N,H,W,wgs", [(10, 128, 256, 0), (1, 128, 256, 8), (2, 256, 128, 16), (5, 64, 512, 24)])
+def test_conv_roll_strided(eng, N, H, W, wgs, prec, monkeypatch):
+    """conv_roll_efd<..., false>: 3x3x3 stride (1,2,2) 8 -> 16 channels (dres4.conv1, DEN.py:252) as a rolling window with
+    the stride-2 footprint stored even columns first; vs F.conv3d and vs conv_tile on the same input."""
+    B, cin, cout = 2, 8, 16
+    x = rnd(B, cin, N, H, W, seed=41)
+    w = rnd(cout, cin, 3, 3, 3, seed=42, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 43)
+    ref = F.relu(ref_bn(F.conv3d(x, w, None, (1, 2, 2), 1), bn))
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    got = eng.op_conv3d(x.cuda(), w, stride=(1, 2, 2), pad=1, bn=bn, relu=1, precision=prec)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_efd<"), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL[prec], rel(got, ref)
+    monkeypatch.setenv("DFFW_NO_ROLL", "1")
+    alt = eng.op_conv3d(x.cuda(), w, stride=(1, 2, 2), pad=1, bn=bn, relu=1, precision=prec)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(alt, ref) <= TOL[prec]
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16"])
 @pytest.mark.parametrize("cin,cout,N,H,W", [(16, 8, 3, 8, 8), (64, 32, 2, 8, 16), (128, 64, 2, 4, 4), (32, 32, 1, 8, 8)])
 def test_transposed_conv_phases(eng, cin, cout, N, H, W, prec):
