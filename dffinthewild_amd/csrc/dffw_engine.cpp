@@ -645,6 +645,36 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.watt, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.watt, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    // the same for the 32-channel block (srd_attention_mfma, two 16-channel output tiles).  3x1x1: chunk k = slice k, K octet g =
+    // input channels 8g..8g+7.  1x1x1: channel chunk c = input channels 16c..16c+15, K octet g = channels 16c+4g..+3 as [hi | lo].
+    if (!L.transposed && L.kh == 1 && L.kw == 1 && L.cin == 32 && L.cout == 32 && !bn && !conv_bias && (L.kd == 3 || L.kd == 1)) {
+        const int nfrag = L.kd == 3 ? 3 * 2 * parts : 2 * parts * 2;
+        std::vector<uint16_t> wr((size_t)nfrag * 512, 0);
+        for (int nt = 0; nt < 2; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = nt * 16 + (lane & 15), gq = lane >> 4;
+                    if (L.kd == 3) {
+                        for (int k = 0; k < 3; ++k) {
+                            const float val = (float)wval(co, gq * 8 + j, Tap{0, 0, 0, k, 0, 0});
+                            uint16_t hi, lo;
+                            host_split(prec, val, hi, lo);
+                            wr[((size_t)(k * 2 + nt) * parts) * 512 + lane * 8 + j] = hi;
+                            if (parts == 2) wr[((size_t)(k * 2 + nt) * parts + 1) * 512 + lane * 8 + j] = lo;
+                        }
+                    } else {
+                        for (int c = 0; c < 2; ++c) {
+                            const float val = (float)wval(co, 16 * c + 4 * gq + (j & 3), Tap{0, 0, 0, 0, 0, 0});
+                            uint16_t hi, lo;
+                            host_split(prec, val, hi, lo);
+                            wr[((size_t)(c * parts) * 2 + nt) * 512 + lane * 8 + j] = hi;
+                            if (parts == 2 && j < 4) wr[((size_t)(c * parts + 1) * 2 + nt) * 512 + lane * 8 + j] = lo;
+                        }
+                    }
+                }
+        HIPCHK(hipMalloc((void **)&pc.watt, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.watt, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     // ---- srd_roll16: the per-slice 1x3x3 16 -> 16 convs: chunk k, K octet g = (filter tap 2k + (g >> 1), channel octet g & 1)
     if (geo == G2S1 && cin_pad == 16 && L.cout == 16 && !shortcut_w) {
         std::vector<uint16_t> wr((size_t)SRD16_CHUNKS * parts * 512, 0);
@@ -1411,6 +1441,18 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
             r.prof_begin(kn, p + ".N_ch_attention", 2.0 * px * 4 * feat.C * feat.C, (with_pool ? 2.25 : 2.0) * px * feat.C * r.elem_bytes());
             r.check(launch_srd_attention(r.e->prec, feat.p, out.p, i3->second.w32, i1->second.w32, feat.B, feat.N, feat.H, feat.W,
                                          feat.C, with_pool ? pooled->p : nullptr, r.s), "srd_attention");
+            r.prof_end();
+        }
+    } else if (feat.C == 32 && i3 != r.e->convs.end() && i1 != r.e->convs.end() && i3->second.watt && i1->second.watt && feat.W % 16 == 0 &&
+               !getenv_flag("DFFW_NO_FUSED_ATTENTION")) {
+        out = r.act(feat.B, feat.N, feat.H, feat.W, feat.C);
+        if (r.ok() && !r.dry) {
+            char kn[64];
+            snprintf(kn, sizeof kn, "dffw::srd_attention_mfma<%d>", r.e->prec);
+            const double px = (double)feat.pixels();
+            r.prof_begin(kn, p + ".N_ch_attention", 2.0 * px * 4 * feat.C * feat.C, 2.0 * px * feat.C * r.elem_bytes());
+            r.check(launch_srd_attention_mfma(r.e->prec, feat.p, out.p, i3->second.watt, i1->second.watt, feat.B, feat.N, feat.H, feat.W, r.s),
+                    "srd_attention_mfma");
             r.prof_end();
         }
     } else {

@@ -28,4 +28,9 @@ void srd_roll16_tile(int *ty, int *tx);
 hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s);
 void srd_roll16_kernel_name(int prec, bool pool, char *buf, int n);
 
+// the attention tail of the 32-channel block on the matrix cores (no LDS; W % 16 == 0).  w3f: [3 slices][2 output tiles][part][64][8],
+// w1f: [2 channel chunks][fragment][2 output tiles][64][8] (pack_conv)
+hipError_t launch_srd_attention_mfma(int prec, const uint16_t *feat, uint16_t *out, const uint16_t *w3f, const uint16_t *w1f, int B, int N,
+                                     int H, int W, hipStream_t s);
+
 }  // namespace dffw

@@ -676,6 +676,132 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- srd_attention_mfma: the attention tail of the 32-channel SRD block (`FM_conv2.1.N_ch_attention`) on the matrix cores ------
+//     out = feat + relu(conv1x1x1(relu(conv3x1x1(feat))))     (DEN.py:322-329; no BatchNorm, no bias)
+// The fused VALU kernel (srd_attention_kernel) stops at 16 channels (C*C*4 FMAs per pixel); at 32 channels the two convs ran as
+// two gather-GEMM launches with the intermediate in HBM.  Pointwise in space, so no LDS: a wave owns 16 consecutive pixels of a
+// row and walks the slices with feat[z-1], feat[z], feat[z+1] as MFMA operand fragments in registers (each record is read once);
+// conv3x1x1 = 3 chunks (one per slice) x 2 output tiles; its ReLU'd result, split to hi/lo in registers, is the operand of the
+// 1x1x1 conv in place (K octet = the lane's own 4 channels as [hi | lo], fragments [w_hi w_hi] and [w_lo 0]).
+template <int PREC>
+__global__ __launch_bounds__(256) void srd_attention_mfma(const uint16_t *__restrict__ feat, uint16_t *__restrict__ out,
+                                                          const uint16_t *__restrict__ w3f, const uint16_t *__restrict__ w1f, int B, int N,
+                                                          int H, int W) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int C = 32, REC = PARTS * C;
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strips_per_row = W / 16;
+    const int64_t nstrips = (int64_t)B * H * strips_per_row;
+    if (strip >= nstrips) return;
+    const int sx = (int)(strip % strips_per_row);
+    const int64_t by = strip / strips_per_row;
+    const int y = (int)(by % H), b = (int)(by / H);
+    const int64_t hw = (int64_t)H * W;
+    const int64_t pix0 = ((int64_t)b * N * H + y) * W + sx * 16 + r;   // the lane's pixel in slice 0
+
+    short8 w3[3][2][PARTS], w1[2][2][2];   // [slice chunk][output tile][part], [channel chunk][fragment][output tile]
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) w3[k][nt][pt] = reinterpret_cast<const short8 *>(w3f)[((k * 2 + nt) * PARTS + pt) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int fr = 0; fr < PARTS; ++fr)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) w1[c][fr][nt] = reinterpret_cast<const short8 *>(w1f)[((c * PARTS + fr) * 2 + nt) * 64 + lane];
+
+    auto load = [&](int z, short8 (&f)[PARTS]) {   // the lane's K octet (channels 8g..8g+7) of feat[z]; zeros outside the stack
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) f[pt] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+        if ((unsigned)z < (unsigned)N) {
+            const uint16_t *p = feat + (pix0 + (int64_t)z * hw) * REC + g * 8;
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) f[pt] = *reinterpret_cast<const short8 *>(p + pt * C);
+        }
+    };
+    short8 f[3][PARTS];
+    load(-1, f[0]);
+    load(0, f[1]);
+    for (int z = 0; z < N; ++z) {
+        load(z + 1, f[2]);
+        f32x4 at[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            at[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if constexpr (PARTS == 2) {
+                    at[nt] = mma<F16>(w3[k][nt][1], f[k][0], at[nt]);
+                    at[nt] = mma<F16>(w3[k][nt][0], f[k][1], at[nt]);
+                }
+                at[nt] = mma<F16>(w3[k][nt][0], f[k][0], at[nt]);
+            }
+        }
+        short8 b2[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t ah01, ah23, al01, al23;
+            Fmt<PREC>::split2(relu_bits(at[c][0]), relu_bits(at[c][1]), ah01, al01);
+            Fmt<PREC>::split2(relu_bits(at[c][2]), relu_bits(at[c][3]), ah23, al23);
+            typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+            const u32x4v bq = {ah01, ah23, al01, al23};
+            b2[c] = __builtin_bit_cast(short8, bq);
+        }
+        const int64_t pix = pix0 + (int64_t)z * hw;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if constexpr (PARTS == 2) o = mma<F16>(w1[c][1][nt], b2[c], o);
+                o = mma<F16>(w1[c][0][nt], b2[c], o);
+            }
+            // + feat[z] at the lane's result channels nt*16 + 4g .. +3 (reloaded: the operand octet holds other channels)
+            const uint16_t *cp = feat + pix * REC + nt * 16 + g * 4;
+            const uint2 ch = *reinterpret_cast<const uint2 *>(cp);
+            uint2 cl = make_uint2(0, 0);
+            if constexpr (PARTS == 2) cl = *reinterpret_cast<const uint2 *>(cp + C);
+            float c0, c1, c2, c3;
+            Fmt<PREC>::join2(ch.x, cl.x, c0, c1);
+            Fmt<PREC>::join2(ch.y, cl.y, c2, c3);
+            uint32_t h01, h23, l01, l23;
+            Fmt<PREC>::split2(c0 + relu_bits(o[0]), c1 + relu_bits(o[1]), h01, l01);
+            Fmt<PREC>::split2(c2 + relu_bits(o[2]), c3 + relu_bits(o[3]), h23, l23);
+            if constexpr (PARTS == 2) {
+                swap16(h01, l01);
+                swap16(h23, l23);
+                *reinterpret_cast<uint4 *>(out + pix * REC + (g & 1) * C + (nt * 2 + (g >> 1)) * 8) = make_uint4(h01, h23, l01, l23);
+            } else {
+                *reinterpret_cast<uint2 *>(out + pix * REC + nt * 16 + g * 4) = make_uint2(h01, h23);
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) {
+            f[0][pt] = f[1][pt];
+            f[1][pt] = f[2][pt];
+        }
+    }
+}
+
+hipError_t launch_srd_attention_mfma(int prec, const uint16_t *feat, uint16_t *out, const uint16_t *w3f, const uint16_t *w1f, int B, int N,
+                                     int H, int W, hipStream_t s) {
+    if (W % 16) return hipErrorInvalidValue;
+    const int64_t nstrips = (int64_t)B * H * (W / 16);
+    const dim3 grid((unsigned)((nstrips + 3) / 4)), block(256);
+    switch (prec) {
+        case P_BF16X3: hipLaunchKernelGGL((srd_attention_mfma<P_BF16X3>), grid, block, 0, s, feat, out, w3f, w1f, B, N, H, W); break;
+        case P_FP16: hipLaunchKernelGGL((srd_attention_mfma<P_FP16>), grid, block, 0, s, feat, out, w3f, w1f, B, N, H, W); break;
+        case P_BF16: hipLaunchKernelGGL((srd_attention_mfma<P_BF16>), grid, block, 0, s, feat, out, w3f, w1f, B, N, H, W); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 void srd_roll_tile(int *ty, int *tx) {
     *ty = 8;
     *tx = 16;

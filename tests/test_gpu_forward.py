@@ -156,6 +156,25 @@ def test_fused_efd_block_matches_two_launch_form(lib_built, B, N, H, W, wgs, pre
         assert cpu_ref.rel_l2(outs[3].cpu(), ref[3]) <= 1e-3
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("B,N,H,W", [(1, 10, 256, 256), (2, 1, 64, 128), (1, 2, 64, 64)])
+def test_mfma_attention_of_the_32_channel_block(lib_built, B, N, H, W, prec, monkeypatch):
+    """srd_attention_mfma: the attention tail of FM_conv2.1 (32 channels, DEN.py:322-329) on the matrix cores, against the
+    two gather-GEMM launches it replaces (DFFW_NO_FUSED_ATTENTION=1): V3 tap, slice counts 1, 2, 10."""
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 6, "smooth").items()}
+    model = model_for(sd, (6, "smooth"), prec)
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=79)).cuda()
+    fd = torch.from_numpy(synth.focus_dists(B, N, 1, 1)).cuda()
+    with torch.no_grad():
+        _, taps = model.forward_with_taps(FS, fd, ["V3"])
+        monkeypatch.setenv("DFFW_NO_FUSED_ATTENTION", "1")
+        _, taps2 = model.forward_with_taps(FS, fd, ["V3"])
+    tol = {"bf16x3": 2e-5, "fp16": 3e-3, "bf16": 3e-2}[prec]
+    err = cpu_ref.rel_l2(taps["V3"].cpu(), taps2["V3"].cpu())
+    assert 0 < err <= tol, err
+
+
 def test_reference_call_sequence_dataparallel(lib_built):
     """test.py:30-32,78-86,115-119 verbatim sequence against the drop-in."""
     import torch.nn as nn
