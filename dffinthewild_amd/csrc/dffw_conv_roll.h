@@ -23,6 +23,12 @@ hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipS
 void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
+// transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one
+// tap x 32 channels, phase 1 after phase 0 in one buffer)
+constexpr int ROLL_CHUNKS_T32_0 = 9, ROLL_CHUNKS_T32_1 = 18;
+void roll_t32_tile(int py, int *ty, int *tx);   // input-grid column of sweep py
+hipError_t launch_conv_roll_t32(int prec, int py, const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_roll_t32_kernel_name(int prec, int py, bool res, char *buf, int n);
 // fused EFD block / strided 3x3x3 conv, 8 -> 16 channels (tiles are 4 x 16 columns of the OUTPUT grid); both filters packed as
 // ROLL_CHUNKS_8 chunks [dz][3 chunks of 4 taps x 8 channels]
 constexpr int ROLL_CHUNKS_8 = 9;

@@ -612,6 +612,252 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll_t(const ConvArgs a, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
 }
 
+// ---- conv_roll_t32: transposed 3x3x3 conv, 32 -> 16 channels (`deconv_2`, `dres3.conv6`), one output row phase per launch ----
+// 16 output channels fill the result rows, so the x phases cannot share a tile, and the filter of all four phases (27 taps x 32
+// channels x 16 = 27 chunks, 216 VGPRs) does not fit beside the pipeline.  Two launches: sweep PY computes the output rows
+// 2y + PY (both x phases) with only that row phase's taps resident (9 / 18 chunks = 72 / 144 VGPRs); each sweep streams the
+// input once (it is a quarter of the output's size).  A chunk = one tap x 32 channels (K octet g = channel octet g), so every
+// operand address is the lane's base plus an immediate.  Skeleton as conv_roll_t; ring of 4 slices (20 KB each).
+template <int PREC, int PY, int RING, bool RES>
+__global__ __launch_bounds__(256) void conv_roll_t32(const ConvArgs a, const RollArgs t) {
+    constexpr int TY = PY ? 4 : 8, TX = 16, NWAVES = 4;   // phase 1 carries twice the filter: one input row per wave instead of two
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int PIXB = 64;
+    constexpr int FY = TY + 1, FX = TX + 1, FPIX = FY * FX;
+    constexpr int NPIECE = PY ? 6 : (PARTS == 2 ? 10 : 12);   // 1 KiB wave instructions per plane: (TY+1) x 17 pixels x 4 channel octets, rounded so that every wave issues the same count
+    static_assert(NPIECE * 64 >= FPIX * 4, "plane holds the footprint");
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    constexpr int MTW = TY / NWAVES;                       // input rows (16-column operand tiles) per wave
+    constexpr int NROW = PY ? 2 : 1;                       // row taps of this phase: py = 0: filter row 1 at input row y; py = 1: row 2 at y, row 0 at y+1
+    constexpr int NCH0 = 3 * NROW, NCH1 = 6 * NROW, NCH = NCH0 + NCH1;   // chunks of x phase 0 (1 column tap) and x phase 1 (2 column taps)
+    static_assert(TX == 16 && TY % NWAVES == 0, "one operand tile = one 16-pixel input row");
+    constexpr int NP = PARTS * NPIECE;
+    constexpr int PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (the counted vmcnt waits rely on it)");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, zbeg, nz, gy0, gx0;
+    };
+    auto decode = [&](int u) {   // units = columns of the INPUT grid
+        Unit c;
+        const int txi = u % t.tiles_x;
+        int tt = u / t.tiles_x;
+        const int tyi = tt % t.tiles_y;
+        tt /= t.tiles_y;
+        const int zp = tt % t.zsplit;
+        c.b = tt / t.zsplit;
+        c.gy0 = tyi * TY;
+        c.gx0 = txi * TX;
+        c.zbeg = zp * a.No / t.zsplit;
+        c.nz = (zp + 1) * a.No / t.zsplit - c.zbeg;
+        return c;
+    };
+
+    const int ps0 = PARTS * a.C0;
+    const int slice_elems = a.Hi * a.Wi * ps0;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0, fslices = 0, fz0 = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+        fslices = c.nz + 2;
+        fz0 = c.zbeg - 1;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int ci = i * 64 + lane, pix = ci >> 2, oct = ci & 3;
+            const int fy = pix / FX, fx = pix - fy * FX;
+            const int iy = c.gy0 + fy, ix = c.gx0 + fx;          // halo on the high side only
+            fok[k] = p < NP && pix < FPIX && iy < a.Hi && ix < a.Wi;
+            const uint16_t *sp = a.in0 + (int64_t)c.b * a.Ni * slice_elems;
+            fsrc[k] = sp + (int64_t)(iy * a.Wi + ix) * ps0 + part * a.C0 + oct * 8;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const int iz = fz0 + fq;
+        const bool zin = (unsigned)iz < (unsigned)a.Ni && fu < uend;
+        unsigned char *slot = smem + fslot * SLOTB;
+        const int64_t zo = (int64_t)iz * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RING) ? 0 : fslot + 1;
+        if (++fq == fslices && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // operand addressing: row j of this wave, input column r, channel octet g; the lane ends up with channels 4g.. of output
+    // pixels (2*row + PY, 2*r) and (2*row + PY, 2*r + 1)
+    int pofs[MTW], voff[MTW];
+    const int lanepart = (PARTS == 2) ? (g & 1) * 16 + (g >> 1) * 8 : g * 4;
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int ty = wave * MTW + j;
+        pofs[j] = (ty * FX + r) * PIXB + g * 16;
+        voff[j] = ((2 * ty + PY) * a.Wo + 2 * r) * (PARTS * 16) + lanepart;
+    }
+    constexpr int pxstep_c = 16;   // (x PARTS) elements from output pixel 2r to 2r + 1
+
+    constexpr int INFLIGHT = RES ? (RING > 4 ? PPW : 0) : (RING - 4) * PPW;
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) issue_next();
+
+    short8 w[NCH][PARTS];
+    {
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) w[c][pt] = wp[(c * PARTS + pt) * 64];
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    int sidx = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        const int64_t obase0 = (((int64_t)U.b * a.No + U.zbeg) * a.Ho + 2 * U.gy0) * a.Wo + 2 * U.gx0;
+        for (int st = 0; st < U.nz + 2; ++st) {
+            const bool live = st < U.nz;
+            const int64_t obase = obase0 + (int64_t)st * a.Ho * a.Wo;
+            const int64_t ubase = obase * (PARTS * 16);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 rq[RES ? 2 * MTW : 1];
+            if constexpr (RES && PARTS == 2) {
+#pragma unroll
+                for (int k = 0; k < 2 * MTW; ++k) rq[k] = u32x4{0, 0, 0, 0};
+            }
+            if (RES && live && PARTS == 2) {
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        const uint16_t *rp = a.res0 + ubase + voff[j] + px * (PARTS * pxstep_c);
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[px * MTW + j]) : "v"(rp) : "memory");
+                    }
+            }
+            if (!(a.dbg & 1)) issue_next();
+
+            f32x4 acc[2][MTW];   // [x phase][row]
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) acc[px][j] = bias4;
+            if (live && !(a.dbg & 2)) {
+                int sb[3];
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    int sl = sidx + dz;
+                    if (sl >= RING) sl -= RING;
+                    sb[dz] = sl * SLOTB;
+                }
+                constexpr int RPC = MTW * PARTS;
+                constexpr int DEPTH = 2;
+                short8 x[DEPTH + 1][MTW][PARTS];
+                // chunk c < NCH0: x phase 0, (slice d, row tap rt) = (c / NROW, c % NROW), input column x;
+                // c >= NCH0: x phase 1, e = c - NCH0: (d, rt, column tap ct) = (e / (2*NROW), (e / 2) % NROW, e % 2): ct = 0 -> column x, 1 -> x+1
+                auto fetch = [&](int c, short8 (&dst)[MTW][PARTS]) {
+                    const int e = c - NCH0;
+                    const int dz = c < NCH0 ? c / NROW : e / (2 * NROW);
+                    const int rt = c < NCH0 ? c % NROW : (e / 2) % NROW;
+                    const int ct = c < NCH0 ? 0 : e % 2;
+                    const int dy = (PY && rt == 1) ? 1 : 0;
+                    const int imm = (dy * FX + ct) * PIXB;
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        const unsigned ad = lds0 + sb[dz] + pofs[j] + imm;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[j][0]) : "v"(ad));
+                        if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(PLANEB));
+                    }
+                };
+#pragma unroll
+                for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + DEPTH < NCH) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
+                    auto &xc = x[c % (DEPTH + 1)];
+                    const int ahead = (NCH - 1 - c < DEPTH ? NCH - 1 - c : DEPTH) * RPC;
+                    if (ahead == 2 * RPC) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(2 * RPC));
+                    else if (ahead == RPC) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0][0]) : "n"(RPC));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0][0]));
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt)
+                            if (j + pt) asm volatile("" : "+v"(xc[j][pt]));
+                    const int px = c < NCH0 ? 0 : 1;
+                    if constexpr (PARTS == 2) {
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) acc[px][j] = mma<F16>(w[c][1], xc[j][0], acc[px][j]);
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) acc[px][j] = mma<F16>(w[c][0], xc[j][1], acc[px][j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) acc[px][j] = mma<F16>(w[c][0], xc[j][0], acc[px][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            if constexpr (RES && PARTS == 2) {
+#pragma unroll
+                for (int k = 0; k < 2 * MTW; ++k) asm volatile("" : "+v"(rq[k]));
+            }
+            sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
+            if (!live) continue;
+            if ((a.dbg & 4) && acc[0][0][0] != 12345.f) continue;
+
+            // ---- epilogues: output pixels 2*r (px = 0) and 2*r + 1 (px = 1) of row 2*row + PY ------------------------------------
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    const int ty = wave * MTW + j;
+                    const int64_t opix = obase + (int64_t)(2 * ty + PY) * a.Wo + 2 * r + px;
+                    const int vo = voff[j] + px * (PARTS * pxstep_c);
+                    float cls = 0.f;
+                    if constexpr (RES && PARTS == 2) {
+                        const u32x4 q = rq[px * MTW + j];
+                        epilogue_quad<PREC, true, true, false>(a, acc[px][j], 0, g, opix, true, cls, make_uint4(q[0], q[1], q[2], q[3]), uint4{}, ubase, vo);
+                    } else {
+                        epilogue_quad<PREC, false, true, false>(a, acc[px][j], 0, g, opix, true, cls, uint4{}, uint4{}, ubase, vo);
+                    }
+                    epilogue_cls(a, cls, g, opix, true);
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
+}
+
 // ---- conv_roll_efd: the EFD block of the 8-channel stage (DEN.py:306-315, `FM_conv1.0`) as one rolling kernel ------------
 //     out = relu( BN(conv3x3x3 stride (1,2,2) (x)) + BN(conv3x3x3 (maxpool(1,2,2)(x))) ),   8 -> 16 channels, half resolution
 // As two launches the strided branch writes its 16-channel result and the pooled branch reads it back as a residual.  Both
@@ -857,6 +1103,38 @@ hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hi
     }
 #undef DFFW_ROLLT_LAUNCH
     return hipGetLastError();
+}
+
+void conv_roll_t32_kernel_name(int prec, int py, bool res, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll_t32<%d, %d, %d, %s>", prec, py, py ? 6 : 4, res ? "true" : "false");
+}
+
+hipError_t launch_conv_roll_t32(int prec, int py, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    const int want = t.wgs > 0 ? t.wgs : 512;
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    const bool res = a.res0 != nullptr && prec == P_BF16X3;
+#define DFFW_T32_LAUNCH(P, R)                                                                      \
+    do {                                                                                           \
+        if (py) hipLaunchKernelGGL((conv_roll_t32<P, 1, 6, R>), grid, block, 0, s, a, t);         \
+        else hipLaunchKernelGGL((conv_roll_t32<P, 0, 4, R>), grid, block, 0, s, a, t);            \
+    } while (0)
+    switch (prec) {
+        case P_BF16X3:
+            if (res) DFFW_T32_LAUNCH(P_BF16X3, true);
+            else DFFW_T32_LAUNCH(P_BF16X3, false);
+            break;
+        case P_FP16: DFFW_T32_LAUNCH(P_FP16, false); break;
+        case P_BF16: DFFW_T32_LAUNCH(P_BF16, false); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_T32_LAUNCH
+    return hipGetLastError();
+}
+
+void roll_t32_tile(int py, int *ty, int *tx) {
+    *ty = py ? 4 : 8;
+    *tx = 16;
 }
 
 void efd_roll_tile(int *ty, int *tx) {

@@ -305,6 +305,7 @@ struct PackedConv {
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
+    uint16_t *wroll_t32 = nullptr; // device: a transposed 3x3x3 32 -> 16 filter in conv_roll_t32's order (row phase 0: 9 chunks, then phase 1: 18)
     uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
     uint16_t *watt = nullptr;      // device: an 8 -> 8 attention conv (3x1x1 or 1x1x1) as srd_roll's stage-C fragments
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
@@ -333,6 +334,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll_t = nullptr;
     if (pc.wroll8) (void)hipFree(pc.wroll8);
     pc.wroll8 = nullptr;
+    if (pc.wroll_t32) (void)hipFree(pc.wroll_t32);
+    pc.wroll_t32 = nullptr;
     if (pc.wsrd) (void)hipFree(pc.wsrd);
     pc.wsrd = nullptr;
     if (pc.watt) (void)hipFree(pc.watt);
@@ -732,6 +735,37 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.wroll8, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll8, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    // ---- conv_roll_t32: transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one fragment set per output row phase py.  A chunk = one
+    // tap x 32 channels (K octet g = channel octet g).  Enumeration (must match the kernel): x phase 0 first: (window slice d,
+    // row tap rt) with filter column 1 at input column x; then x phase 1: (d, rt, ct): ct = 0 -> filter column 2 at x, ct = 1 ->
+    // filter column 0 at x+1.  Row taps: py = 0: filter row 1 at input row y; py = 1: rt = 0 -> filter row 2 at y, rt = 1 -> row 0 at y+1.
+    if (geo == G3T && cin_pad == 32 && L.cout == 16 && !getenv("DFFW_NO_ROLL_T")) {
+        std::vector<uint16_t> wr((size_t)(ROLL_CHUNKS_T32_0 + ROLL_CHUNKS_T32_1) * parts * 512, 0);
+        size_t chunk0 = 0;
+        for (int py = 0; py < 2; ++py) {
+            const int nrow = py ? 2 : 1, nch0 = 3 * nrow, nch = 9 * nrow;
+            for (int c = 0; c < nch; ++c) {
+                const int e = c - nch0;
+                const int d = c < nch0 ? c / nrow : e / (2 * nrow);
+                const int rt = c < nch0 ? c % nrow : (e / 2) % nrow;
+                const int ct = c < nch0 ? 0 : e % 2;
+                const int ky = py ? (rt == 0 ? 2 : 0) : 1, dy = (py && rt == 1) ? 1 : 0;
+                const int kx = c < nch0 ? 1 : (ct == 0 ? 2 : 0), dx = ct;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float val = (float)wval(lane & 15, (lane >> 4) * 8 + j, Tap{d - 1, dy, dx, 2 - d, ky, kx});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = ((chunk0 + c) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        if (parts == 2) wr[base + 512] = lo;
+                    }
+            }
+            chunk0 += nch;
+        }
+        HIPCHK(hipMalloc((void **)&pc.wroll_t32, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wroll_t32, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     // ---- conv_roll_t: transposed 3x3x3 s(1,2,2), 16 -> 8 channels.  Result rows 0-7 = output pixel 2x, rows 8-15 = pixel
     // 2x+1; chunk c < 3: output row phase py = 0 (filter row 1 at input row y), slice c of the window; c >= 3: py = 1,
     // slice (c-3)/2, filter row 2 at input row y ((c-3) even) or filter row 0 at input row y+1 (odd).  Lane group g
@@ -1059,6 +1093,39 @@ struct Run {
         a.zero = e->zero_page;
         { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 7) : 0; }
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
+        // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
+        if (pc.wroll_t32 && in0.C == 32 && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
+            (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= 256 && !getenv_flag("DFFW_NO_ROLL") && !getenv_flag("DFFW_NO_ROLL_T32")) {
+            if (dry) return out;
+            a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
+            a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
+            a.dbg &= 6;
+            for (int py = 0; py < 2; ++py) {
+                int rty, rtx;
+                roll_t32_tile(py, &rty, &rtx);
+                RollArgs t;
+                memset(&t, 0, sizeof t);
+                const int parts = prec_parts(e->prec);
+                t.wroll = pc.wroll_t32 + (size_t)(py ? ROLL_CHUNKS_T32_0 : 0) * parts * 512;
+                t.tiles_y = in0.H / rty;
+                t.tiles_x = in0.W / rtx;
+                t.zsplit = 1;
+                t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
+                { const char *z = getenv("DFFW_ROLL_WGS"); t.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                char kn[96];
+                conv_roll_t32_kernel_name(e->prec, py, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                g_last_kernel = kn;
+                if (e->profiling) {
+                    const double opx = (double)out.B * No * Ho * Wo * 0.5;   // this sweep's output pixels
+                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
+                                         + opx * L.cout * elem_bytes() * ((o.discard ? 0 : 1) + (o.out_pre ? 1 : 0) + (o.res0 ? 1 : 0)) + (o.cls ? opx * 4.0 : 0.0);
+                    prof_begin(kn, name + (py ? " (odd rows)" : " (even rows)"), 2.0 * (double)a.M * (py ? 18.0 : 9.0) * L.cin * L.cout, bytes);
+                }
+                check(launch_conv_roll_t32(e->prec, py, a, t, s), name.c_str());
+                prof_end();
+            }
+            return out;
+        }
         // strided 3x3x3 8 -> 16 (dres4.conv1): the single-branch form of conv_roll_efd
         {
             int ety, etx;

@@ -131,6 +131,30 @@ def test_conv_roll_transposed(eng, N, H, W, zsplit, residual, wgs, prec, monkeyp
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("N,H,W,residual,wgs", [(10, 64, 256, True, 0), (1, 128, 128, False, 8), (2, 64, 256, True, 16), (5, 128, 128, False, 24)])
+def test_conv_roll_transposed_32(eng, N, H, W, residual, wgs, prec, monkeypatch):
+    """conv_roll_t32: ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1), 32 -> 16 channels (`deconv_2`, `dres3.conv6`, DEN.py:41-48) as two
+    rolling sweeps, one per output row phase (each with only that phase's taps resident); + BN + residual + ReLU."""
+    B, cin, cout = 2, 32, 16
+    x = rnd(B, cin, N, H, W, seed=51)
+    w = rnd(cin, cout, 3, 3, 3, seed=52, scale=(2.0 / (cin * 27)) ** 0.5 * 3)
+    bn = bn_params(cout, 53)
+    res = rnd(B, cout, N, 2 * H, 2 * W, seed=54) if residual else None
+    ref = ref_bn(F.conv_transpose3d(x, w, None, (1, 2, 2), 1, (0, 1, 1)), bn)
+    ref = F.relu(ref + res) if residual else F.relu(ref)
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_t32<"), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL[prec], rel(got, ref)
+    monkeypatch.setenv("DFFW_NO_ROLL", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(alt, ref) <= TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("N,H,W,wgs", [(10, 128, 256, 0), (1, 128, 256, 8), (2, 256, 128, 16), (5, 64, 512, 24)])
 def test_conv_roll_strided(eng, N, H, W, wgs, prec, monkeypatch):
     """conv_roll_efd<..., false>: 3x3x3 stride (1,2,2) 8 -> 16 channels (dres4.conv1, DEN.py:252) as a rolling window with
