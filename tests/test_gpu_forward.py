@@ -101,12 +101,13 @@ def test_oracle_parity_fresh_inputs_and_batch_independence(lib_built):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
-@pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 3, 128, 256, 16), (3, 1, 128, 128, 0), (2, 2, 96, 288, 8)])
+@pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 3, 128, 256, 16), (3, 1, 128, 128, 0), (2, 2, 96, 288, 8), (3, 2, 352, 96, 0)])
 def test_fused_srd_block_matches_three_launch_form(lib_built, B, N, H, W, wgs, prec, monkeypatch):
     """srd_roll (dffw_srd_roll.hip): conv.0 -> conv.2 (+x) -> attention over slices -> (1,2,2) max-pool of the 8-channel
     block (DEN.py:317-330) in one persistent kernel, against the three-launch form (conv_tile x 2 + srd_attention_kernel)
     on the same input: V1 (the block's output) and V2 (fed by the pooled copy) taps.  Every slice count incl. 1 and 2,
-    non-square maps, one column per workgroup and long column streams, all three arithmetics.  The two forms round `feat`
+    non-square maps, one column per workgroup and long column streams, a column count that is not a multiple of the 8 XCD
+    ranges (3 x 352 x 96: 396 columns of the 16-channel block), all three arithmetics.  The two forms round `feat`
     differently (fp32 in LDS vs storage format in HBM), hence a tolerance instead of bit equality."""
     entries = list(graph.param_entries(graph.dff_net_convs()))
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 3, "smooth").items()}
