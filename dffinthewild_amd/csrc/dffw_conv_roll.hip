@@ -684,7 +684,8 @@ __global__ __launch_bounds__(256) void conv_roll_t32(const ConvArgs a, const Rol
             const int ci = i * 64 + lane, pix = ci >> 2, oct = ci & 3;
             const int fy = pix / FX, fx = pix - fy * FX;
             const int iy = c.gy0 + fy, ix = c.gx0 + fx;          // halo on the high side only
-            fok[k] = p < NP && pix < FPIX && iy < a.Hi && ix < a.Wi;
+            // (a 16-channel input runs on the same kernel: its channel octets 2, 3 read the zero page and carry zero weights)
+            fok[k] = p < NP && pix < FPIX && iy < a.Hi && ix < a.Wi && oct * 8 < a.C0;
             const uint16_t *sp = a.in0 + (int64_t)c.b * a.Ni * slice_elems;
             fsrc[k] = sp + (int64_t)(iy * a.Wi + ix) * ps0 + part * a.C0 + oct * 8;
         }

@@ -739,7 +739,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // tap x 32 channels (K octet g = channel octet g).  Enumeration (must match the kernel): x phase 0 first: (window slice d,
     // row tap rt) with filter column 1 at input column x; then x phase 1: (d, rt, ct): ct = 0 -> filter column 2 at x, ct = 1 ->
     // filter column 0 at x+1.  Row taps: py = 0: filter row 1 at input row y; py = 1: rt = 0 -> filter row 2 at y, rt = 1 -> row 0 at y+1.
-    if (geo == G3T && cin_pad == 32 && L.cout == 16 && !getenv("DFFW_NO_ROLL_T")) {
+    if (geo == G3T && (cin_pad == 32 || cin_pad == 16) && L.cout == 16 && !getenv("DFFW_NO_ROLL_T")) {   // (16 input channels: octets 2, 3 get zero weights)
         std::vector<uint16_t> wr((size_t)(ROLL_CHUNKS_T32_0 + ROLL_CHUNKS_T32_1) * parts * 512, 0);
         size_t chunk0 = 0;
         for (int py = 0; py < 2; ++py) {
@@ -753,7 +753,8 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 const int kx = c < nch0 ? 1 : (ct == 0 ? 2 : 0), dx = ct;
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const float val = (float)wval(lane & 15, (lane >> 4) * 8 + j, Tap{d - 1, dy, dx, 2 - d, ky, kx});
+                        const int cin = (lane >> 4) * 8 + j;
+                        const float val = cin < cin_pad ? (float)wval(lane & 15, cin, Tap{d - 1, dy, dx, 2 - d, ky, kx}) : 0.f;
                         uint16_t hi, lo;
                         host_split(prec, val, hi, lo);
                         const size_t base = ((chunk0 + c) * parts) * 512 + (size_t)lane * 8 + j;
@@ -1094,7 +1095,7 @@ struct Run {
         { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 7) : 0; }
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
-        if (pc.wroll_t32 && in0.C == 32 && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
+        if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
             (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= 256 && !getenv_flag("DFFW_NO_ROLL") && !getenv_flag("DFFW_NO_ROLL_T32")) {
             if (dry) return out;
             a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
