@@ -678,6 +678,72 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.watt, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.watt, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    // ---- of_roll (alignment network, stride-1 blocks): conv.0 with 8 (3 real) input channels -> 16: chunk k, K octet g = tap 4k + g;
+    // conv.2 16 -> 16 with the block's 1x1x1 shortcut folded in (shortcut_w): 5 chunks over t as below + ONE chunk whose K octet g
+    // = channel octet g of the block input at the centre tap
+    if (geo == G2S1 && cin_pad == 8 && L.cout == 16 && !shortcut_w) {
+        std::vector<uint16_t> wr((size_t)3 * parts * 512, 0);
+        for (int c = 0; c < 3; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int tap = 4 * c + (lane >> 4);
+                    float val = 0.f;
+                    if (tap < 9) val = (float)wval(lane & 15, j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // of_roll8: conv.2 8 -> 8 with the folded shortcut, pixel-pair form: chunk ky as for srd_roll (K octet g = input column 2*pair + g),
+    // chunk 3 = shortcut: K octet g < 2 = the 8 block-input channels of pixel 2*pair + g, seen only by that pixel's result rows
+    if (geo == G2S1 && cin_own == 8 && L.cout == 8 && shortcut_w && shortcut_cin <= 8) {
+        std::vector<uint16_t> wr((size_t)4 * parts * 512, 0);
+        for (int c = 0; c < 4; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = lane & 15, gq = lane >> 4, cout = row & 7, px = row >> 3;
+                    float val = 0.f;
+                    if (c < 3) {
+                        const int kx = gq - px;
+                        if (kx >= 0 && kx <= 2) val = (float)wval(cout, j, Tap{0, c - 1, kx - 1, 0, c, kx});
+                    } else if (gq == px && j < shortcut_cin) {
+                        val = (float)wval(cout, cin_own + j, Tap{0, 0, 0, 0, 1, 1});
+                    }
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    if (geo == G2S1 && cin_own == 16 && L.cout == 16 && shortcut_w && (shortcut_cin + 7) / 8 * 8 <= 16) {
+        std::vector<uint16_t> wr((size_t)OF_CHUNKS_B * parts * 512, 0);
+        for (int c = 0; c < OF_CHUNKS_B; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = lane & 15, gq = lane >> 4;
+                    float val = 0.f;
+                    if (c < 5) {
+                        const int tap = 2 * c + (gq >> 1);
+                        if (tap < 9) val = (float)wval(co, (gq & 1) * 8 + j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                    } else if (gq * 8 + j < shortcut_cin) {
+                        val = (float)wval(co, cin_own + gq * 8 + j, Tap{0, 0, 0, 0, 1, 1});
+                    }
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     // ---- srd_roll16: the per-slice 1x3x3 16 -> 16 convs: chunk k, K octet g = (filter tap 2k + (g >> 1), channel octet g & 1)
     if (geo == G2S1 && cin_pad == 16 && L.cout == 16 && !shortcut_w) {
         std::vector<uint16_t> wr((size_t)SRD16_CHUNKS * parts * 512, 0);
@@ -1809,6 +1875,40 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
 // resnet_block_2d_OF (End_to_End.py:135-145): relu(feature(x) + BN(conv(relu(BN(conv_s(x))))))
 static Act of_block(Run &r, const std::string &p, const Act &x) {
     ConvOpt rl; rl.relu = 1;
+    // stride-1 block with 16 output channels on whole 8 x 16 columns: conv.0, conv.2 and the shortcut in one streaming kernel
+    {
+        auto c0 = r.e->convs.find(p + ".conv.0.0"), c2 = r.e->convs.find(p + ".conv.2.0");
+        const auto end = r.e->convs.end();
+        const int co = (c0 != end) ? c0->second.def.cout : 0;
+        if (r.e->convs.find(p + ".feature") == end && c0 != end && c2 != end && c0->second.wsrd && c2->second.wsrd && (x.C == 8 || x.C == 16) &&
+            (co == 16 || (co == 8 && x.C == 8)) && c2->second.def.cout == co && c2->second.cin_all == co + x.C && x.H % 8 == 0 && x.W % 16 == 0 &&
+            (int64_t)x.B * (x.H / 8) * (x.W / 16) >= 256 && !getenv_flag("DFFW_NO_FUSED_OF") && !getenv_flag("DFFW_NO_TILE")) {
+            Act out = r.act(x.B, x.N, x.H, x.W, co);
+            if (r.ok() && !r.dry) {
+                if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return out; }
+                SrdArgs a;
+                memset(&a, 0, sizeof a);
+                a.x = x.p; a.out = out.p;
+                a.w0 = c0->second.wsrd; a.w2 = c2->second.wsrd;
+                a.b0 = c0->second.bias; a.b2 = c2->second.bias;
+                a.zero = r.e->zero_page;
+                a.B = x.B; a.N = x.N; a.H = x.H; a.W = x.W;
+                a.tiles_y = x.H / 8; a.tiles_x = x.W / 16;
+                a.total_tiles = x.B * a.tiles_y * a.tiles_x;
+                { const char *z = getenv("DFFW_SRD_WGS"); a.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                char kn[64];
+                if (co == 8) of_roll8_kernel_name(r.e->prec, kn, sizeof kn);
+                else of_roll_kernel_name(r.e->prec, x.C == 8, kn, sizeof kn);
+                g_last_kernel = kn;
+                const double px = (double)x.pixels();
+                const LayerDef &L0 = c0->second.def;
+                r.prof_begin(kn, p, 2.0 * px * (9.0 * L0.cin * co + 9.0 * co * co + (double)L0.cin * co), px * (x.C + co) * r.elem_bytes());
+                r.check(co == 8 ? launch_of_roll8(r.e->prec, a, r.s) : launch_of_roll(r.e->prec, x.C == 8, a, r.s), "of_roll");
+                r.prof_end();
+            }
+            return out;
+        }
+    }
     Act t = r.conv(p + ".conv.0.0", x, rl);
     if (r.e->convs.find(p + ".feature") == r.e->convs.end()) {   // stride-1 block: shortcut folded into conv.2 over [t | x]
         ConvOpt o; o.relu = 1; o.in1 = &x;

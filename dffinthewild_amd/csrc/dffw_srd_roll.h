@@ -28,6 +28,14 @@ void srd_roll16_tile(int *ty, int *tx);
 hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s);
 void srd_roll16_kernel_name(int prec, bool pool, char *buf, int n);
 
+// a stride-1 residual block of the alignment network (8 or 16 -> 16 channels, columns of 8 x 16 pixels): a.w0 = conv.0 as 3 (8
+// input channels: 4 taps per chunk) or 5 chunks, a.w2 = conv.2 as 5 chunks + 1 shortcut chunk (pack_conv); a.b0 / a.b2 their shifts
+constexpr int OF_CHUNKS_B = 6;
+hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s);
+void of_roll_kernel_name(int prec, bool cin8, char *buf, int n);
+// ... and the 8 -> 8 channel blocks (pixel-pair form): a.w0 = conv.0 as 3 pair-form chunks, a.w2 = conv.2 as 3 chunks + 1 shortcut chunk
+hipError_t launch_of_roll8(int prec, const SrdArgs &a, hipStream_t s);
+void of_roll8_kernel_name(int prec, char *buf, int n);
 // the attention tail of the 32-channel block on the matrix cores (no LDS; W % 16 == 0).  w3f: [3 slices][2 output tiles][part][64][8],
 // w1f: [2 channel chunks][fragment][2 output tiles][64][8] (pack_conv)
 hipError_t launch_srd_attention_mfma(int prec, const uint16_t *feat, uint16_t *out, const uint16_t *w3f, const uint16_t *w1f, int B, int N,

@@ -24,6 +24,7 @@
 // operands, exactly as in the three-launch form.
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 
 #include "dffw_device.h"
 #include "dffw_srd_roll.h"
@@ -356,6 +357,233 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
 }
 
+// ---- of_roll8: the 8-channel stride-1 residual blocks of the alignment network (`OF_feature.0`, `OF_feature.1`, full resolution) --
+// As of_roll_kernel, in srd_roll_kernel's pixel-pair form (8 output channels): stage A = conv.0 -> t in LDS, stage B = conv.2 over
+// t (3 chunks) + one chunk for the 1x1x1 shortcut (K octet 0 = the even pixel's 8 input channels, octet 1 = the odd pixel's), ReLU,
+// stores.  a.w2 = conv.2 as 3 pair-form chunks + the shortcut chunk (pack_conv).
+template <int PREC>
+__global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int C = 8, TY = 8, TX = 16, NWAVES = 4;
+    constexpr int XY = TY + 4, XX = TX + 4, XPIX = XY * XX;        // x footprint
+    constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;    // region of t that conv.2 needs
+    constexpr int PIXB = C * 2;                                    // bytes per pixel per plane
+    constexpr int NPIECE = (XPIX + 63) / 64;                       // 1 KiB wave instructions per plane (one 16-byte chunk per pixel)
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    constexpr int RX = 4;                                          // x FIFO depth
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (counted vmcnt waits)");
+    constexpr int TPLANEB = (TPIX * PIXB + 15) / 16 * 16;
+    constexpr int X_OFF = 0, T_OFF = RX * SLOTB;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[T_OFF + PARTS * TPLANEB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto lds_store8 = [&](unsigned byte_off, uint32_t v0, uint32_t v1) {
+        const u32x2 d = {v0, v1};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(lds0 + byte_off), "v"(d) : "memory");
+    };
+    auto lds_store16 = [&](unsigned byte_off, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + byte_off), "v"(v) : "memory"); };
+
+    // ---- columns of this workgroup: as conv_roll (XCD-contiguous ranges, round-robin inside the XCD) ----------------
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+
+    // ---- x FIFO: the slices of the workgroup's columns as one stream (N per column) ---------------------------------
+    const int rec = PARTS * C;                                     // 16-bit elements per pixel record
+    const int slice_elems = a.H * a.W * rec;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int pix = i * 64 + lane;
+            const int fy = pix / XX, sx = pix - fy * XX;
+            const int fx = sx < XX / 2 ? 2 * sx : 2 * (sx - XX / 2) + 1;   // LDS rows hold the even columns first, then the odd ones
+            const int iy = c.gy0 - 2 + fy, ix = c.gx0 - 2 + fx;
+            fok[k] = p < NP && pix < XPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            fsrc[k] = a.x + (int64_t)c.b * a.N * slice_elems + (int64_t)(iy * a.W + ix) * rec + part * C;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const bool zin = fu < uend;
+        unsigned char *slot = smem + X_OFF + fslot * SLOTB;
+        const int64_t zo = (int64_t)fq * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RX) ? 0 : fslot + 1;
+        if (++fq == a.N && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // ---- per-lane constants ------------------------------------------------------------------------------------------
+    // Both convs have 8 output channels: a GEMM column is a PAIR of horizontally adjacent pixels (result rows 0-7 = even
+    // pixel, 8-15 = odd pixel) contracting per filter row over the 4 input columns the pair touches (4 x 8 channels = one
+    // 32-deep chunk; K octet g = input column 2*pair + g), as in conv_roll's pair form: no dead rows, half the tiles.
+    // LDS rows (x and t) keep the even columns first, then the odd ones, so the pairs of a tile read consecutive 16-byte slots.
+    // stage A: the 10 x 18 t pixels are 90 pairs = 6 operand tiles (the last one partly idle): waves 2, 3 take two tiles
+    // each, waves 0, 1 one each (those two waves also run stage C of an earlier slice in the same phase)
+    constexpr int TA = 2;
+    const int nA = wave < 2 ? 2 : 1;
+    constexpr int APAIRS = TYT * (TXT / 2);
+    int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
+    bool ta_ok[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        const int tile = j == 0 ? wave : 4 + wave;
+        int pi = tile * 16 + r;
+        ta_ok[j] = pi < APAIRS;
+        if (pi >= APAIRS) pi = APAIRS - 1;   // idle columns recompute the last pair, nothing is stored for them
+        const int row = pi / (TXT / 2), pc = pi - row * (TXT / 2);
+        ta_y[j] = row;
+        ta_x[j] = 2 * pc + (g >> 1);        // the t pixel this lane ends up with (channels (g & 1)*4 ..)
+        pa[j] = (row * XX + ((g & 1) ? XX / 2 : 0) + pc + (g >> 1)) * PIXB;   // input column 2*pc + g of row `row`
+        ta_st[j] = T_OFF + (row * TXT + ((g >> 1) ? TXT / 2 : 0) + pc) * PIXB + (g & 1) * 8;
+    }
+    // stage B: the 8 x 16 feat pixels are 64 pairs = 4 tiles, one per wave
+    const int pb_pi = wave * 16 + r, pb_y = pb_pi / (TX / 2), pb_pc = pb_pi % (TX / 2), pb_x = 2 * pb_pc + (g >> 1);
+    const int pbo = (pb_y * TXT + ((g & 1) ? TXT / 2 : 0) + pb_pc + (g >> 1)) * PIXB;
+    // shortcut operand: K octet g < 2 = the 8 input channels of pixel 2*pair + g at the centre tap (octets 2, 3: zero weights)
+    const int pb_sc = ((pb_y + 2) * XX + ((g & 1) ? XX / 2 : 0) + pb_pc + 1) * PIXB;
+    // the two filters as MFMA A-fragments (3 chunks each) and their BatchNorm shifts
+    short8 w0[3][PARTS], w2[3][PARTS], wsc[PARTS];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) {
+            w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
+            w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
+        }
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) wsc[pt] = reinterpret_cast<const short8 *>(a.w2)[(3 * PARTS + pt) * 64 + lane];
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + (g & 1) * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + (g & 1) * 4);
+    // one operand tile: 3 chunks (filter rows) x hi/lo, read by inline asm (hipcc degrades every lgkmcnt wait to 0 and adds
+    // vmcnt(0) in front of reads of DMA-filled slots while an LDS-DMA is outstanding) and contracted as they arrive
+    auto tile_mma = [&](unsigned base, int rowB, int loB, const short8 (&wf)[3][PARTS], f32x4 acc) {
+        short8 xh[3], xl[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned ad = base + k * rowB;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
+            else xl[k] = xh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xh[0]), "+v"(xl[0]) : "n"(2 * PARTS));
+            else if (k == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xh[1]), "+v"(xl[1]) : "n"(PARTS));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[2]), "+v"(xl[2]));
+            if constexpr (PARTS == 2) {
+                acc = mma<F16>(wf[k][1], xh[k], acc);
+                acc = mma<F16>(wf[k][0], xl[k], acc);
+            }
+            acc = mma<F16>(wf[k][0], xh[k], acc);
+        }
+        return acc;
+    };
+
+    constexpr int INFLIGHT = (RX - 2) * PPW;   // slices that may stay in flight when the next one is needed
+#pragma unroll
+    for (int q = 0; q < RX - 1; ++q) issue_next();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // compiler-visible vmcnt(0): filters, shifts and the first slices
+    asm volatile("s_barrier" ::: "memory");
+
+    int xslot = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        for (int s = 0; s < a.N; ++s) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image --------------------------------
+#pragma unroll
+            for (int j = 0; j < TA; ++j) {
+                if (j >= nA) break;
+                const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], XX * PIXB, PLANEB, w0, b0);
+                const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
+                const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                if (ta_ok[j]) {
+                    uint32_t h01, h23, l01, l23;
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    lds_store8(ta_st[j], h01, h23);
+                    if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // ---- stage B: out = relu(conv.2(t) + shift + shortcut(x)) -------------------------------------------------------------
+            {
+                f32x4 acc = tile_mma(lds0 + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
+                const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_sc;
+                short8 sh, sl;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(sh) : "v"(xp));
+                if constexpr (PARTS == 2) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sl) : "v"(xp), "n"(PLANEB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh), "+v"(sl));
+                    acc = mma<F16>(wsc[1], sh, acc);
+                    acc = mma<F16>(wsc[0], sl, acc);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh));
+                }
+                acc = mma<F16>(wsc[0], sh, acc);
+                uint32_t h01, h23, l01, l23;
+                Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
+                Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
+                const int64_t pix = (((int64_t)U.b * a.N + s) * a.H + U.gy0 + pb_y) * a.W + U.gx0 + pb_x;
+                if constexpr (PARTS == 2) {
+                    swap16(h01, l01);
+                    swap16(h23, l23);
+                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C) = make_uint4(h01, h23, l01, l23);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out + pix * rec + (g & 1) * 4) = make_uint2(h01, h23);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_next();
+            xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
+}
+
 // ---- srd_roll16: the same block for the 16-channel half-resolution stage (`FM_conv1.1`) -----------------------------------
 // 16 output channels fill the MFMA result rows, so no pixel pairs: a GEMM column is one pixel, the 1x3x3 convs contract over
 // 5 chunks of (2 taps x 16 channels) (tap 9 = zeros), records are 32 bytes per plane (natural column order).  Columns are
@@ -676,6 +904,249 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- of_roll: a stride-1 residual block of the alignment network (End_to_End.py:135-145, `OF_feature.0`, `OF_feature.1`) -------
+//     out = relu( conv1x1x1(x) + BN(conv1x3x3(relu(BN(conv1x3x3(x))))) ),   8 (3 real) or 16 -> 16 channels, full resolution
+// As two launches t = relu(BN(conv(x))) went through HBM and the second conv re-read x for the folded shortcut (two 16-channel
+// stages + a mostly empty third one).  Here, as in srd_roll16: x slices stream through an LDS FIFO, stage A leaves t in LDS,
+// stage B contracts t (5 chunks) plus ONE extra chunk for the 1x1x1 shortcut (the centre pixel of x, already in LDS) and stores
+// the block's output.  Slices are independent (no attention), so a step is A -> barrier -> B -> barrier.
+template <int PREC, bool CIN8>
+__global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int C = 16, CI = CIN8 ? 8 : 16, TY = 8, TX = 16, NWAVES = 4;
+    constexpr int XY = TY + 4, XX = TX + 4, XPIX = XY * XX;
+    constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;
+    constexpr int PIXB = C * 2, XPIXB = CI * 2, XOCT = CI / 8;
+    constexpr int NPIECE = (XPIX * XOCT + 63) / 64;                // 1 KiB wave instructions per plane
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    constexpr int RX = CIN8 ? 4 : 3;
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (counted vmcnt waits)");
+    constexpr int TPLANEB = TPIX * PIXB;
+    constexpr int X_OFF = 0, T_OFF = RX * SLOTB;
+    constexpr int NCHA = CIN8 ? 3 : 5, NCHB = 5;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[T_OFF + PARTS * TPLANEB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto lds_store8 = [&](unsigned byte_off, uint32_t v0, uint32_t v1) {
+        const u32x2 d = {v0, v1};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(lds0 + byte_off), "v"(d) : "memory");
+    };
+    auto lds_store16 = [&](unsigned byte_off, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + byte_off), "v"(v) : "memory"); };
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+
+    const int rec = PARTS * C, xrec = PARTS * CI;
+    const int slice_elems = a.H * a.W * xrec;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int ci = i * 64 + lane, pix = ci / XOCT, oct = ci % XOCT;
+            const int fy = pix / XX, fx = pix - fy * XX;
+            const int iy = c.gy0 - 2 + fy, ix = c.gx0 - 2 + fx;
+            fok[k] = p < NP && pix < XPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            fsrc[k] = a.x + (int64_t)c.b * a.N * slice_elems + (int64_t)(iy * a.W + ix) * xrec + part * CI + oct * 8;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const bool zin = fu < uend;
+        unsigned char *slot = smem + X_OFF + fslot * SLOTB;
+        const int64_t zo = (int64_t)fq * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RX) ? 0 : fslot + 1;
+        if (++fq == a.N && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // stage A: the 10 x 18 t pixels are 12 operand tiles (the last one partly idle), three per wave
+    constexpr int TA = 3;
+    int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
+    bool ta_ok[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        int p = (wave * TA + j) * 16 + r;
+        ta_ok[j] = p < TPIX;
+        if (p >= TPIX) p = TPIX - 1;
+        ta_y[j] = p / TXT;
+        ta_x[j] = p - ta_y[j] * TXT;
+        pa[j] = (ta_y[j] * XX + ta_x[j]) * XPIXB + (CIN8 ? 0 : (g & 1) * 16);
+        ta_st[j] = T_OFF + p * PIXB + g * 8;
+    }
+    // K octets: 8 input channels: chunk k, octet g = filter tap 4k + g; 16 channels: (tap 2k + (g >> 1), channel octet g & 1);
+    // taps >= 9 carry zero weights
+    int tapA[NCHA], tapB[NCHB];
+#pragma unroll
+    for (int k = 0; k < NCHA; ++k) {
+        const int tap = CIN8 ? 4 * k + g : 2 * k + (g >> 1);
+        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
+        tapA[k] = (dy * XX + dx) * XPIXB;
+    }
+#pragma unroll
+    for (int k = 0; k < NCHB; ++k) {
+        const int tap = 2 * k + (g >> 1);
+        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
+        tapB[k] = (dy * TXT + dx) * PIXB;
+    }
+    // stage B: wave w = output rows 2w, 2w+1
+    constexpr int TB = 2;
+    int pbo[TB], pbx[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int fy = wave * TB + j;
+        pbo[j] = (fy * TXT + r) * PIXB + (g & 1) * 16;
+        pbx[j] = ((fy + 2) * XX + r + 2) * XPIXB + (g < XOCT ? g : 0) * 16;   // shortcut chunk: channel octet g of the centre pixel of x
+    }
+    short8 w0[NCHA][PARTS], w2[NCHB + 1][PARTS];   // conv.2: 5 chunks over t + the shortcut chunk over x
+#pragma unroll
+    for (int k = 0; k < NCHA; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < NCHB + 1; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
+    // contraction of one operand tile: chunk k reads at base + tapo[k]; inline-asm LDS reads with counted waits (see srd_roll)
+    auto tile_mma5 = [&](unsigned base, const int *tapo, int loB, const short8 (*wf)[PARTS], f32x4 acc, auto nctag) {
+        constexpr int NC = decltype(nctag)::value;
+        short8 xh[NC], xl[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const unsigned ad = base + tapo[k];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
+            else xl[k] = xh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int left = (NC - 1 - k) * PARTS;
+            if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xh[k]), "+v"(xl[k]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[k]), "+v"(xl[k]));
+            if constexpr (PARTS == 2) {
+                acc = mma<F16>(wf[k][1], xh[k], acc);
+                acc = mma<F16>(wf[k][0], xl[k], acc);
+            }
+            acc = mma<F16>(wf[k][0], xh[k], acc);
+        }
+        return acc;
+    };
+
+    constexpr int INFLIGHT = (RX - 2) * PPW;
+#pragma unroll
+    for (int q = 0; q < RX - 1; ++q) issue_next();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    int xslot = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        for (int s = 0; s < a.N; ++s) {
+            // (1) this step's x slice has landed (for every wave after the barrier); stage B of the previous step has read t
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            const unsigned xs = lds0 + X_OFF + xslot * SLOTB;
+            // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image (conv.2's padding) ------------
+#pragma unroll
+            for (int j = 0; j < TA; ++j) {
+                const f32x4 acc = tile_mma5(xs + pa[j], tapA, PLANEB, w0, b0, std::integral_constant<int, NCHA>{});
+                const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
+                const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                if (ta_ok[j]) {
+                    uint32_t h01, h23, l01, l23;
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    lds_store8(ta_st[j], h01, h23);
+                    if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // ---- stage B: out = relu(conv.2(t) + shift + shortcut(x)) -----------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                f32x4 acc = tile_mma5(lds0 + T_OFF + pbo[j], tapB, TPLANEB, w2, b2, std::integral_constant<int, NCHB>{});
+                {   // the shortcut chunk: centre pixel of x, its channel octets as K octets (weights of absent octets are zeros)
+                    short8 sh, sl;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(sh) : "v"(xs + pbx[j]));
+                    if constexpr (PARTS == 2) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sl) : "v"(xs + pbx[j]), "n"(PLANEB));
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh), "+v"(sl));
+                        acc = mma<F16>(w2[NCHB][1], sh, acc);
+                        acc = mma<F16>(w2[NCHB][0], sl, acc);
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh));
+                    }
+                    acc = mma<F16>(w2[NCHB][0], sh, acc);
+                }
+                uint32_t h01, h23, l01, l23;
+                Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
+                Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
+                const int64_t pix = (((int64_t)U.b * a.N + s) * a.H + U.gy0 + wave * TB + j) * a.W + U.gx0 + r;
+                if constexpr (PARTS == 2) {
+                    swap16(h01, l01);
+                    swap16(h23, l23);
+                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+                }
+            }
+            // (3) the x slot is free: queue the slice RX-1 ahead into it
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_next();
+            xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- srd_attention_mfma: the attention tail of the 32-channel SRD block (`FM_conv2.1.N_ch_attention`) on the matrix cores ------
 //     out = feat + relu(conv1x1x1(relu(conv3x1x1(feat))))     (DEN.py:322-329; no BatchNorm, no bias)
 // The fused VALU kernel (srd_attention_kernel) stops at 16 channels (C*C*4 FMAs per pixel); at 32 channels the two convs ran as
@@ -832,6 +1303,42 @@ hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_SRD16_LAUNCH
+    return hipGetLastError();
+}
+
+void of_roll8_kernel_name(int prec, char *buf, int n) { snprintf(buf, n, "dffw::of_roll8_kernel<%d>", prec); }
+
+hipError_t launch_of_roll8(int prec, const SrdArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : 768;
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    switch (prec) {
+        case P_BF16X3: hipLaunchKernelGGL((of_roll8_kernel<P_BF16X3>), grid, block, 0, s, a); break;
+        case P_FP16: hipLaunchKernelGGL((of_roll8_kernel<P_FP16>), grid, block, 0, s, a); break;
+        case P_BF16: hipLaunchKernelGGL((of_roll8_kernel<P_BF16>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+void of_roll_kernel_name(int prec, bool cin8, char *buf, int n) { snprintf(buf, n, "dffw::of_roll_kernel<%d, %s>", prec, cin8 ? "true" : "false"); }
+
+hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : (cin8 ? 768 : 512);
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+#define DFFW_OF_LAUNCH(P)                                                                   \
+    do {                                                                                    \
+        if (cin8) hipLaunchKernelGGL((of_roll_kernel<P, true>), grid, block, 0, s, a);      \
+        else hipLaunchKernelGGL((of_roll_kernel<P, false>), grid, block, 0, s, a);          \
+    } while (0)
+    switch (prec) {
+        case P_BF16X3: DFFW_OF_LAUNCH(P_BF16X3); break;
+        case P_FP16: DFFW_OF_LAUNCH(P_FP16); break;
+        case P_BF16: DFFW_OF_LAUNCH(P_BF16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_OF_LAUNCH
     return hipGetLastError();
 }
 

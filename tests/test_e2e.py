@@ -151,6 +151,34 @@ def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (2, 128, 256)])
+def test_hip_e2e_fused_alignment_blocks_match_two_launch_form(lib_built, monkeypatch, B, H, W, precision):
+    """of_roll8 / of_roll (dffw_srd_roll.hip): the stride-1 residual blocks of the alignment network (End_to_End.py:135-145:
+    OF_feature.0, OF_feature.1 at full resolution, OF_feature1.1 at half) as one streaming kernel each (conv.0 -> t in LDS ->
+    conv.2 + 1x1x1 shortcut), against the two-launch form on shapes large enough for whole-column grids, and against the oracle."""
+    g, sd, FS, fd, fov = load(SMOOTH[0])
+    from dffinthewild_amd import synth
+    FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=91))
+    fd = fd[:1].expand(B, -1, -1, -1).contiguous()
+    fov = fov[:1].expand(B, -1, -1, -1, -1).contiguous()
+    with torch.no_grad():
+        outs, taps = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
+        monkeypatch.setenv("DFFW_NO_FUSED_OF", "1")
+        outs2, taps2 = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
+    tol = {"bf16x3": 1e-4, "fp16": 2e-2, "bf16": 1e-1}[precision]
+    for tag in ("head3", "head2", "head1", "alpha"):
+        err = cpu_ref.rel_l2(taps[tag].cpu(), taps2[tag].cpu())
+        assert err <= tol, (tag, err)
+    assert cpu_ref.rel_l2(taps["head1"].cpu(), taps2["head1"].cpu()) > 0      # 0 would mean both runs took the same path
+    if precision == "bf16x3" and B == 1:
+        with torch.no_grad():
+            ref = cpu_ref.e2e_forward(cpu_ref.to_torch_state(sd), FS, fd, fov)
+        for name, o, r in zip(OUT_NAMES, outs, ref):
+            assert cpu_ref.rel_l2(o.cpu(), r) <= 1e-3, name
+
+
+@pytest.mark.gpu
 def test_hip_e2e_call_contract(lib_built):
     """TRS.py:31-37,44 call sequence (DataParallel wrap, module.-prefixed checkpoint) and the error behaviour."""
     import torch.nn as nn
