@@ -745,8 +745,10 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- srd_roll16: the per-slice 1x3x3 16 -> 16 convs: chunk k, K octet g = (filter tap 2k + (g >> 1), channel octet g & 1)
+    // (packed with a sixth, all-zero chunk: the same buffer then serves as the second conv of of_roll_kernel, whose shortcut chunk
+    // it leaves empty, for plain conv -> conv chains such as the alignment heads' .2.0 -> .4.0)
     if (geo == G2S1 && cin_pad == 16 && L.cout == 16 && !shortcut_w) {
-        std::vector<uint16_t> wr((size_t)SRD16_CHUNKS * parts * 512, 0);
+        std::vector<uint16_t> wr((size_t)OF_CHUNKS_B * parts * 512, 0);
         for (int c = 0; c < SRD16_CHUNKS; ++c)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
@@ -2003,10 +2005,43 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             y0 = r.conv(hp + ".0.0", vol, rl);
             r.drop(vol);
         }
-        Act y1 = r.conv(hp + ".2.0", y0, rl);
-        r.drop(y0);
-        Act y2 = r.conv(hp + ".4.0", y1, rl);
-        r.drop(y1);
+        Act y2;
+        {
+            // two 16 -> 16 per-slice convs in a row (level-1 head at full resolution): one streaming kernel, the intermediate in LDS
+            auto c2 = r.e->convs.find(hp + ".2.0"), c4 = r.e->convs.find(hp + ".4.0");
+            const auto end = r.e->convs.end();
+            if (y0.C == 16 && c2 != end && c4 != end && c2->second.wsrd && c4->second.wsrd && c2->second.def.cout == 16 && c4->second.def.cout == 16 &&
+                c2->second.cin_all == 16 && c4->second.cin_all == 16 && y0.H % 8 == 0 && y0.W % 16 == 0 &&
+                (int64_t)y0.B * (y0.H / 8) * (y0.W / 16) >= 256 && !getenv_flag("DFFW_NO_FUSED_OF") && !getenv_flag("DFFW_NO_TILE")) {
+                y2 = r.act(y0.B, y0.N, y0.H, y0.W, 16);
+                if (r.ok() && !r.dry) {
+                    if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return r.err; }
+                    SrdArgs a;
+                    memset(&a, 0, sizeof a);
+                    a.x = y0.p; a.out = y2.p;
+                    a.w0 = c2->second.wsrd; a.w2 = c4->second.wsrd;
+                    a.b0 = c2->second.bias; a.b2 = c4->second.bias;
+                    a.zero = r.e->zero_page;
+                    a.B = y0.B; a.N = y0.N; a.H = y0.H; a.W = y0.W;
+                    a.tiles_y = y0.H / 8; a.tiles_x = y0.W / 16;
+                    a.total_tiles = y0.B * a.tiles_y * a.tiles_x;
+                    { const char *z = getenv("DFFW_SRD_WGS"); a.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                    char kn2[64];
+                    of_roll_kernel_name(prec, false, kn2, sizeof kn2);
+                    g_last_kernel = kn2;
+                    const double px = (double)y0.pixels();
+                    r.prof_begin(kn2, hp + ".2.0+.4.0", 2.0 * px * 2 * 9.0 * 16 * 16, px * 32 * r.elem_bytes());
+                    r.check(launch_of_roll(prec, false, a, r.s), "of_roll (head)");
+                    r.prof_end();
+                }
+                r.drop(y0);
+            } else {
+                Act y1 = r.conv(hp + ".2.0", y0, rl);
+                r.drop(y0);
+                y2 = r.conv(hp + ".4.0", y1, rl);
+                r.drop(y1);
+            }
+        }
         const int64_t hw = (int64_t)y2.H * y2.W;
         float *hf = (float *)r.raw(na * hw * sizeof(float));
         ConvOpt of; of.outf = hf; of.outf_ch = 3;
