@@ -1762,10 +1762,14 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     const std::string P = "DFF_net";
     const int prec = r.e->prec;
     ConvOpt rl; rl.relu = 1;
-    // below ~3M stack pixels (batch <= 4 at 10x256x256) the low-resolution layers cannot fill 256 CUs on their own:
-    // the three pyramid scales then run side by side (measured +7 % at batch 1, +5 % at batch 4; the regression
-    // heads on a side stream gained nothing)
-    if ((int64_t)B * N * H * W < (3 << 20) && !getenv_flag("DFFW_NO_CONCURRENT")) r.enable_concurrency();
+    // the low-resolution layers of the pyramid cannot fill 256 CUs on their own (at batch 32 its 1/32-resolution scale is
+    // 128 tiles per launch): the three pyramid scales run side by side on the main + two side streams (measured +7 % at
+    // batch 1, +5 % at batch 4, +4 % at batch 8, +1..2.5 % at batch 32; the regression heads on a side stream gained
+    // nothing).  DFFW_CONCURRENT_MAX_PIXELS restricts it to stacks below that many pixels.
+    {
+        const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS");
+        if ((!z || (int64_t)B * N * H * W < atoll(z)) && !getenv_flag("DFFW_NO_CONCURRENT")) r.enable_concurrency();
+    }
 
     // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80
     const std::string stem_name = P + ".FM_measure.Focus_extraction.0.0";
