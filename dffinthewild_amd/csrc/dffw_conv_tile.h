@@ -12,6 +12,8 @@ enum Geo {
     G2S1 = 3,  // 1x3x3 per-slice conv, pad (0,1,1)           (6 layers)
     G2D = 4,   // the stem: 1x9x9, dilation (1,2,2), pad (0,8,8), on the paired-pixel (W+2)-wide input (see stack_in)
     G2S2 = 5,  // 1x3x3 per-slice conv, stride (1,2,2), pad (0,1,1): the down-sampling blocks of the alignment network
+    G2P = 6,   // the stem in pixel-pair form: result rows 0-7 = the 8 channels of pixel x, rows 8-15 = of pixel x+2 (both see the
+               // same five paired-pixel records per filter row); reads the fp32 / raw focal stack only (no record volume)
     GEO_COUNT = 6
 };
 
@@ -29,6 +31,7 @@ inline GeoInfo geo_info(int geo) {
         case G3T: return GeoInfo{-1, 1, 0, 1, 0, 1, 1, 2, 4};
         case G2D: return GeoInfo{0, 0, -8, 8, -6, 10, 1, 1, 1};
         case G2S2: return GeoInfo{0, 0, -1, 1, -1, 1, 2, 1, 1};
+        case G2P: return GeoInfo{0, 0, -8, 8, -6, 10, 1, 1, 1};
         default: return GeoInfo{0, 0, -1, 1, -1, 1, 1, 1, 1};
     }
 }

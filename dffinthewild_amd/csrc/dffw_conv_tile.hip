@@ -40,6 +40,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
     constexpr int MTW = T::MT / NWAVES;  // operand tiles (16 grid points) per wave
+    constexpr bool STEM = (GEO == G2D || GEO == G2P);   // the stem, per pixel or (STEMP) per pixel pair
+    constexpr bool STEMP = (GEO == G2P);
     constexpr int CG8 = CG / 8;
 
     // LDS image: PARTS planes (hi, lo) of [footprint pixel][CG channels], 16-bit.  With CG = 8 a pixel is
@@ -105,10 +107,22 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
         const int p = (wave * MTW + j) * 16 + r;
-        const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
-        pofs[j] = ((tz * T::FY + ty * G::S) * T::FXL + tx) * PIXB;
-        voff[j] = ((tz * a.Ho + ty * G::OS) * a.Wo + tx * G::OS) * (PARTS * a.Cout) + lanepart;
-        tcrd[j] = tx | (ty << 8) | (tz << 16);
+        if constexpr (STEMP) {
+            // pair k of a row = pixels (x, x+2) with x = (k & 1) + 4 * (k >> 1); its records sit at packed column k (+ jx per
+            // filter column pair).  Lane rows 0-1 (g = 0, 1) end up with pixel x, rows 2-3 with pixel x+2: each as "row g & 1"
+            // of its own 8-channel record.
+            constexpr int HP = TX / 2;
+            const int k = p % HP, ty = (p / HP) % TY, tz = p / (HP * TY);
+            const int tx = (k & 1) + 4 * (k >> 1) + 2 * (g >> 1);
+            pofs[j] = ((tz * T::FY + ty) * T::FXL + k) * PIXB;
+            voff[j] = ((tz * a.Ho + ty) * a.Wo + tx) * (PARTS * 8) + ((PARTS == 2) ? (g & 1) * 8 : (g & 1) * 4);
+            tcrd[j] = tx | (ty << 8) | (tz << 16);
+        } else {
+            const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+            pofs[j] = ((tz * T::FY + ty * G::S) * T::FXL + tx) * PIXB;
+            voff[j] = ((tz * a.Ho + ty * G::OS) * a.Wo + tx * G::OS) * (PARTS * a.Cout) + lanepart;
+            tcrd[j] = tx | (ty << 8) | (tz << 16);
+        }
     }
     // BatchNorm shift of this lane's 4 output channels per 16-channel tile: the accumulators start from it
     // (not for the 4-pass transposed conv: there hipcc then allocates three accumulator sets)
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     const Coord cur = decode(tile);
     // split-K (few-tile layers with a deep contraction, see Run::conv): blockIdx.z owns a contiguous range of the
     // channel-group stages and writes raw fp32 partial sums; splitk_finish adds them up and runs the epilogue
-    const bool splitk = SPLITK && GEO != G2D && t.ksplit > 1;
+    const bool splitk = SPLITK && !STEM && t.ksplit > 1;
     const int st_lo = splitk ? (int)blockIdx.z * t.nstage / t.ksplit : 0;
     const int st_hi = splitk ? ((int)blockIdx.z + 1) * t.nstage / t.ksplit : t.nstage;
     // pass split (transposed conv, few tiles): the 4 sub-pixel passes write disjoint output phases, so they can be
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
         const int W = a.Wi - 2;
         const int64_t plane = (int64_t)a.Ni * a.Hi * W;
         const float *src = a.fs32 + (int64_t)c.b * 3 * plane + (int64_t)c.gz0 * a.Hi * W;
-        constexpr bool rawmode = (GEO == G2D) && SPLITK;   // the stem's "SPLITK" instantiation is its raw-source variant (it never splits K)
+        constexpr bool rawmode = STEM && SPLITK;   // the stem's "SPLITK" instantiation is its raw-source variant (it never splits K)
         RawStack rs{};
         if constexpr (rawmode) rs = *reinterpret_cast<const RawStack *>(a.fs32);   // wave-uniform: scalar loads
         const int64_t rbase = c.b * rs.sb + c.gz0 * rs.sn;
@@ -221,7 +235,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
         for (int it = 0; it < NIT; ++it) {
             const int p = tid + it * NWAVES * 64;
             if (p >= T::FPIX) break;
-            const int fy = p / T::FXL, fx = p - fy * T::FXL;
+            const int fy = p / T::FXL, fl = p - fy * T::FXL;
+            const int fx = STEMP ? 4 * (fl >> 1) + (fl & 1) : fl;   // pair form keeps the footprint columns = 0,1 mod 4 only
             const int iy = iy0 + fy, q = ix0 + fx;
             short8 h = short8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
             if ((unsigned)iy < (unsigned)a.Hi) {
@@ -241,9 +256,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
         }
     };
     bool from_stack = false;
-    if constexpr (GEO == G2D) from_stack = a.fs32 != nullptr;
+    if constexpr (STEM) from_stack = STEMP || a.fs32 != nullptr;
     if (from_stack) {
-        if constexpr (GEO == G2D) fill_from_stack(cur);
+        if constexpr (STEM) fill_from_stack(cur);
     } else if (!(a.dbg & 1)) {
         issue_fill(cur, st_lo);
     }
@@ -435,6 +450,18 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                         for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4 *>(pz + opix * cpad + (ntb + nt) * 16 + g * 4) = acc[nt][j];
                     }
                 }
+            } else if (STEMP) {
+                // pixel-pair stem: lane rows 0-1 hold pixel x's 8 channels, rows 2-3 pixel x+2's -- each lane is "row g & 1" of
+                // its own pixel's record, the packed form of the 8-channel epilogue with no register shuffling
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    int64_t opix;
+                    const bool pv = where(j, opix);
+                    float cls = 0.f;
+                    epilogue_quad<PREC, false, true, !BIAS_IN_ACC>(a, acc[0][j], 0, g & 1, opix, pv, cls, uint4{}, uint4{}, ubase, voff[j]);
+                    epilogue_cls(a, cls, g, opix, pv, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else if (NT == 1 && a.Cout == 8 && !a.outf) {
                 // 8 output channels occupy only lane rows 0-1 of a result tile: pack operand tiles j and j+1 into
                 // one register set (rows 2-3 <- rows 0-1 of tile j+1, v_permlane32_swap) and run ONE epilogue for both
@@ -531,7 +558,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(22, G2S2, 2, 5, 4, 16, 8, 0)   \
     X(23, G3T, 1, 5, 4, 16, 32, 0)   \
     X(24, G3T, 2, 5, 4, 16, 32, 1)   \
-    X(25, G3T, 4, 5, 4, 16, 32, 1)
+    X(25, G3T, 4, 5, 4, 16, 32, 1)   \
+    X(32, G2P, 1, 1, 16, 32, 8, 0)
 // 8-wave "wide" variants: 640-point tiles, same work per wave.  Measured +8..17 % on the bandwidth-bound
 // single-stage layers with <= 16 output channels (one more resident wave per SIMD for the same LDS, 17 % less
 // halo per output), -10 % on the 32-channel / multi-stage ones, so the engine asks for them only for the former.
@@ -541,7 +569,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(28, G2S1, 1, 5, 8, 16, 8, 0)   \
     X(29, G2S1, 1, 5, 8, 16, 16, 0)  \
     X(30, G2S1, 2, 5, 8, 16, 16, 1)  \
-    X(31, G2D, 1, 1, 32, 32, 8, 0)
+    X(31, G2D, 1, 1, 32, 32, 8, 0)   \
+    X(33, G2P, 1, 1, 32, 32, 8, 0)
 
 // the 4-wave configurations few-tile layers end up on after the channel split (3x3x3 at stride 1 and 2, <= 32 output
 // channels per workgroup): these also exist as split-K kernels
@@ -626,6 +655,12 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
             break;
         case 2000 + 31:
             hipLaunchKernelGGL((conv_tile<PREC, G2D, 1, 1, 32, 32, 8, 0, 8, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, 1), dim3(512), 0, s, a, t);
+            break;
+        case 2000 + 32:
+            hipLaunchKernelGGL((conv_tile<PREC, G2P, 1, 1, 16, 32, 8, 0, 4, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, 1), dim3(256), 0, s, a, t);
+            break;
+        case 2000 + 33:
+            hipLaunchKernelGGL((conv_tile<PREC, G2P, 1, 1, 32, 32, 8, 0, 8, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, 1), dim3(512), 0, s, a, t);
             break;
         default: return hipErrorInvalidValue;
     }

@@ -300,6 +300,8 @@ struct PackedConv {
     float *bias = nullptr;  // device, nt*16 floats
     std::vector<Variant> variants;
     TilePack tile;
+    TilePack tile_pair;     // the stem once more, for the pixel-pair kernel (G2P); bias_pair = its BatchNorm shift for both pixels' rows
+    float *bias_pair = nullptr;
     float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
@@ -319,13 +321,17 @@ static void free_packed(PackedConv &pc) {
     }
     pc.variants.clear();
     pc.bias = nullptr;
-    for (int i = 0; i < 4; ++i) {
-        if (pc.tile.tab[i]) (void)hipFree(pc.tile.tab[i]);
-        if (pc.tile.wpk[i]) (void)hipFree(pc.tile.wpk[i]);
-        pc.tile.tab[i] = nullptr;
-        pc.tile.wpk[i] = nullptr;
+    for (TilePack *tp : {&pc.tile, &pc.tile_pair}) {
+        for (int i = 0; i < 4; ++i) {
+            if (tp->tab[i]) (void)hipFree(tp->tab[i]);
+            if (tp->wpk[i]) (void)hipFree(tp->wpk[i]);
+            tp->tab[i] = nullptr;
+            tp->wpk[i] = nullptr;
+        }
+        tp->cfg = nullptr;
     }
-    pc.tile.cfg = nullptr;
+    if (pc.bias_pair) (void)hipFree(pc.bias_pair);
+    pc.bias_pair = nullptr;
     if (pc.w32) (void)hipFree(pc.w32);
     pc.w32 = nullptr;
     if (pc.wroll) (void)hipFree(pc.wroll);
@@ -368,6 +374,12 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     for (int c = 0; c < L.cout; ++c) bias[c] = (float)shift[c];
     HIPCHK(hipMalloc((void **)&pc.bias, bias.size() * sizeof(float)));
     HIPCHK(hipMemcpy(pc.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (L.cout == 8 && pc.nt == 1) {   // pixel-pair kernels: rows 8-15 are the second pixel's 8 channels
+        std::vector<float> b2(16);
+        for (int c = 0; c < 16; ++c) b2[c] = (float)shift[c & 7];
+        HIPCHK(hipMalloc((void **)&pc.bias_pair, b2.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(pc.bias_pair, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
 
     // The stem reads the paired-pixel (W+2)-wide volume written by stack_in: pixel p lives in the first half
     // of record p+2, so every x-offset of its taps is shifted by +2.
@@ -500,10 +512,10 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         if (geo == G3T && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;
         // wide (8-wave, 640-point) tile wherever an instantiation exists (dffw_conv_tile.hip lists what was measured)
         const bool wide = !getenv("DFFW_NO_WIDE");
-        const TileCfg *cfg = tile_cfg_find(geo, pc.nt, cg, wide);
-        if (cfg && cin_t % cg == 0) {
-            const GeoInfo gi = geo_info(geo);
-            TilePack &tp = pc.tile;
+        // pair: the stem's pixel-pair form (G2P) -- result rows 8-15 carry the filter as pixel x+2 sees the same records, and the
+        // LDS image keeps only the footprint columns = 0,1 mod 4 (tap offsets in packed columns)
+        auto pack_tile = [&](TilePack &tp, const TileCfg *cfg, int cg, bool pair) -> int {
+            const GeoInfo gi = geo_info(cfg->geo);
             tp.cfg = cfg;
             tp.nstage = cin_t / cg;
             tp.npass = (int)tapsets.size();
@@ -520,7 +532,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 for (int k8 = 0; k8 < K8; ++k8) {
                     const Tap &tpp = taps[k8 / cg8];
                     const int dzz = tpp.dz - gi.minz, dyy = tpp.dy - gi.miny, dxx = tpp.dx - gi.minx;
-                    const int lx = (gi.s == 2) ? ((dxx & 1) * (cfg->fxl / 2) + (dxx >> 1)) : dxx;
+                    const int lx = pair ? dxx / 2 : ((gi.s == 2) ? ((dxx & 1) * (cfg->fxl / 2) + (dxx >> 1)) : dxx);
                     tab[k8] = ((dzz * cfg->fy + dyy) * cfg->fxl + lx) * (cg * 2) + (k8 % cg8) * 16;
                 }
                 std::vector<uint16_t> wpk((size_t)tp.nstage * KC * pc.nt * parts * 512, 0);
@@ -533,6 +545,15 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                                     const int k = kc * 32 + (lane >> 4) * 8 + j;
                                     const int tapi = k / cg, cin = st * cg + k % cg;
                                     float val = 0.f;
+                                    if (pair) {
+                                        // row half h = pixel x + 2h: the record's pixels are filter columns (jx - h, jx + 1 - h) for it
+                                        const int h = (lane & 15) >> 3;
+                                        if (tapi < (int)taps.size() && (cin & 3) != 3) {
+                                            Tap u = taps[tapi];
+                                            u.kx = taps[tapi].kx + (cin >= 4 ? 1 : 0) - h;
+                                            if (u.kx >= 0 && u.kx <= 8) val = (float)wval(cout & 7, cin & 3, u);
+                                        }
+                                    } else
                                     if (cout < L.cout && tapi < (int)taps.size()) val = (float)wval_t(cout, cin, taps[tapi]);
                                     uint16_t hi, lo;
                                     host_split(prec, val, hi, lo);
@@ -545,6 +566,17 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 HIPCHK(hipMalloc((void **)&tp.wpk[ps], wpk.size() * sizeof(uint16_t)));
                 HIPCHK(hipMemcpy(tp.wpk[ps], wpk.data(), wpk.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             }
+            return DFFW_OK;
+        };
+        const TileCfg *cfg = tile_cfg_find(geo, pc.nt, cg, wide);
+        if (cfg && cin_t % cg == 0) {
+            const int rc = pack_tile(pc.tile, cfg, cg, false);
+            if (rc != DFFW_OK) return rc;
+        }
+        const TileCfg *pcfg = (stem && L.cout == 8 && !getenv("DFFW_NO_STEM_PAIR")) ? tile_cfg_find(G2P, 1, 8, wide) : nullptr;
+        if (pcfg) {
+            const int rc = pack_tile(pc.tile_pair, pcfg, 8, true);
+            if (rc != DFFW_OK) return rc;
         }
     }
     // ---- third packing: conv_roll (rolling window along the slices) for the 16-channel 3x3x3 stride-1 layers ------
@@ -1264,7 +1296,11 @@ struct Run {
                 return out;
             }
         }
-        const TilePack &tp = pc.tile;
+        // the stem straight from the focal stack: pixel-pair form (half the MFMAs and LDS reads of the per-pixel kernel)
+        const bool stem_pair = o.fs32 && pc.tile_pair.cfg && pc.bias_pair && Wo % pc.tile_pair.cfg->tx == 0 && Ho % pc.tile_pair.cfg->ty == 0 &&
+                               !getenv_flag("DFFW_NO_STEM_PAIR");
+        if (stem_pair) a.bias = pc.bias_pair;
+        const TilePack &tp = stem_pair ? pc.tile_pair : pc.tile;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
         // rolling-window kernel: 16-channel 3x3x3 stride-1 layers whose grid is whole columns and fills the chip
         {
