@@ -230,6 +230,42 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             return __fsub_rn(__fdiv_rn(v, 127.5f), 1.0f);       // float32 divide, then subtract: as dffw_pack_stack / the loaders
         };
         const int iy0 = c.gy0 + G::MINY, ix0 = c.gx0 + G::MINX;
+        if constexpr (STEMP && !rawmode) {
+            // pair form from the fp32 stack: the records at packed columns 2m, 2m+1 of a row are pixels (4m-2, 4m) and
+            // (4m-1, 4m+1) past the footprint origin = the 4 consecutive, 16-byte aligned pixels from column gx0 - 8 + 4m:
+            // one float4 load per colour plane makes two records, and a quad is inside the image or outside it as a whole
+            constexpr int QR = T::FXL / 2, NQ = T::FY * QR;
+            constexpr int NITQ = (NQ + NWAVES * 64 - 1) / (NWAVES * 64);
+#pragma unroll
+            for (int it = 0; it < NITQ; ++it) {
+                const int p2 = tid + it * NWAVES * 64;
+                if (p2 >= NQ) break;
+                const int fy = p2 / QR, m = p2 - fy * QR;
+                const int iy = iy0 + fy, x = c.gx0 - 8 + 4 * m;
+                const bool in = (unsigned)iy < (unsigned)a.Hi && (unsigned)x < (unsigned)W;
+                short8 ha = short8{0, 0, 0, 0, 0, 0, 0, 0}, la = ha, hb = ha, lb = ha;
+                if (in) {
+                    const float *sp = src + (int64_t)iy * W + x;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(sp + ch * plane);
+                        uint16_t hi, lo;
+                        Fmt<PREC>::split(v[0], hi, lo); ha[ch] = (short)hi; la[ch] = (short)lo;
+                        Fmt<PREC>::split(v[2], hi, lo); ha[4 + ch] = (short)hi; la[4 + ch] = (short)lo;
+                        Fmt<PREC>::split(v[1], hi, lo); hb[ch] = (short)hi; lb[ch] = (short)lo;
+                        Fmt<PREC>::split(v[3], hi, lo); hb[4 + ch] = (short)hi; lb[4 + ch] = (short)lo;
+                    }
+                }
+                unsigned char *dst = smem + (fy * T::FXL + 2 * m) * PIXB;
+                *reinterpret_cast<short8 *>(dst) = ha;
+                *reinterpret_cast<short8 *>(dst + PIXB) = hb;
+                if constexpr (PARTS == 2) {
+                    *reinterpret_cast<short8 *>(dst + PLANEB) = la;
+                    *reinterpret_cast<short8 *>(dst + PLANEB + PIXB) = lb;
+                }
+            }
+            return;
+        }
         constexpr int NIT = (T::FPIX + NWAVES * 64 - 1) / (NWAVES * 64);
 #pragma unroll   // constant trip count: the loads of all iterations can be in flight together
         for (int it = 0; it < NIT; ++it) {
