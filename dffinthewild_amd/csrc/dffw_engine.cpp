@@ -573,7 +573,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
             const int rc = pack_tile(pc.tile, cfg, cg, false);
             if (rc != DFFW_OK) return rc;
         }
-        const TileCfg *pcfg = (stem && L.cout == 8 && !getenv("DFFW_NO_STEM_PAIR")) ? tile_cfg_find(G2P, 1, 8, wide) : nullptr;
+        const TileCfg *pcfg = (stem && L.cout == 8 && !getenv("DFFW_NO_STEM_PAIR")) ? tile_cfg_find(G2P, 1, 8, wide && !getenv("DFFW_STEM_NARROW")) : nullptr;
         if (pcfg) {
             const int rc = pack_tile(pc.tile_pair, pcfg, 8, true);
             if (rc != DFFW_OK) return rc;
