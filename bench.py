@@ -96,6 +96,9 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
                              "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
                              "share_of_forward_time": round(conv_ms / total_ms, 3)},
         "profiled_forward_ms": round(total_ms, 3), "n_launches": len(rows),
+        "durations": "HIP events around every launch of one extra forward after the timed region, on the launch stream; in this "
+                     "profiling mode the engine runs the pyramid's three scales one after the other (side by side, as in the timed "
+                     "steps, small kernels share the chip and a launch's duration is not the kernel's own)",
     }
     # the heaviest kernel that is MFMA-bound by the same criterion (the 3x3x3 aggregation convs of the north star)
     mf = {k: a for k, a in conv.items() if fractions(a)[2] > fractions(a)[3]}

@@ -1804,7 +1804,8 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     // nothing).  DFFW_CONCURRENT_MAX_PIXELS restricts it to stacks below that many pixels.
     {
         const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS");
-        if ((!z || (int64_t)B * N * H * W < atoll(z)) && !getenv_flag("DFFW_NO_CONCURRENT")) r.enable_concurrency();
+        // (not in profiling mode: the per-launch event durations are meant to be each kernel's own)
+        if ((!z || (int64_t)B * N * H * W < atoll(z)) && !getenv_flag("DFFW_NO_CONCURRENT") && !r.e->profiling) r.enable_concurrency();
     }
 
     // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80

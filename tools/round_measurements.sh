@@ -13,7 +13,11 @@ python bench.py --batch 8 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 
 python bench.py --input u8 --steps 10 --warmup 3 > $out/bench_u8.json 2>/dev/null
 python bench.py --workload e2e --dump-layers $out/layers_e2e.tsv > $out/bench_e2e.json 2>/dev/null
 python bench.py --workload e2e --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > $out/bench_e2e_b1.json 2>/dev/null
+# kernel durations: with the pyramid branches serialised, as in bench.py's own profiled forward (side by side, three small kernels
+# share the chip and each one's duration says nothing about the kernel)
+export DFFW_NO_CONCURRENT=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/rocprof_bench.json 2> $out/rocprof.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+unset DFFW_NO_CONCURRENT
 for f in $out/bench_*.json; do echo "$f: $(cut -c1-110 $f)"; done
