@@ -100,6 +100,14 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
                      "profiling mode the engine runs the pyramid's three scales one after the other (side by side, as in the timed "
                      "steps, small kernels share the chip and a launch's duration is not the kernel's own)",
     }
+    # whole forward against its layer-by-layer roofline: sum over launches of max(MFMA time, HBM time) with each launch's
+    # algorithmic FLOPs (x3 MFMA issue in the split-bf16 mode) and algorithmic bytes ("the exact ceiling is the
+    # per-layer sum of max(.,.)")
+    issue = 3.0 if precision == "bf16x3" else 1.0
+    bound_ms = sum(max(flops * issue / (PEAK_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)) for _, _, flops, nbytes, _ in rows) * 1e3
+    roof["forward_vs_layerwise_roofline"] = {"bound_ms": round(bound_ms, 3), "measured_ms": round(total_ms, 3), "frac": round(bound_ms / total_ms, 4),
+                                             "definition": "sum over the launches of max(algorithmic FLOPs x MFMA issues per product / dense peak, "
+                                                           "algorithmic bytes / 8 TB/s) / sum of the launches' measured durations"}
     # the heaviest kernel that is MFMA-bound by the same criterion (the 3x3x3 aggregation convs of the north star)
     mf = {k: a for k, a in conv.items() if fractions(a)[2] > fractions(a)[3]}
     if mf:

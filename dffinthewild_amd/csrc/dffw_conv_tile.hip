@@ -529,6 +529,33 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                         epilogue_cls(a, cls, g, opix, pv);
                     }
                 }
+            } else if (GEO == G3T && PIPE == 1 && NT <= 2 && PARTS == 2 && a.res0 && !a.res1 && !a.outf && !a.res_bcast) {
+                // transposed convs with a skip connection (dres*.conv5/6): all residual pieces of the pass are requested before the
+                // first is consumed.  The loop below requests one, waits, stores, requests the next -- measured ~35k cycles per
+                // pass on dres2.conv6, mostly load latency; these kernels are LDS-limited to two workgroups per CU, so the 40
+                // registers are there.
+                uint4 rq[NT][MTW];
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    int64_t opix;
+                    const bool pv = where(j, opix);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bool wv = pv && ((ntb + nt) * 2 + (g >> 1)) * 8 < a.Cout;
+                        rq[nt][j] = make_uint4(0, 0, 0, 0);
+                        if (wv) rq[nt][j] = *reinterpret_cast<const uint4 *>(a.res0 + ubase + (int64_t)(voff[j] + (ntb + nt) * 16));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    int64_t opix;
+                    const bool pv = where(j, opix);
+                    float cls = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) epilogue_quad<PREC, true, true, !BIAS_IN_ACC>(a, acc[nt][j], ntb + nt, g, opix, pv, cls, rq[nt][j], uint4{}, ubase, voff[j]);
+                    epilogue_cls(a, cls, g, opix, pv);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < MTW; ++j) {
