@@ -312,8 +312,14 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             const int KC = t.KC[pass];
             const int *tab = t.tab[pass] + g;
 
-            for (int st = st_lo; st < st_hi; ++st) {
-                const bool prefilled = (pass == pass_lo && st == st_lo);   // queued by the prologue
+            for (int sti = st_lo; sti < st_hi; ++sti) {
+                // transposed conv over several channel-group stages: odd passes walk the stages backwards, so every pass
+                // after the first starts on the image the previous pass ended on (5 fills per tile instead of 8 for two
+                // stages; measured on dres2.conv6: a fill is 10.7k cycles of issue + 6.2k of wait per workgroup)
+                const bool backwards = (GEO == G3T) && ((pass - pass_lo) & 1);
+                const int st = backwards ? st_hi - 1 - (sti - st_lo) : sti;
+                const bool resident = (GEO == G3T) && pass > pass_lo && sti == st_lo && st_hi - st_lo > 1;   // staged by the previous pass
+                const bool prefilled = (pass == pass_lo && sti == st_lo);   // queued by the prologue
                 // first chunk's weight fragments and tap offset: requested BEFORE waiting for the footprint DMA so
                 // that their L2 latency overlaps it
                 const int wstride = NTT * PARTS * 64;   // fragments (16 B per lane) per 32-deep chunk
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
 #pragma unroll
                     for (int pt = 0; pt < PARTS; ++pt) wfirst[nt][pt] = wp[(nt * PARTS + pt) * 64];
                 const int tfirst = tab[0];
-                if ((pass == pass_lo || st_hi - st_lo > 1) && !(a.dbg & 1)) {
+                if ((pass == pass_lo || st_hi - st_lo > 1) && !resident && !(a.dbg & 1)) {
                     if (!prefilled) {
                         __syncthreads();  // everyone is done reading the previous image
                         issue_fill(cur, st);
