@@ -545,25 +545,29 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
         const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
         const float wx1 = sx - x0f, wy1 = sy - y0f, wz1 = sz - z0f;
         const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1}, wz[2] = {1.0f - wz1, wz1};
+        // the (up to) 8 corners once per pixel: offset, weight, validity; then per channel all corner loads are requested
+        // together (as nested loops with early-outs every corner waited for its own load).  Corners outside the volume, or on a
+        // slice with zero weight, are skipped exactly as before, and the sum runs in the same (dz, dy, dx) order.
+        int64_t coff[8];
+        float cw[8];
+        bool cok[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+            const int zz = z0 + dz, yc = y0 + dy, xc = x0 + dx;
+            cok[k] = zz >= 0 && zz < N && wz[dz] != 0.f && yc >= 0 && yc < H && xc >= 0 && xc < W;
+            coff[k] = cok[k] ? (int64_t)zz * plane + (int64_t)yc * W + xc : 0;
+            cw[k] = wx[dx] * wy[dy] * wz[dz];
+        }
         for (int c = 0; c < C; ++c) {
             const float *src = x + ((int64_t)b * C + c) * N * plane;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[coff[k]];
             float acc = 0.f;
 #pragma unroll
-            for (int dz = 0; dz < 2; ++dz) {
-                const int zz = z0 + dz;
-                if (zz < 0 || zz >= N || wz[dz] == 0.f) continue;
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int yc = y0 + dy;
-                    if (yc < 0 || yc >= H) continue;
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int xc = x0 + dx;
-                        if (xc < 0 || xc >= W) continue;
-                        acc += src[(int64_t)zz * plane + (int64_t)yc * W + xc] * (wx[dx] * wy[dy] * wz[dz]);
-                    }
-                }
-            }
+            for (int k = 0; k < 8; ++k)
+                if (cok[k]) acc += v[k] * cw[k];
             out[(((int64_t)b * C + c) * N + n) * plane + (int64_t)yy * W + xx] = acc;
         }
     }
