@@ -210,6 +210,28 @@ template <int PREC>
 __global__ __launch_bounds__(256) void from_ncdhw_pad_kernel(const float *__restrict__ x, uint16_t *__restrict__ out, int B,
                                                              int Cs, int C, int64_t plane) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
+    if (C == 8) {
+        // the focal stack as the alignment network's 8-channel input: one thread per pixel, plane-coalesced loads, the whole
+        // record as one 16-byte store per part (one thread per element meant 2-byte stores)
+        const int64_t npix = (int64_t)B * plane;
+        for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = pix / plane, q = pix - b * plane;
+            short8 h = short8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < Cs) {
+                    uint16_t hi, lo;
+                    Fmt<PREC>::split(x[(b * Cs + c) * plane + q], hi, lo);
+                    h[c] = (short)hi;
+                    l[c] = (short)lo;
+                }
+            }
+            uint16_t *o = out + pix * (PARTS * 8);
+            *reinterpret_cast<short8 *>(o) = h;
+            if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(o + 8) = l;
+        }
+        return;
+    }
     const int64_t total = (int64_t)B * plane * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
