@@ -13,7 +13,7 @@ def load(path):
             seen.add(key); n[k]+=1; dur[k]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
     return d,n,dur
 tabs=[load(p) for p in sys.argv[1:]]
-kernels=sorted(tabs[0][2], key=lambda k:-tabs[0][2][k])[:int(10)]
+kernels=sorted(tabs[0][2], key=lambda k:-tabs[0][2][k])[:int(14)]
 for k in kernels:
     print(f"== {k}  n={tabs[0][1][k]} time={tabs[0][2][k]:.0f} us")
     for d,n,dur in tabs:
