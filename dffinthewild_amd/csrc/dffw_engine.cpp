@@ -1863,8 +1863,13 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     r.tap("FS_volume", vol);
 
     // confidence head -> mid_out                                                   DEN.py:83-90
+    // (on side stream 0 next to dres0 / deconv_1 when branch concurrency is on: two 1/8-resolution convs and a regression head
+    // that nothing else waits for)
     const int h8 = H / 8, w8 = W / 8;
     float *conf = (float *)r.raw((int64_t)B * N * h8 * w8 * sizeof(float));
+    r.forked = r.concurrent;
+    r.fork(0);
+    r.on(0);
     {
         Act c = r.conv(P + ".confidence.0.0", vol, rl);
         ConvOpt of; of.outf = conf;
@@ -1874,6 +1879,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
         regress(r, "regress.mid_out", conf, B, N, h8, w8, H, W, fd, fst, out[0]);
         r.drop_raw(conf);
     }
+    r.on(-1);
 
     // refinement                                                                   DEN.py:92-108
     Act d0 = r.conv(P + ".dres0.0.0", vol, rl);
@@ -1882,6 +1888,9 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     r.drop(d0);
     Act x1 = r.conv(P + ".deconv_1.0", d1);
     r.drop(d1);
+    r.join(0);
+    r.forked = false;
+    r.release_deferred();
 
     Act pre_a, out_a;
     const int h4 = H / 4, w4 = W / 4;

@@ -180,6 +180,16 @@ class Engine:
             self._ws[key] = ws
         return ws
 
+    def _call_ws(self, B, N, H, W, extra, call):
+        """Run ``call(ws)`` (a C-ABI forward returning its status) on the cached workspace.  The size is cached per shape, but
+        the engine's allocation path also depends on its DFFW_* switches (read per call): if it reports the workspace too
+        small (-3) the size is asked for again under the present switches and the forward repeated once."""
+        rc = call(self._workspace(B, N, H, W, extra))
+        if rc == -3:
+            self._ws.clear()
+            rc = call(self._workspace(B, N, H, W, extra))
+        return rc
+
     def forward(self, FS, focus_dists, taps=None):
         """FS (B,3,N,H,W) float32 on this engine's device; focus_dists broadcastable to (B,N,H,W).
         Returns (mid_out, pred1, pred2, pred3); with ``taps`` (list of names) also a dict of
@@ -191,16 +201,16 @@ class Engine:
         outs = [torch.empty((B, H, W), dtype=torch.float32, device=FS.device) for _ in range(4)]
         optrs = (c_void_p * 4)(*[o.data_ptr() for o in outs])
         with self._lock, torch.cuda.device(self.index):
-            ws = self._workspace(B, N, H, W)
-            args = [self._h, c_void_p(FS.data_ptr()), c_void_p(fd.data_ptr()), strides, B, N, H, W, optrs,
-                    c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index)]
+            def args(ws):
+                return [self._h, c_void_p(FS.data_ptr()), c_void_p(fd.data_ptr()), strides, B, N, H, W, optrs,
+                        c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index)]
             if not taps:
-                _check(lib.dffw_forward(*args), "dffw_forward")
+                _check(self._call_ws(B, N, H, W, 0, lambda ws: lib.dffw_forward(*args(ws))), "dffw_forward")
                 return tuple(outs)
             shapes = _tap_shapes(B, N, H, W)
             bufs = {nm: torch.empty(shapes[nm], dtype=torch.float32, device=FS.device) for nm in taps}
             tarr = (_Tap * len(bufs))(*[_Tap(nm.encode(), c_void_p(t.data_ptr()), t.numel()) for nm, t in bufs.items()])
-            _check(lib.dffw_forward_taps(*args, tarr, len(bufs)), "dffw_forward_taps")
+            _check(self._call_ws(B, N, H, W, 0, lambda ws: lib.dffw_forward_taps(*args(ws), tarr, len(bufs))), "dffw_forward_taps")
             return tuple(outs), bufs
 
 
@@ -213,9 +223,10 @@ class Engine:
         outs = [torch.empty((B, H, W), dtype=torch.float32, device=fd.device) for _ in range(4)]
         optrs = (c_void_p * 4)(*[o.data_ptr() for o in outs])
         with self._lock, torch.cuda.device(self.index):
-            ws = self._workspace(B, N, H, W, extra=B * 3 * N * H * W * 4 + 256)
-            _check(lib.dffw_forward_raw(self._h, c_void_p(raw), dtype, (c_int64 * 5)(*strides), h, w, c_void_p(fd.data_ptr()), fst,
-                                        B, N, H, W, optrs, c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index)),
+            st5 = (c_int64 * 5)(*strides)
+            _check(self._call_ws(B, N, H, W, B * 3 * N * H * W * 4 + 256,
+                                 lambda ws: lib.dffw_forward_raw(self._h, c_void_p(raw), dtype, st5, h, w, c_void_p(fd.data_ptr()), fst,
+                                                                 B, N, H, W, optrs, c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index))),
                    "dffw_forward_raw")
         return tuple(outs)
 
@@ -232,16 +243,16 @@ class Engine:
         aligned = torch.empty_like(FS)
         optrs = (c_void_p * 4)(*[o.data_ptr() for o in outs])
         with self._lock, torch.cuda.device(self.index):
-            ws = self._workspace(B, N, H, W)
             bufs, tarr, nt = {}, None, 0
             if taps:
                 shapes = _tap_shapes(B, N, H, W)
                 bufs = {nm: torch.empty(shapes[nm], dtype=torch.float32, device=FS.device) for nm in taps}
                 tarr = (_Tap * len(bufs))(*[_Tap(nm.encode(), c_void_p(t.data_ptr()), t.numel()) for nm, t in bufs.items()])
                 nt = len(bufs)
-            _check(lib.dffw_forward_e2e(self._h, c_void_p(FS.data_ptr()), c_void_p(fd.data_ptr()), strides,
-                                        c_void_p(fov.data_ptr()), B, N, H, W, optrs, c_void_p(aligned.data_ptr()),
-                                        c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index), tarr, nt),
+            _check(self._call_ws(B, N, H, W, 0,
+                                 lambda ws: lib.dffw_forward_e2e(self._h, c_void_p(FS.data_ptr()), c_void_p(fd.data_ptr()), strides,
+                                                                 c_void_p(fov.data_ptr()), B, N, H, W, optrs, c_void_p(aligned.data_ptr()),
+                                                                 c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(self.index), tarr, nt)),
                    "dffw_forward_e2e")
         res = tuple(outs) + (aligned,)
         return (res, bufs) if taps else res
