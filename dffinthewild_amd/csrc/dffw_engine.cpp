@@ -1863,13 +1863,16 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     r.tap("FS_volume", vol);
 
     // confidence head -> mid_out                                                   DEN.py:83-90
-    // (on side stream 0 next to dres0 / deconv_1 when branch concurrency is on: two 1/8-resolution convs and a regression head
-    // that nothing else waits for)
+    // (on side stream 0 next to dres0 / deconv_1 below 16M stack pixels: two 1/8-resolution convs and a regression head that
+    // nothing else waits for -- measured +2.7 % at batch 1, +2.3 % at batch 8, -0.3 % at batch 32 where dres0 fills the chip)
     const int h8 = H / 8, w8 = W / 8;
     float *conf = (float *)r.raw((int64_t)B * N * h8 * w8 * sizeof(float));
-    r.forked = r.concurrent;
-    r.fork(0);
-    r.on(0);
+    const bool conf_side = r.concurrent && (int64_t)B * N * H * W < (16 << 20) && !getenv_flag("DFFW_NO_CONF_FORK");
+    r.forked = conf_side;
+    if (conf_side) {
+        r.fork(0);
+        r.on(0);
+    }
     {
         Act c = r.conv(P + ".confidence.0.0", vol, rl);
         ConvOpt of; of.outf = conf;
@@ -1888,7 +1891,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     r.drop(d0);
     Act x1 = r.conv(P + ".deconv_1.0", d1);
     r.drop(d1);
-    r.join(0);
+    if (conf_side) r.join(0);
     r.forked = false;
     r.release_deferred();
 
