@@ -163,12 +163,14 @@ class Network(nn.Module):
         FS, focus_dists = self._check_inputs(FS, focus_dists)
         return self._engine_on(FS.device).forward(FS, focus_dists)
 
-    def forward_raw(self, raw, focus_dists, layout="NHWC", crop=None):
+    def forward_raw(self, raw, focus_dists, layout="NHWC", crop=None, norm="f32"):
         """The same forward fed with the stack as the loaders hold it BEFORE `FS/127.5 - 1.0` (uint8 or float32 0..255
         CUDA tensor in one of pipeline._LAYOUTS, optional crop (y0,x0,h,w)): normalisation, transpose and the -1
         padding to multiples of 32 (test_Dataloader.py:122-141) happen inside the stem kernel's loader.  Bit-identical
-        to `self(pipeline.pack_stack(raw, layout, crop), focus_dists)`; output maps have the padded size."""
+        to `self(pipeline.pack_stack(raw, layout, crop, norm=norm), focus_dists)`; output maps have the padded size.
+        norm="f64" selects the FS6 loader's float64 normalisation (test_Dataloader.py:31-39), see pipeline.pack_stack."""
         from . import pipeline as _pl
+        nflag = _pl._norm_flag(norm)
         if layout not in _pl._LAYOUTS:
             raise ValueError(f"unknown layout {layout!r}")
         if self.training:
@@ -192,7 +194,7 @@ class Network(nn.Module):
             raise RuntimeError(f"raw stack is on {raw.device} but focus_dists on {focus_dists.device}")
         st = raw.stride()
         ptr = raw.data_ptr() + (y0 * st[ay] + x0 * st[ax]) * raw.element_size()
-        return self._engine_on(raw.device).forward_raw(ptr, (st[0], st[an], st[ay], st[ax], st[ac]), 0 if raw.dtype == torch.uint8 else 1,
+        return self._engine_on(raw.device).forward_raw(ptr, (st[0], st[an], st[ay], st[ax], st[ac]), (0 if raw.dtype == torch.uint8 else 1) | nflag,
                                                        h, w, focus_dists.float(), B, N, H, W)
 
     def forward_with_taps(self, FS, focus_dists, names):

@@ -226,8 +226,10 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             if constexpr (!rawmode) return src[(int64_t)iy * W + ch * plane + q];
             if (iy >= rs.h || q >= rs.w) return -1.f;     // the loaders' pad value (test_Dataloader.py:126-137)
             const int64_t o = rbase + iy * rs.sy + q * rs.sx + ch * rs.sc;
-            const float v = rs.dtype == 0 ? (float)reinterpret_cast<const uint8_t *>(rs.p)[o] : reinterpret_cast<const float *>(rs.p)[o];
-            return __fsub_rn(__fdiv_rn(v, 127.5f), 1.0f);       // float32 divide, then subtract: as dffw_pack_stack / the loaders
+            const float v = (rs.dtype & 1) == 0 ? (float)reinterpret_cast<const uint8_t *>(rs.p)[o] : reinterpret_cast<const float *>(rs.p)[o];
+            // the FS6 loader normalises in float64 and rounds once (DFFW_RAW_NORM_F64, test_Dataloader.py:31-39) ...
+            if (rs.dtype & DFFW_RAW_NORM_F64_BIT) return (float)__dsub_rn(__ddiv_rn((double)v, 127.5), 1.0);
+            return __fsub_rn(__fdiv_rn(v, 127.5f), 1.0f);       // ... the others: float32 divide, then subtract (as dffw_pack_stack)
         };
         const int iy0 = c.gy0 + G::MINY, ix0 = c.gx0 + G::MINX;
         if constexpr (STEMP && !rawmode) {

@@ -1004,6 +1004,46 @@ static bool getenv_flag(const char *name) {
     return v && *v && *v != '0';
 }
 
+// The DFFW_* kernel-path switches, read from the environment ONCE per forward (Run's constructor): the
+// graph code below never calls getenv itself, so a forward sees one consistent set and pays for one scan of environ.
+#define DFFW_SWITCHES(X)                                                                                                 \
+    X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
+    X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(NO_PP)
+enum SwitchId {
+#define X_ID(n) SW_##n,
+    DFFW_SWITCHES(X_ID)
+#undef X_ID
+    SW_COUNT
+};
+struct Switches {
+    bool f[SW_COUNT];
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0;
+    int64_t concurrent_max_pixels = -1;   // < 0: no limit
+    const char *trace_layer = nullptr, *trace_out = nullptr;
+    bool on(int id) const { return f[id]; }
+    static Switches read() {
+        Switches s;
+        int i = 0;
+#define X_RD(n) s.f[i++] = getenv_flag("DFFW_" #n);
+        DFFW_SWITCHES(X_RD)
+#undef X_RD
+        auto geti = [](const char *name, int lo, int dflt) {
+            const char *z = getenv(name);
+            return (z && atoi(z) >= lo) ? atoi(z) : dflt;
+        };
+        s.roll_wgs = geti("DFFW_ROLL_WGS", 8, 0);
+        s.srd_wgs = geti("DFFW_SRD_WGS", 8, 0);
+        s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
+        { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
+        { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
+        { const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS"); s.concurrent_max_pixels = z ? atoll(z) : -1; }
+        s.trace_layer = getenv("DFFW_TRACE_LAYER");
+        s.trace_out = getenv("DFFW_TRACE_OUT");
+        return s;
+    }
+};
+
 struct ConvOpt {
     const Act *in1 = nullptr;
     const Act *res0 = nullptr, *res1 = nullptr;
@@ -1040,7 +1080,10 @@ struct Run {
     int ev_next = 0;
     std::vector<void *> deferred;
 
-    Run(dffw_engine *e_, hipStream_t s_, bool dry_, char *ws_, int64_t cap) : e(e_), s(s_), arena(cap), dry(dry_), ws(ws_), main_s(s_) {}
+    const Switches sw;   // the DFFW_* switches as they were when this forward started
+
+    Run(dffw_engine *e_, hipStream_t s_, bool dry_, char *ws_, int64_t cap)
+        : e(e_), s(s_), arena(cap), dry(dry_), ws(ws_), main_s(s_), sw(Switches::read()) {}
 
     bool ok() const { return err == DFFW_OK; }
 
@@ -1120,7 +1163,7 @@ struct Run {
         auto it = e->convs.find(name);
         if (it == e->convs.end()) return false;
         const TileCfg *c = it->second.tile.cfg;
-        return c && !getenv_flag("DFFW_NO_TILE") && gW * 2 >= c->tx && gH * 2 >= c->ty;
+        return c && !sw.on(SW_NO_TILE) && gW * 2 >= c->tx && gH * 2 >= c->ty;
     }
 
     Act conv(const std::string &name, const Act &in0, const ConvOpt &o = ConvOpt()) {
@@ -1192,11 +1235,11 @@ struct Run {
         a.relu = o.relu;
         if (!dry && e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
-        { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 7) : 0; }
+        a.dbg = sw.debug_flags & 7;
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
-            (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= 256 && !getenv_flag("DFFW_NO_ROLL") && !getenv_flag("DFFW_NO_ROLL_T32")) {
+            (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= 256 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_T32)) {
             if (dry) return out;
             a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
             a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
@@ -1212,7 +1255,7 @@ struct Run {
                 t.tiles_x = in0.W / rtx;
                 t.zsplit = 1;
                 t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
-                { const char *z = getenv("DFFW_ROLL_WGS"); t.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                t.wgs = sw.roll_wgs;
                 char kn[96];
                 conv_roll_t32_kernel_name(e->prec, py, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
                 g_last_kernel = kn;
@@ -1232,8 +1275,8 @@ struct Run {
             int ety, etx;
             efd_roll_tile(&ety, &etx);
             if (pc.wroll8 && !L.transposed && L.sh == 2 && in0.C == 8 && !o.in1 && !o.res0 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre &&
-                !o.cls && Ho % ety == 0 && Wo % etx == 0 && (int64_t)in0.B * (Ho / ety) * (Wo / etx) >= 256 && !getenv_flag("DFFW_NO_ROLL") &&
-                !getenv_flag("DFFW_NO_ROLL_S2")) {
+                !o.cls && Ho % ety == 0 && Wo % etx == 0 && (int64_t)in0.B * (Ho / ety) * (Wo / etx) >= 256 && !sw.on(SW_NO_ROLL) &&
+                !sw.on(SW_NO_ROLL_S2)) {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
@@ -1245,7 +1288,7 @@ struct Run {
                 t.tiles_x = Wo / etx;
                 t.zsplit = 1;
                 t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
-                { const char *z = getenv("DFFW_ROLL_WGS"); t.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                t.wgs = sw.roll_wgs;
                 char kn[96];
                 conv_roll_efd_kernel_name(e->prec, false, kn, sizeof kn);
                 g_last_kernel = kn;
@@ -1265,7 +1308,7 @@ struct Run {
             roll_tile(&rty, &rtx);
             const int cols = (in0.H / rty) * (in0.W / rtx);
             if (pc.wroll_t && in0.H % rty == 0 && in0.W % rtx == 0 && in0.C == 16 && !o.in1 && !o.res_bcast && !o.res1 && !o.outf &&
-                (int64_t)in0.B * cols >= 256 && !getenv_flag("DFFW_NO_ROLL")) {
+                (int64_t)in0.B * cols >= 256 && !sw.on(SW_NO_ROLL)) {
                 if (dry) return out;
                 a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
                 a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
@@ -1275,10 +1318,10 @@ struct Run {
                 t.tiles_y = in0.H / rty;
                 t.tiles_x = in0.W / rtx;
                 t.zsplit = ((int64_t)in0.B * cols < 1024 && No >= 8) ? 2 : 1;
-                { const char *z = getenv("DFFW_ROLL_ZSPLIT"); if (z && atoi(z) >= 1 && atoi(z) <= No) t.zsplit = atoi(z); }
+                if (sw.roll_zsplit >= 1 && sw.roll_zsplit <= No) t.zsplit = sw.roll_zsplit;
                 t.total_tiles = in0.B * t.zsplit * cols;
                 t.wgs = 0;
-                { const char *z = getenv("DFFW_ROLL_WGS"); if (z && atoi(z) >= 8) t.wgs = atoi(z); }
+                if (sw.roll_wgs) t.wgs = sw.roll_wgs;
                 t.pair = 1;
                 char kn[96];
                 conv_roll_t_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
@@ -1298,7 +1341,7 @@ struct Run {
         }
         // the stem straight from the focal stack: pixel-pair form (half the MFMAs and LDS reads of the per-pixel kernel)
         const bool stem_pair = o.fs32 && pc.tile_pair.cfg && pc.bias_pair && Wo % pc.tile_pair.cfg->tx == 0 && Ho % pc.tile_pair.cfg->ty == 0 &&
-                               !getenv_flag("DFFW_NO_STEM_PAIR");
+                               !sw.on(SW_NO_STEM_PAIR);
         if (stem_pair) a.bias = pc.bias_pair;
         const TilePack &tp = stem_pair ? pc.tile_pair : pc.tile;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
@@ -1308,7 +1351,7 @@ struct Run {
             roll_tile(&rty, &rtx);
             const int cols = (Ho / rty) * (Wo / rtx);
             if (pc.wroll && Ho % rty == 0 && Wo % rtx == 0 && in0.C % 8 == 0 && (!o.in1 || o.in1->C == in0.C) && !o.res_bcast && !o.res1 &&
-                (int64_t)in0.B * cols >= 256 && !getenv_flag("DFFW_NO_ROLL")) {
+                (int64_t)in0.B * cols >= 256 && !sw.on(SW_NO_ROLL)) {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
@@ -1318,11 +1361,11 @@ struct Run {
                 t.tiles_y = Ho / rty;
                 t.tiles_x = Wo / rtx;
                 t.zsplit = ((int64_t)in0.B * cols < 1024 && No >= 8) ? 2 : 1;
-                { const char *z = getenv("DFFW_ROLL_ZSPLIT"); if (z && atoi(z) >= 1 && atoi(z) <= No) t.zsplit = atoi(z); }
+                if (sw.roll_zsplit >= 1 && sw.roll_zsplit <= No) t.zsplit = sw.roll_zsplit;
                 t.total_tiles = in0.B * t.zsplit * cols;
                 t.wgs = 0;
                 t.pair = pc.roll_pair ? 1 : 0;
-                { const char *z = getenv("DFFW_ROLL_WGS"); if (z && atoi(z) >= 8) t.wgs = atoi(z); }
+                if (sw.roll_wgs) t.wgs = sw.roll_wgs;
                 {
                     char kn[96];
                     conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, pc.roll_pair, kn, sizeof kn);
@@ -1343,7 +1386,7 @@ struct Run {
                 return out;
             }
         }
-        const bool use_tile = tp.cfg && !getenv_flag("DFFW_NO_TILE") && gW * 2 >= tp.cfg->tx && gH * 2 >= tp.cfg->ty &&
+        const bool use_tile = tp.cfg && !sw.on(SW_NO_TILE) && gW * 2 >= tp.cfg->tx && gH * 2 >= tp.cfg->ty &&
                               in0.C % 8 == 0 && (!o.in1 || o.in1->C % 8 == 0);
         if (use_tile) {
             const TileCfg *cfg = tp.cfg;   // may be replaced by a narrower instantiation of the same tile (channel split)
@@ -1374,7 +1417,7 @@ struct Run {
             t.nsplit = 1;
             // few-tile layers (the 1/16..1/32-resolution pyramid, or batch 1): split the output channels over
             // grid.y so that at least ~one workgroup per CU exists
-            if (t.total_tiles < 256 && pc.nt > 1 && !o.cls && !getenv_flag("DFFW_NO_SPLIT")) {
+            if (t.total_tiles < 256 && pc.nt > 1 && !o.cls && !sw.on(SW_NO_SPLIT)) {
                 const int want = (256 + t.total_tiles - 1) / t.total_tiles;   // split factor that would fill the chip
                 for (int nts = pc.nt / 2; nts >= 1; nts /= 2) {               // coarsest split first
                     const TileCfg *c2 = tile_cfg_find_like(tp.cfg, nts);
@@ -1392,11 +1435,10 @@ struct Run {
             float *partial = nullptr;
             const int64_t M_out = (int64_t)out.B * No * Ho * Wo;
             // transposed conv on few tiles: its 4 sub-pixel passes as 4 workgroups (no reduction, any epilogue)
-            const char *thr_env = getenv("DFFW_SPLIT_WG");
-            const int thr = thr_env ? atoi(thr_env) : 256;   // measured best of 64/128/256/512 at batch 1, 4, 8
-            t.pass_split = (L.transposed && t.total_tiles * t.nsplit <= thr && !getenv_flag("DFFW_NO_SPLITK")) ? 1 : 0;
+            const int thr = sw.split_wg;
+            t.pass_split = (L.transposed && t.total_tiles * t.nsplit <= thr && !sw.on(SW_NO_SPLITK)) ? 1 : 0;
             if (!t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
-                !getenv_flag("DFFW_NO_SPLITK")) {
+                !sw.on(SW_NO_SPLITK)) {
                 const int want = 256 / (t.total_tiles * t.nsplit);
                 t.ksplit = std::max(1, std::min(std::min(tp.nstage, want), 8));
                 if (t.ksplit > 1) {
@@ -1411,20 +1453,31 @@ struct Run {
                 return out;
             }
             // persistent warp-specialised kernel when the layer has enough tiles to keep one workgroup per CU busy
+            // (rejected experiment, built only with `make STREAM=1`: persistent warp-specialised kernel)
+#ifdef DFFW_WITH_STREAM
             const TileCfg *scfg = stream_cfg_find(cfg->geo, cfg->nt, cfg->cg);
             const bool use_stream = scfg && scfg->tz == cfg->tz && scfg->ty == cfg->ty && scfg->tx == cfg->tx &&
-                                    t.total_tiles >= 1024 && getenv_flag("DFFW_STREAM");   // opt-in: measured slower than conv_tile
+                                    t.total_tiles >= 1024 && sw.on(SW_STREAM);
             if (use_stream) t.grid = 256;   // 8 XCDs x 32 CUs, one resident workgroup each
+#else
+            const TileCfg *scfg = nullptr;
+            const bool use_stream = false;
+#endif
+            auto kernel_name = [&](char *kn, int n) {
+#ifdef DFFW_WITH_STREAM
+                if (use_stream) return conv_stream_kernel_name(e->prec, scfg, kn, n);
+#endif
+                (void)scfg;
+                conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & DFFW_ARGS_RAW), kn, n);
+            };
             {
                 char kn[96];
-                if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
-                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & DFFW_ARGS_RAW), kn, sizeof kn);
+                kernel_name(kn, sizeof kn);
                 g_last_kernel = kn;
             }
             if (e->profiling) {
                 char kn[96];
-                if (use_stream) conv_stream_kernel_name(e->prec, scfg, kn, sizeof kn);
-                else conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & DFFW_ARGS_RAW), kn, sizeof kn);
+                kernel_name(kn, sizeof kn);
                 const double opx = (double)out.B * No * Ho * Wo;
                 const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
                                      + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
@@ -1432,15 +1485,17 @@ struct Run {
                                      + (double)L.kd * L.kh * L.kw * L.cin * L.cout * elem_bytes();
                 prof_begin(kn, name, flops, bytes);
             }
+#ifdef DFFW_WITH_STREAM
             if (use_stream) {
                 check(launch_conv_stream(e->prec, scfg, a, t, s), name.c_str());
                 prof_end();
                 return out;
             }
+#endif
             // debug timeline of one layer: DFFW_TRACE_LAYER=<layer name> DFFW_TRACE_OUT=<file>; per tile 8 x u64
             // (s_memtime at start / fill issued / fill landed / contraction done / stores acknowledged, HW_ID)
             unsigned long long *trace = nullptr;
-            const char *tl = getenv("DFFW_TRACE_LAYER"), *tout = getenv("DFFW_TRACE_OUT");
+            const char *tl = sw.trace_layer, *tout = sw.trace_out;
             if (tl && tout && name == tl) {
                 check(hipMalloc((void **)&trace, (size_t)t.total_tiles * 64), "trace alloc");
                 if (ok()) check(hipMemsetAsync(trace, 0, (size_t)t.total_tiles * 64, s), "trace memset");
@@ -1556,13 +1611,13 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
         if (x.C == 16) srd_roll16_tile(&sty, &stx);
         else srd_roll_tile(&sty, &stx);
         const auto end = r.e->convs.end();
-        if ((x.C == 8 || (x.C == 16 && !getenv_flag("DFFW_NO_FUSED_SRD16"))) && c0 != end && c2 != end && a3 != end && a1 != end &&
+        if ((x.C == 8 || (x.C == 16 && !r.sw.on(SW_NO_FUSED_SRD16))) && c0 != end && c2 != end && a3 != end && a1 != end &&
             c0->second.wsrd && c2->second.wsrd && a3->second.w32 &&
             a1->second.w32 && a3->second.watt && a1->second.watt && a3->second.def.kd == 3 && a1->second.def.kd == 1 &&
             x.H % sty == 0 && x.W % stx == 0 && x.H % 2 == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= 256 &&
-            !getenv_flag("DFFW_NO_FUSED_SRD") && !getenv_flag("DFFW_NO_FUSED_ATTENTION") && !getenv_flag("DFFW_NO_TILE")) {
+            !r.sw.on(SW_NO_FUSED_SRD) && !r.sw.on(SW_NO_FUSED_ATTENTION) && !r.sw.on(SW_NO_TILE)) {
             Act out = r.act(x.B, x.N, x.H, x.W, x.C);
-            const bool with_pool = pooled && !getenv_flag("DFFW_NO_FUSED_POOL");
+            const bool with_pool = pooled && !r.sw.on(SW_NO_FUSED_POOL);
             if (with_pool) *pooled = r.act(x.B, x.N, x.H / 2, x.W / 2, x.C);
             if (r.ok() && !r.dry) {
                 if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return out; }
@@ -1577,7 +1632,7 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
                 a.B = x.B; a.N = x.N; a.H = x.H; a.W = x.W;
                 a.tiles_y = x.H / sty; a.tiles_x = x.W / stx;
                 a.total_tiles = x.B * a.tiles_y * a.tiles_x;
-                { const char *z = getenv("DFFW_SRD_WGS"); a.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                a.wgs = r.sw.srd_wgs;
                 char kn[64];
                 if (x.C == 16) srd_roll16_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
                 else srd_roll_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
@@ -1602,9 +1657,9 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
     auto i3 = r.e->convs.find(p + ".N_ch_attention.0");
     auto i1 = r.e->convs.find(p + ".N_ch_attention.2");
     if (srd_attention_supported(feat.C) && i3 != r.e->convs.end() && i1 != r.e->convs.end() && i3->second.w32 && i1->second.w32 &&
-        !getenv_flag("DFFW_NO_FUSED_ATTENTION")) {
+        !r.sw.on(SW_NO_FUSED_ATTENTION)) {
         out = r.act(feat.B, feat.N, feat.H, feat.W, feat.C);
-        const bool with_pool = pooled && !getenv_flag("DFFW_NO_FUSED_POOL");
+        const bool with_pool = pooled && !r.sw.on(SW_NO_FUSED_POOL);
         if (with_pool) *pooled = r.act(feat.B, feat.N, feat.H / 2, feat.W / 2, feat.C);
         if (r.ok() && !r.dry) {
             char kn[64];
@@ -1616,7 +1671,7 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
             r.prof_end();
         }
     } else if (feat.C == 32 && i3 != r.e->convs.end() && i1 != r.e->convs.end() && i3->second.watt && i1->second.watt && feat.W % 16 == 0 &&
-               !getenv_flag("DFFW_NO_FUSED_ATTENTION")) {
+               !r.sw.on(SW_NO_FUSED_ATTENTION)) {
         out = r.act(feat.B, feat.N, feat.H, feat.W, feat.C);
         if (r.ok() && !r.dry) {
             char kn[64];
@@ -1648,8 +1703,8 @@ static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr
         const int Ho = x.H / 2, Wo = x.W / 2;
         const auto end = r.e->convs.end();
         if (x.C == 8 && pooled && pooled->p && ca != end && cb != end && ca->second.wroll8 && cb->second.wroll8 && x.H % 2 == 0 && x.W % 2 == 0 &&
-            Ho % ty == 0 && Wo % tx == 0 && (int64_t)x.B * (Ho / ty) * (Wo / tx) >= 256 && !getenv_flag("DFFW_NO_ROLL") &&
-            !getenv_flag("DFFW_NO_FUSED_EFD") && !getenv_flag("DFFW_NO_TILE")) {
+            Ho % ty == 0 && Wo % tx == 0 && (int64_t)x.B * (Ho / ty) * (Wo / tx) >= 256 && !r.sw.on(SW_NO_ROLL) &&
+            !r.sw.on(SW_NO_FUSED_EFD) && !r.sw.on(SW_NO_TILE)) {
             Act out = r.act(x.B, x.N, Ho, Wo, 16);
             if (r.ok() && !r.dry) {
                 if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return out; }
@@ -1666,7 +1721,7 @@ static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr
                 a.relu = 1;
                 a.zero = r.e->zero_page;
                 a.M = (int64_t)x.B * x.N * Ho * Wo;
-                { const char *d = getenv("DFFW_DEBUG_FLAGS"); a.dbg = d ? (atoi(d) & 6) : 0; }
+                a.dbg = r.sw.debug_flags & 6;
                 RollArgs t;
                 memset(&t, 0, sizeof t);
                 t.wroll = ca->second.wroll8;
@@ -1675,7 +1730,7 @@ static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr
                 t.tiles_y = Ho / ty; t.tiles_x = Wo / tx;
                 t.zsplit = 1;
                 t.total_tiles = x.B * t.tiles_y * t.tiles_x;
-                { const char *z = getenv("DFFW_ROLL_WGS"); t.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                t.wgs = r.sw.roll_wgs;
                 char kn[64];
                 conv_roll_efd_kernel_name(r.e->prec, true, kn, sizeof kn);
                 g_last_kernel = kn;
@@ -1803,15 +1858,15 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     // batch 1, +5 % at batch 4, +4 % at batch 8, +1..2.5 % at batch 32; the regression heads on a side stream gained
     // nothing).  DFFW_CONCURRENT_MAX_PIXELS restricts it to stacks below that many pixels.
     {
-        const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS");
+        const int64_t z = r.sw.concurrent_max_pixels;
         // (not in profiling mode: the per-launch event durations are meant to be each kernel's own)
-        if ((!z || (int64_t)B * N * H * W < atoll(z)) && !getenv_flag("DFFW_NO_CONCURRENT") && !r.e->profiling) r.enable_concurrency();
+        if ((z < 0 || (int64_t)B * N * H * W < z) && !r.sw.on(SW_NO_CONCURRENT) && !r.e->profiling) r.enable_concurrency();
     }
 
     // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80
     const std::string stem_name = P + ".FM_measure.Focus_extraction.0.0";
     Act stem;
-    if (r.tiled(stem_name, H, W) && !getenv_flag("DFFW_NO_FUSED_STEM")) {
+    if (r.tiled(stem_name, H, W) && !r.sw.on(SW_NO_FUSED_STEM)) {
         // the tiled stem kernel builds its paired-pixel records from the fp32 stack on the fly: no record volume
         Act geom;
         geom.B = B; geom.N = N; geom.H = H; geom.W = W + 2; geom.C = 8;
@@ -1867,7 +1922,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     // nothing else waits for -- measured +2.7 % at batch 1, +2.3 % at batch 8, -0.3 % at batch 32 where dres0 fills the chip)
     const int h8 = H / 8, w8 = W / 8;
     float *conf = (float *)r.raw((int64_t)B * N * h8 * w8 * sizeof(float));
-    const bool conf_side = r.concurrent && (int64_t)B * N * H * W < (16 << 20) && !getenv_flag("DFFW_NO_CONF_FORK");
+    const bool conf_side = r.concurrent && (int64_t)B * N * H * W < (16 << 20) && !r.sw.on(SW_NO_CONF_FORK);
     r.forked = conf_side;
     if (conf_side) {
         r.fork(0);
@@ -1937,7 +1992,7 @@ static Act of_block(Run &r, const std::string &p, const Act &x) {
         const int co = (c0 != end) ? c0->second.def.cout : 0;
         if (r.e->convs.find(p + ".feature") == end && c0 != end && c2 != end && c0->second.wsrd && c2->second.wsrd && (x.C == 8 || x.C == 16) &&
             (co == 16 || (co == 8 && x.C == 8)) && c2->second.def.cout == co && c2->second.cin_all == co + x.C && x.H % 8 == 0 && x.W % 16 == 0 &&
-            (int64_t)x.B * (x.H / 8) * (x.W / 16) >= 256 && !getenv_flag("DFFW_NO_FUSED_OF") && !getenv_flag("DFFW_NO_TILE")) {
+            (int64_t)x.B * (x.H / 8) * (x.W / 16) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
             Act out = r.act(x.B, x.N, x.H, x.W, co);
             if (r.ok() && !r.dry) {
                 if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return out; }
@@ -1950,7 +2005,7 @@ static Act of_block(Run &r, const std::string &p, const Act &x) {
                 a.B = x.B; a.N = x.N; a.H = x.H; a.W = x.W;
                 a.tiles_y = x.H / 8; a.tiles_x = x.W / 16;
                 a.total_tiles = x.B * a.tiles_y * a.tiles_x;
-                { const char *z = getenv("DFFW_SRD_WGS"); a.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                a.wgs = r.sw.srd_wgs;
                 char kn[64];
                 if (co == 8) of_roll8_kernel_name(r.e->prec, kn, sizeof kn);
                 else of_roll_kernel_name(r.e->prec, x.C == 8, kn, sizeof kn);
@@ -2019,7 +2074,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
         char kn[56];
         snprintf(kn, sizeof kn, "dffw::flow_volume_kernel<%d>", prec);
         Act y0;
-        if (r.e->convs.count(hp + ".0.0#ref") && !getenv_flag("DFFW_NO_HEAD_SPLIT")) {
+        if (r.e->convs.count(hp + ".0.0#ref") && !r.sw.on(SW_NO_HEAD_SPLIT)) {
             // the head's first conv is linear in its input channels: the part over the warped reference slice is the same
             // for all N slices of a sample, so it runs once per sample (1/N of the work, no ref channels in the volume) and
             // enters the per-slice conv over [cur | flow] as a slice-broadcast residual in front of the ReLU
@@ -2065,7 +2120,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             const auto end = r.e->convs.end();
             if (y0.C == 16 && c2 != end && c4 != end && c2->second.wsrd && c4->second.wsrd && c2->second.def.cout == 16 && c4->second.def.cout == 16 &&
                 c2->second.cin_all == 16 && c4->second.cin_all == 16 && y0.H % 8 == 0 && y0.W % 16 == 0 &&
-                (int64_t)y0.B * (y0.H / 8) * (y0.W / 16) >= 256 && !getenv_flag("DFFW_NO_FUSED_OF") && !getenv_flag("DFFW_NO_TILE")) {
+                (int64_t)y0.B * (y0.H / 8) * (y0.W / 16) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
                 y2 = r.act(y0.B, y0.N, y0.H, y0.W, 16);
                 if (r.ok() && !r.dry) {
                     if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return r.err; }
@@ -2078,7 +2133,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
                     a.B = y0.B; a.N = y0.N; a.H = y0.H; a.W = y0.W;
                     a.tiles_y = y0.H / 8; a.tiles_x = y0.W / 16;
                     a.total_tiles = y0.B * a.tiles_y * a.tiles_x;
-                    { const char *z = getenv("DFFW_SRD_WGS"); a.wgs = (z && atoi(z) >= 8) ? atoi(z) : 0; }
+                    a.wgs = r.sw.srd_wgs;
                     char kn2[64];
                     of_roll_kernel_name(prec, false, kn2, sizeof kn2);
                     g_last_kernel = kn2;
@@ -2293,7 +2348,8 @@ int dffw_forward_raw(dffw_engine *e, const void *raw, int dtype, const int64_t r
                      int64_t workspace_bytes, void *hip_stream) {
     if (!e || !raw || !raw_strides || !focus_dists || !fd_strides || !out) return fail(DFFW_EINVAL, "null argument");
     if (e->net != DFFW_NET_DEPTH) return fail(DFFW_EINVAL, "dffw_forward_raw serves DFFW_NET_DEPTH engines");
-    if (dtype != DFFW_RAW_U8 && dtype != DFFW_RAW_F32) return fail(DFFW_EINVAL, "unknown raw dtype %d", dtype);
+    if ((dtype & ~DFFW_RAW_NORM_F64) != DFFW_RAW_U8 && (dtype & ~DFFW_RAW_NORM_F64) != DFFW_RAW_F32) return fail(DFFW_EINVAL, "unknown raw dtype %d", dtype);
+    static_assert(DFFW_RAW_NORM_F64 == DFFW_RAW_NORM_F64_BIT, "dffw.h and dffw_internal.h disagree");
     int rc = check_dims(B, N, H, W);
     if (rc) return rc;
     if (h < 1 || w < 1 || h > H || w > W) return fail(DFFW_EINVAL, "source %dx%d does not fit the padded stack %dx%d", h, w, H, W);

@@ -35,11 +35,12 @@ static_assert(sizeof(TapEntry) == 16, "TapEntry must be 16 bytes");
 // 0..255, any layout, described by element strides; rows >= h / cols >= w of the (padded) stack read as -1.
 struct RawStack {
     const void *p;                  // null: not used
-    int dtype;                      // DFFW_RAW_U8 / DFFW_RAW_F32
+    int dtype;                      // DFFW_RAW_U8 / DFFW_RAW_F32, | DFFW_RAW_NORM_F64 (float64 normalisation of the FS6 loader)
     int64_t sb, sn, sy, sx, sc;     // element strides: sample, slice, row, col, colour channel
     int h, w;                       // rows / cols present in the source
 };
 
+#define DFFW_RAW_NORM_F64_BIT 16   // == DFFW_RAW_NORM_F64 of include/dffw.h (device code does not include that header)
 #define DFFW_ARGS_RAW 8
 // (ConvArgs must not grow: the register allocation of the lean transposed-conv kernels is sensitive to its size, a
 // 56-byte larger argument block cost them 38 %)

@@ -16,9 +16,11 @@ namespace dffw {
 // ---- pack_stack -----------------------------------------------------------------------------------------------
 // out[b][c][n][y][x] = raw[b,n,y,x,c] / 127.5 - 1 for y < h, x < w, else -1 (the loaders' constant pad value),
 // float32 arithmetic in the loaders' order (divide, then subtract: test_Dataloader.py:84,122,213; Test_dataloader.py:58).
+// NORM64: the FS6 loader (test_Dataloader.py:31-39) accumulates its images into np.zeros((256,256,3,0)) -- a float64
+// array -- so its `mats_input/127.5 - 1.0` runs in float64 and torch.Tensor() rounds once to float32 at the end.
 // One thread per output row segment of 4 pixels: the writes (the larger side: 12 B/pixel vs 3 B/pixel of uint8
 // input) are 16-byte coalesced; the strided source reads go through L2.
-template <typename T>
+template <typename T, bool NORM64>
 __global__ __launch_bounds__(256) void pack_stack_kernel(const T *raw, int64_t sb, int64_t sn, int64_t sy, int64_t sx, int64_t sc, int B, int N,
                                                           int h, int w, int Hp, int Wp, float *out) {
     const int64_t W4 = Wp / 4;
@@ -37,7 +39,10 @@ __global__ __launch_bounds__(256) void pack_stack_kernel(const T *raw, int64_t s
         for (int k = 0; k < 4; ++k) {
             const int x = x0 + k;
             v[k] = -1.0f;
-            if (y < h && x < w) v[k] = __fsub_rn(__fdiv_rn((float)raw[b * sb + n * sn + y * sy + x * sx + c * sc], 127.5f), 1.0f);
+            if (y < h && x < w) {
+                const T u = raw[b * sb + n * sn + y * sy + x * sx + c * sc];
+                v[k] = NORM64 ? (float)__dsub_rn(__ddiv_rn((double)u, 127.5), 1.0) : __fsub_rn(__fdiv_rn((float)u, 127.5f), 1.0f);
+            }
         }
         *reinterpret_cast<float4 *>(out + ((((int64_t)b * 3 + c) * N + n) * Hp + y) * Wp + x0) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -248,6 +253,8 @@ int dffw_jet_lut(uint8_t *lut768) {
 int dffw_pack_stack(int device, const void *raw, int dtype, const int64_t strides[5], int B, int N, int h, int w, int Hp, int Wp,
                     float *FS, void *hip_stream) {
     if (!raw || !strides || !FS) return dffw_fail(DFFW_EINVAL, "null argument");
+    const bool norm64 = (dtype & DFFW_RAW_NORM_F64) != 0;
+    dtype &= ~DFFW_RAW_NORM_F64;
     if (dtype != DFFW_RAW_U8 && dtype != DFFW_RAW_F32) return dffw_fail(DFFW_EINVAL, "unknown raw dtype %d", dtype);
     if (B < 1 || N < 1 || h < 1 || w < 1) return dffw_fail(DFFW_EINVAL, "empty stack (B=%d N=%d h=%d w=%d)", B, N, h, w);
     if (Hp < h || Wp < w || Hp % 32 || Wp % 32)
@@ -256,12 +263,17 @@ int dffw_pack_stack(int device, const void *raw, int dtype, const int64_t stride
     hipStream_t s = (hipStream_t)hip_stream;
     const int64_t total = (int64_t)B * 3 * N * Hp * (Wp / 4);
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    if (dtype == DFFW_RAW_U8)
-        hipLaunchKernelGGL(pack_stack_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t *)raw, strides[0], strides[1], strides[2], strides[3],
-                           strides[4], B, N, h, w, Hp, Wp, FS);
-    else
-        hipLaunchKernelGGL(pack_stack_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)raw, strides[0], strides[1], strides[2], strides[3],
-                           strides[4], B, N, h, w, Hp, Wp, FS);
+#define DFFW_PACK(T, N64)                                                                                                        \
+    hipLaunchKernelGGL((pack_stack_kernel<T, N64>), dim3(grid), dim3(256), 0, s, (const T *)raw, strides[0], strides[1], strides[2], strides[3], \
+                       strides[4], B, N, h, w, Hp, Wp, FS)
+    if (dtype == DFFW_RAW_U8) {
+        if (norm64) DFFW_PACK(uint8_t, true);
+        else DFFW_PACK(uint8_t, false);
+    } else {
+        if (norm64) DFFW_PACK(float, true);
+        else DFFW_PACK(float, false);
+    }
+#undef DFFW_PACK
     IO_HIPCHK(hipGetLastError());
     return DFFW_OK;
 }

@@ -81,10 +81,20 @@ def _load():
     lib.dffw_metrics_scratch_bytes.restype = c_int64
     lib.dffw_metrics.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                  c_int64, c_void_p]
+    lib.dffw_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.dffw_comm_init_rank.argtypes = [c_int, c_int, c_int, ctypes.c_char_p, POINTER(c_void_p)]
+    lib.dffw_comm_init_all.argtypes = [c_int, POINTER(c_int), POINTER(c_void_p)]
+    lib.dffw_comm_destroy.argtypes = [c_void_p]
+    lib.dffw_comm_destroy.restype = None
+    lib.dffw_comm_rank.argtypes = [c_void_p]
+    lib.dffw_comm_size.argtypes = [c_void_p]
+    lib.dffw_allgather.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     return lib
 
 
 lib = _load()
+COMM_ID_BYTES = 128
+RAW_NORM_F64 = 16   # DFFW_RAW_NORM_F64: the FS6 loader's float64 normalisation
 
 # every symbol include/dffw.h declares (tests check the library exports each one)
 ABI_SYMBOLS = (
@@ -93,6 +103,8 @@ ABI_SYMBOLS = (
     "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
     "dffw_op_fov_warp", "dffw_forward_e2e", "dffw_last_conv_kernel",
     "dffw_forward_raw", "dffw_pack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
+    "dffw_comm_unique_id", "dffw_comm_init_rank", "dffw_comm_init_all", "dffw_comm_destroy", "dffw_comm_rank", "dffw_comm_size",
+    "dffw_allgather", "dffw_comm_group_start", "dffw_comm_group_end",
 )
 
 

@@ -32,10 +32,19 @@ def _dev(t, what):
     return t.device.index if t.device.index is not None else torch.cuda.current_device()
 
 
-def pack_stack(raw, layout="NHWC", crop=None, multiple=32):
+def _norm_flag(norm):
+    if norm not in ("f32", "f64"):
+        raise ValueError(f"norm must be 'f32' or 'f64', got {norm!r}")
+    return engine.RAW_NORM_F64 if norm == "f64" else 0
+
+
+def pack_stack(raw, layout="NHWC", crop=None, multiple=32, norm="f32"):
     """raw: uint8 or float32 (0..255) CUDA tensor in `layout`, with or without a leading batch dim (any strides: a
     view of a larger buffer is fine).  crop = (y0, x0, h, w).  Returns float32 (B,3,N,Hp,Wp) = raw/127.5-1, padded at
-    the bottom/right to multiples of 32 with -1: the tensor the reference's loaders hand to the model."""
+    the bottom/right to multiples of 32 with -1: the tensor the reference's loaders hand to the model.
+    norm="f32": float32 divide then subtract (the DDFF / HCI / Smartphone / Real_Scenes loaders); norm="f64": the FS6 /
+    DefocusNet loader's arithmetic (test_Dataloader.py:31-39 builds a float64 array, torch.Tensor() rounds once)."""
+    nflag = _norm_flag(norm)
     if layout not in _LAYOUTS:
         raise ValueError(f"unknown layout {layout!r} (one of {sorted(_LAYOUTS)})")
     dev = _dev(raw, "raw stack")
@@ -58,7 +67,7 @@ def pack_stack(raw, layout="NHWC", crop=None, multiple=32):
     off = (y0 * st[ay] + x0 * st[ax]) * raw.element_size()
     FS = torch.empty((B, 3, N, Hp, Wp), dtype=torch.float32, device=raw.device)
     with torch.cuda.device(dev):
-        _check(lib.dffw_pack_stack(dev, c_void_p(raw.data_ptr() + off), 0 if raw.dtype == torch.uint8 else 1, strides, B, N, h, w,
+        _check(lib.dffw_pack_stack(dev, c_void_p(raw.data_ptr() + off), (0 if raw.dtype == torch.uint8 else 1) | nflag, strides, B, N, h, w,
                                    Hp, Wp, c_void_p(FS.data_ptr()), _stream_ptr(dev)), "dffw_pack_stack")
     return FS
 

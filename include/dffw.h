@@ -162,14 +162,19 @@ int dffw_op_regress(int device, const float *score, int B, int N, int h, int w, 
  * by the per-slice field-of-view scale and translation.  alpha: device fp32 (B,3,N) = (scale offset,
  * x shift, y shift) per slice; fovs: device fp32 (B,N); out: (B,C,N,H,W); flow: (B,2,N,H,W) or NULL (the
  * pixel-unit flow the reference returns as its second value).  alpha_from_sample0 != 0 reproduces the
- * reference's batch>1 broadcast quirk (every sample uses sample 0's scale offset and FOV). */
+ * reference's batch>1 broadcast quirk (End_to_End.py:112: `alpha[:,0,:,:] + FOVs` broadcasts to (B,B,N,1,1) and
+ * `[:,0]` keeps alpha[0,n] + FOVs[b,n]: every sample uses SAMPLE 0's scale offset with its OWN FOV). */
 int dffw_op_fov_warp(int device, const float *x, int B, int C, int N, int H, int W, const float *alpha,
                      const float *fovs, int alpha_from_sample0, float *out, float *flow, void *hip_stream);
 
 /* ---- input pipeline ---------------------------------------------------------------
  * Replaces the NumPy tensor assembly of the reference's loaders: `FS/127.5 - 1.0`, the transpose to (3,N,H,W) and the
- * bottom/right padding to multiples of 32 with -1 (Depth_Estimation_Test/test_Dataloader.py:36-39 FS6, :80-89 HCI,
- * :122-141 DDFF, :197-228 Smartphone; End_to_End/Test_dataloader.py:56-75 Real_Scenes).
+ * bottom/right padding to multiples of 32 with -1 (Depth_Estimation_Test/test_Dataloader.py:80-89 HCI, :122-141 DDFF,
+ * :197-228 Smartphone; End_to_End/Test_dataloader.py:56-75 Real_Scenes: all float32 arrays, i.e. a float32 divide followed
+ * by a float32 subtract).  The FS6 / DefocusNet loader (test_Dataloader.py:31-39) differs: it concatenates its images onto
+ * np.zeros((256,256,3,0)), a FLOAT64 array, so its `/127.5 - 1.0` runs in float64 and torch.Tensor() rounds once at the end
+ * (128 of the 256 byte values then differ by one float32 ulp from the float32 form): OR DFFW_RAW_NORM_F64 into `dtype` to get
+ * that arithmetic, (float)((double)v / 127.5 - 1.0).
  *   raw      device uint8 (DFFW_RAW_U8) or fp32 0..255 (DFFW_RAW_F32) stack in ANY source layout, described by
  *            element strides {batch, slice, row, col, channel}: (N,H,W,3) hdf5 stacks, (H,W,3,N) / (H,W,N,3) image
  *            arrays; a crop (test_Dataloader.py:205, Test_dataloader.py:58) is a pointer offset by the caller
@@ -178,6 +183,7 @@ int dffw_op_fov_warp(int device, const float *x, int B, int C, int N, int H, int
  *            subtract; -1 in the padding).  Enqueue-only on hip_stream. */
 #define DFFW_RAW_U8 0
 #define DFFW_RAW_F32 1
+#define DFFW_RAW_NORM_F64 16 /* flag OR-ed into dtype: normalise in float64, round once (the FS6 loader) */
 int dffw_pack_stack(int device, const void *raw, int dtype, const int64_t strides[5], int B, int N, int h, int w,
                     int Hp, int Wp, float *FS, void *hip_stream);
 
@@ -217,6 +223,30 @@ int dffw_jet_lut(uint8_t *lut768);
 int64_t dffw_metrics_scratch_bytes(int B);
 int dffw_metrics(int device, const float *est, int B, int H, int W, const float *gt, const uint8_t *mask,
                  const float *conf, int h, int w, double *out, void *scratch, int64_t scratch_bytes, void *hip_stream);
+
+/* ---- multi-GPU: RCCL all-gather of the depth maps ---------------------------------------------
+ * The forward has no cross-sample operation, so a batch is sharded on dim 0 over the GPUs of a node with no data-path
+ * collective; what the reference's nn.DataParallel does after the replicas finish (Depth_Estimation_Test/test.py:32:
+ * gather the outputs on device 0) becomes ONE ncclAllGather (RCCL over xGMI) of every rank's (b,H,W) fp32 maps, enqueued
+ * on the compute stream behind the last head kernel.  librccl.so is bound with dlopen at the first call (override the
+ * path with the environment variable DFFW_RCCL_LIB); nothing here is needed for single-GPU use.
+ *   one process per GPU:  rank 0 calls dffw_comm_unique_id and hands the 128 bytes to the other ranks (file, pipe, MPI ...);
+ *                         every rank calls dffw_comm_init_rank(device, nranks, rank, id, &comm)
+ *   one process, n GPUs:  dffw_comm_init_all(n, devices, comms); calls for several comms from one thread go between
+ *                         dffw_comm_group_start / dffw_comm_group_end
+ *   dffw_allgather        recv[r*count .. (r+1)*count) on every rank = rank r's send[0 .. count) (device fp32); equal
+ *                         counts on all ranks; enqueue-only on hip_stream. */
+#define DFFW_COMM_ID_BYTES 128
+typedef struct dffw_comm dffw_comm;
+int dffw_comm_unique_id(char id[DFFW_COMM_ID_BYTES]);
+int dffw_comm_init_rank(int device, int nranks, int rank, const char id[DFFW_COMM_ID_BYTES], dffw_comm **out);
+int dffw_comm_init_all(int ndev, const int *devices, dffw_comm **out /* [ndev] */);
+void dffw_comm_destroy(dffw_comm *c);
+int dffw_comm_rank(const dffw_comm *c);
+int dffw_comm_size(const dffw_comm *c);
+int dffw_allgather(dffw_comm *c, const float *send, float *recv, int64_t count, void *hip_stream);
+int dffw_comm_group_start(void);
+int dffw_comm_group_end(void);
 
 #ifdef __cplusplus
 }

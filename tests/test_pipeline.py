@@ -39,6 +39,25 @@ def test_oracle_pack_stack_layouts_agree():
     assert a[1, 2, 3, 4] == np.float32(nhwc[2, 3, 4, 1]) / np.float32(127.5) - np.float32(1.0)
 
 
+def test_oracle_fs6_float64_normalisation_all_byte_values():
+    """The FS6 / DefocusNet loader (test_Dataloader.py:31-39) normalises in float64 (its accumulator np.zeros((256,256,3,0))
+    is float64) and rounds to float32 once in torch.Tensor(); the other loaders divide float32 arrays.  All 256 byte values:
+    the oracle's norm64 mode equals the loader's own NumPy lines, and differs from the float32 form for some values."""
+    img = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)          # one "image" holding every byte value
+    mats_input = np.zeros((16, 16, 3, 0))                                              # test_Dataloader.py:31 (float64)
+    mats_input = np.concatenate((mats_input, np.expand_dims(img, axis=-1)), axis=3)    # :34
+    mats_input = mats_input / 127.5 - 1.0                                              # :36
+    mats_input = np.transpose(mats_input, (2, 3, 0, 1))                                # :39
+    want = torch.Tensor(mats_input).numpy()                                            # :42 (the single rounding)
+    assert mats_input.dtype == np.float64 and want.dtype == np.float32
+    got = ref.pack_stack(img[..., None], "HWCN", norm64=True)
+    assert np.array_equal(got[:, :, :16, :16], want)
+    f32 = ref.pack_stack(img[..., None], "HWCN")
+    ndiff = int((got[0, 0, :16, :16] != f32[0, 0, :16, :16]).sum())
+    assert 0 < ndiff < 256, ndiff                                                      # the two arithmetics are NOT interchangeable
+    assert np.max(np.abs(got - f32)) <= np.spacing(np.float32(1.0))                    # ... but never more than one ulp apart
+
+
 def test_oracle_metrics_known_answers():
     gt = np.full((4, 4), 2.0, np.float32)
     est = gt.copy()
@@ -73,6 +92,24 @@ def test_pack_stack_bit_exact(pl, layout, shape, crop, dtype):
     big = torch.from_numpy(np.stack([raw, raw[::-1].copy()])).cuda()
     got2 = pl.pack_stack(big, layout, crop)
     assert np.array_equal(got2[0].cpu().numpy(), want) and np.array_equal(got2[1].cpu().numpy(), ref.pack_stack(raw[::-1], layout, crop))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["u8", "f32"])
+def test_pack_stack_fs6_float64_normalisation_bit_exact(pl, dtype):
+    """norm="f64" (DFFW_RAW_NORM_F64): every byte value, both source dtypes, against the oracle's float64 path (which the CPU
+    test above pins to the loader's own NumPy lines); norm="f32" on the same input keeps the float32 arithmetic."""
+    vals = np.arange(256, dtype=np.uint8)
+    raw = np.stack([np.roll(vals, k) for k in range(40)]).reshape(40, 256, 1, 1).repeat(3, axis=2).repeat(5, axis=3)   # (H=40, W=256, 3, N=5)
+    raw = raw.astype(np.uint8 if dtype == "u8" else np.float32)
+    t = torch.from_numpy(raw).cuda()
+    got64 = pl.pack_stack(t, "HWCN", norm="f64")[0].cpu().numpy()
+    got32 = pl.pack_stack(t, "HWCN")[0].cpu().numpy()
+    assert np.array_equal(got64, ref.pack_stack(raw, "HWCN", norm64=True))
+    assert np.array_equal(got32, ref.pack_stack(raw, "HWCN"))
+    assert (got64 != got32).any()
+    with pytest.raises(ValueError):
+        pl.pack_stack(t, "HWCN", norm="f16")
 
 
 @pytest.mark.gpu
@@ -165,5 +202,10 @@ def test_forward_raw_is_bit_identical_to_pack_then_forward(pl, layout, shape, cr
     with torch.no_grad():
         a = model.forward_raw(raw, fd, layout, crop)
         b = model(pl.pack_stack(raw, layout, crop), fd)
+        a64 = model.forward_raw(raw, fd, layout, crop, norm="f64")      # the FS6 loader's float64 normalisation in the stem loader
+        b64 = model(pl.pack_stack(raw, layout, crop, norm="f64"), fd)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+    for x, y in zip(a64, b64):
+        assert torch.equal(x, y)
+    assert not torch.equal(a64[3], a[3])
