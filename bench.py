@@ -6,10 +6,11 @@
 A "step" is one pass of the hot path (DFF_net.forward, reference DEN.py:74-127, through
 libdffw.so) over one batch of synthetic 10-slice 3x256x256 focal stacks per GPU — BASELINE.json's
 config "DefocusNet-shape 10-slice 256x256 stacks, batch=32, 1xMI355X" (config 3; config 4 is the
-same per-GPU batch on 8 GPUs).  Inputs are resident in HBM before the timed region.  For N > 1 the
-driver launches one rank per GPU with torch.distributed.run; every rank processes its own 32
-stacks (weak scaling, no data-path collective) and the per-rank depth maps are collected with one
-RCCL all-gather inside the timed step.
+same per-GPU batch on 8 GPUs).  Inputs are resident in HBM before the timed region.  For N > 1 one
+rank runs per GPU -- launched by torch.distributed.run, or, when bench.py is invoked plainly with
+--gpus N, by bench.py itself (N fresh child processes) -- every rank processes its own 32 stacks
+(weak scaling, no data-path collective) and the per-rank depth maps are collected with one RCCL
+all-gather inside the timed step (its bus GB/s is reported under "allgather").
 
 `--workload e2e` runs BASELINE.json's config 5 instead (not the default line): the End_to_End variant —
 alignment network + FOV warp + DFF_net (End_to_End/End_to_End.py) — on 10-slice 480x640 stacks, batch 8.
@@ -82,7 +83,12 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
         return tf, gbs, tf / PEAK_MFMA_TFLOPS, gbs / PEAK_HBM_GBS
 
     tf, gbs, f_mfma, f_hbm = fractions(dom)
-    hbm_bound = f_hbm >= f_mfma          # the roof the kernel sits closer to is the one that binds it
+    # which roof binds the kernel: the larger of its two minimum times, MFMA time counted with the instruction issues the
+    # arithmetic mode really pays per algorithmic product (split-bf16: 3) -- SURVEY.md 8d
+    issue = 3.0 if precision == "bf16x3" else 1.0
+    t_mfma = dom["flops"] * issue / (PEAK_MFMA_TFLOPS * 1e12)
+    t_hbm = dom["bytes"] / (PEAK_HBM_GBS * 1e9)
+    hbm_bound = t_hbm > t_mfma
     roof = {
         "bound": "hbm" if hbm_bound else "mfma", "kernel": dom_name,
         "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
@@ -91,6 +97,10 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
         "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
         "algorithmic_gb_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
         "tflops": round(tf, 2), "frac_mfma": round(f_mfma, 4), "algorithmic_gbs": round(gbs, 1), "frac_hbm": round(f_hbm, 4),
+        "mfma_issues_per_product": issue, "frac_of_issue_ceiling": round(f_mfma * issue, 4),
+        "arithmetic_intensity_flop_per_byte": round(dom["flops"] / dom["bytes"], 1),
+        "bound_rule": "mfma if algorithmic FLOPs x MFMA issues per product / 2.5 PFLOP/s >= algorithmic bytes / 8 TB/s, else hbm; "
+                      "frac = algorithmic work / measured time / peak (so a split-bf16 kernel tops out at 1/3 of the dense MFMA peak)",
         "share_of_forward_time": round(dom["ms"] / total_ms, 3),
         "all_conv_kernels": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                              "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
@@ -103,13 +113,22 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
     # whole forward against its layer-by-layer roofline: sum over launches of max(MFMA time, HBM time) with each launch's
     # algorithmic FLOPs (x3 MFMA issue in the split-bf16 mode) and algorithmic bytes ("the exact ceiling is the
     # per-layer sum of max(.,.)")
-    issue = 3.0 if precision == "bf16x3" else 1.0
     bound_ms = sum(max(flops * issue / (PEAK_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)) for _, _, flops, nbytes, _ in rows) * 1e3
     roof["forward_vs_layerwise_roofline"] = {"bound_ms": round(bound_ms, 3), "measured_ms": round(total_ms, 3), "frac": round(bound_ms / total_ms, 4),
                                              "definition": "sum over the launches of max(algorithmic FLOPs x MFMA issues per product / dense peak, "
                                                            "algorithmic bytes / 8 TB/s) / sum of the launches' measured durations"}
+    # the north star's graded subset: the 3-D cost-aggregation convs (SPP_module, confidence,
+    # dres0, deconv_1..3, dres2..4; 48.685 GF per 10x256x256 stack)
+    agg3d = [(fl, ms) for _, layer, fl, _, ms in rows
+             if any(layer.startswith("DFF_net." + p) for p in ("SPP_module", "confidence", "dres0", "deconv_", "dres2", "dres3", "dres4"))]
+    if agg3d:
+        gfl, gms = sum(f for f, _ in agg3d), sum(m for _, m in agg3d)
+        gtf = gfl / (gms * 1e-3) / 1e12
+        roof["aggregation_3d_convs"] = {"gflop": round(gfl / 1e9, 2), "ms": round(gms, 3), "achieved": round(gtf, 2), "unit": "TFLOP/s",
+                                        "frac": round(gtf / PEAK_MFMA_TFLOPS, 4), "frac_of_issue_ceiling": round(gtf * issue / PEAK_MFMA_TFLOPS, 4),
+                                        "launches": len(agg3d), "share_of_forward_time": round(gms / total_ms, 3)}
     # the heaviest kernel that is MFMA-bound by the same criterion (the 3x3x3 aggregation convs of the north star)
-    mf = {k: a for k, a in conv.items() if fractions(a)[2] > fractions(a)[3]}
+    mf = {k: a for k, a in conv.items() if a["flops"] * issue / (PEAK_MFMA_TFLOPS * 1e12) >= a["bytes"] / (PEAK_HBM_GBS * 1e9)}
     if mf:
         mk, ma = max(mf.items(), key=lambda kv: kv[1]["ms"])
         mtf, mgbs, mfm, mfh = fractions(ma)
@@ -171,6 +190,24 @@ def cpu_baseline_e2e(sd, seconds, H, W, batch=2):
     return base, ref
 
 
+def physical_cores(default):
+    """Physical cores this process may run on (unique (package, core) pairs of /proc/cpuinfo within the affinity mask)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cpu, pkg = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("processor"):
+                    cpu = int(line.split(":")[1])
+                elif line.startswith("physical id"):
+                    pkg = int(line.split(":")[1])
+                elif line.startswith("core id") and cpu in allowed:
+                    seen.add((pkg, int(line.split(":")[1])))
+        return len(seen) or default
+    except (OSError, ValueError, AttributeError):
+        return default
+
+
 def cpu_baseline(sd, seconds, batch=8):
     """Oracle forward on a bounded sample (one batch of `batch` 10x256x256 stacks, repeated) on this box's
     host cores.  PyTorch-CPU stops scaling (and degrades) past ~32 threads for these small convs
@@ -178,18 +215,29 @@ def cpu_baseline(sd, seconds, batch=8):
     thread count is min(cores available, 32); `cores` in the JSON is what was actually used."""
     from oracle import cpu_ref
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(avail, 32)
-    torch.set_num_threads(cores)
+    phys = physical_cores(avail)
     FS = torch.from_numpy(synth.focal_stack(batch, 10, 256, 256, seed=1000))
     fd = torch.from_numpy(synth.focus_dists(batch, 10, 256, 256))
+    # two thread policies share the time budget: all physical cores (SURVEY.md 8d) and 32 threads (the optimum of the
+    # sweep in profiles/*cpu_threads_sweep*: PyTorch-CPU degrades past ~32 threads on these small convs); the faster one is
+    # the reported baseline, both are named in `sample`
+    policies = sorted({min(avail, 32), min(avail, phys)})
+    tried = {}
+    ref = None
     with torch.no_grad():
-        ref = cpu_ref.dff_forward(sd, FS, fd)          # warm-up, also the parity reference for the first stacks
-        times = []
-        t_end = time.time() + seconds
-        while len(times) < 2 or (time.time() < t_end and len(times) < 10):
-            t0 = time.perf_counter()
-            cpu_ref.dff_forward(sd, FS, fd)
-            times.append(time.perf_counter() - t0)
+        for cores_k in policies:
+            torch.set_num_threads(cores_k)
+            r = cpu_ref.dff_forward(sd, FS, fd)          # warm-up, also the parity reference for the first stacks
+            ref = ref if ref is not None else r
+            ts = []
+            t_end = time.time() + seconds / len(policies)
+            while len(ts) < 1 or (time.time() < t_end and len(ts) < 10):
+                t0 = time.perf_counter()
+                cpu_ref.dff_forward(sd, FS, fd)
+                ts.append(time.perf_counter() - t0)
+            tried[cores_k] = ts
+    cores = min(tried, key=lambda k: min(tried[k]))
+    times = tried[cores]
     best = min(times)
     model_name = ""
     try:
@@ -203,9 +251,53 @@ def cpu_baseline(sd, seconds, batch=8):
     base = {"value": round(batch / best, 3), "unit": "stacks/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} forwards of one batch of {batch} 10x3x256x256 stacks after 1 warm-up, best of "
                       f"(mean {sum(times)/len(times):.2f} s per batch); oracle/cpu_ref.py = the reference's PyTorch-CPU "
-                      f"fp32 arithmetic restated; {avail} logical cores available, {cores} threads used",
+                      f"fp32 arithmetic restated; {avail} logical / {phys} physical cores available, {cores} threads used "
+                      f"(best of the policies tried: " + ", ".join(f"{k} threads {batch / min(v):.2f} stacks/s" for k, v in sorted(tried.items())) + ")",
             "cpu": model_name}
     return base, ref
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without an outer launcher: N child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run would set them), rendezvous on 127.0.0.1.  Rank 0's stdout (the JSON line) is passed
+    through; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def measure_allgather(local, world, iters=20):
+    """The step's one collective on its own: RCCL all-gather of this rank's pred3 maps, timed over `iters` calls between
+    device synchronisations (max over ranks).  bus GB/s = bytes every rank receives from the others / time."""
+    for _ in range(3):
+        ddist.all_gather_depth(local)
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ddist.all_gather_depth(local)
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=local.device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    sec = float(t.item())
+    nbytes = local.numel() * local.element_size()
+    return {"collective": "all_gather_into_tensor (backend nccl = RCCL over xGMI)", "ranks": torch.distributed.get_world_size(),
+            "bytes_per_rank": nbytes, "result_bytes": nbytes * world, "us_per_call": round(sec * 1e6, 1),
+            "algbw_GBs": round(nbytes * world / sec / 1e9, 2), "busbw_GBs": round(nbytes * (world - 1) / sec / 1e9, 2),
+            "sample": f"{iters} back-to-back calls after 3 warm-ups, outside the timed steps (each timed step also contains one)"}
 
 
 def main():
@@ -231,10 +323,11 @@ def main():
     args = ap.parse_args()
 
     rank, local_rank, world = ddist.env_world()
+    if world == 1 and args.gpus > 1:
+        # invoked plainly (no torch.distributed.run around it): start one fresh process per GPU ourselves.  Nothing in
+        # this parent has touched the GPU yet, and the children are new processes (spawned, not exec'ed over this one).
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -288,6 +381,7 @@ def main():
         elapsed = float(t.item())
     stacks = world * B * args.steps
     value = stacks / elapsed
+    allgather = measure_allgather(outs[3], world) if world > 1 else None
 
     result = None
     if rank == 0:
@@ -313,6 +407,8 @@ def main():
                        else "float32 (B,3,N,H,W), the reference's tensor contract"},
             "forward_tflops_algorithmic": round(value * GFLOP_PER_STACK * scale / 1e3, 2),   # DFF_net's convs only
         }
+        if allgather:
+            result["allgather"] = allgather
     if rank == 0 and not args.no_roofline and raw_u8 is None:
         roof, per_kernel, rows = roofline_from_profile(model, inputs, device, args.precision)
         result["roofline"] = roof

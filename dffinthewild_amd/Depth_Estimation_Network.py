@@ -69,6 +69,27 @@ class Network(nn.Module):
         self._inherited_fp = None   # set on DataParallel replicas
         self._tensors = None        # cached list of parameters/buffers for _fingerprint
 
+    # ---- copy / pickle: the usual nn.Module idioms (copy.deepcopy for EMA / SWA clones, torch.save(model)) ----------
+    # The packed-weight cache holds ctypes engine handles and a lock: neither may be copied (a second owner of a
+    # dffw_engine* would free it twice).  A copy therefore carries the parameters only and packs its own engine at its
+    # first forward.  (DataParallel replicas are NOT copies in this sense: _replicate_for_data_parallel below shares
+    # the cache on purpose.)
+    _RUNTIME_STATE = ("_engines", "_token", "_guard", "_inherited_fp", "_tensors")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._RUNTIME_STATE:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._engines = {}
+        self._token = [0]
+        self._guard = threading.Lock()
+        self._inherited_fp = None
+        self._tensors = None
+
     # ---- weight contract ------------------------------------------------------------------------
     @staticmethod
     def _conv_rows():

@@ -1078,6 +1078,7 @@ struct Run {
     bool concurrent = false;
     bool forked = false;
     int ev_next = 0;
+    unsigned side_open = 0;   // side streams forked and not yet joined
     std::vector<void *> deferred;
 
     const Switches sw;   // the DFFW_* switches as they were when this forward started
@@ -1096,13 +1097,23 @@ struct Run {
         hipEvent_t v = e->ev[ev_next++ % dffw_engine::NEV];
         check(hipEventRecord(v, main_s), "fork record");
         check(hipStreamWaitEvent(e->side[k], v, 0), "fork wait");
+        fork_mark(k);
     }
     void on(int k) { s = (concurrent && !dry && k >= 0) ? e->side[k] : main_s; }   // stream of the following launches
+    void fork_mark(int k) { side_open |= 1u << k; }
     void join(int k) {   // the main stream waits for everything queued on side stream k
-        if (!concurrent || dry || !ok()) return;
+        if (!concurrent || dry || !e->side[k]) return;
+        // (also after an error: kernels already queued on the side stream use the workspace, and the caller is free to
+        // recycle it as soon as the main stream is done)
         hipEvent_t v = e->ev[ev_next++ % dffw_engine::NEV];
-        check(hipEventRecord(v, e->side[k]), "join record");
-        check(hipStreamWaitEvent(main_s, v, 0), "join wait");
+        const hipError_t h1 = hipEventRecord(v, e->side[k]);
+        const hipError_t h2 = h1 == hipSuccess ? hipStreamWaitEvent(main_s, v, 0) : h1;
+        side_open &= ~(1u << k);
+        if (ok()) check(h2, "join");
+    }
+    ~Run() {   // a forked section left through an error path: join whatever is still open
+        for (int k = 0; k < dffw_engine::NSIDE; ++k)
+            if (side_open & (1u << k)) join(k);
     }
     void release_deferred() {
         for (void *p : deferred) arena.release(dry ? (int64_t)(uintptr_t)p - 256 : (int64_t)((char *)p - ws));

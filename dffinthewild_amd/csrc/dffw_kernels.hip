@@ -552,9 +552,11 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
         t /= H;
         const int n = (int)(t % N);
         const int b = (int)(t / N);
-        const int ab = alpha_from_sample0 ? 0 : b;   // the reference's batch>1 broadcast takes sample 0's alpha
+        // the reference's batch>1 quirk (End_to_End.py:112): `alpha[:,0,:,:] + FOVs` broadcasts to (B,B,N,1,1) and `[:,0]` keeps
+        // alpha[0,n] + FOVs[b,n] -- sample 0's scale offset, but every sample's OWN field of view
+        const int ab = alpha_from_sample0 ? 0 : b;
         const float a0 = alpha[(ab * 3 + 0) * N + n], a1 = alpha[(b * 3 + 1) * N + n], a2 = alpha[(b * 3 + 2) * N + n];
-        const float f = a0 + fov[(alpha_from_sample0 ? 0 : b) * N + n];
+        const float f = a0 + fov[b * N + n];
         const WarpPoint wp = warp_point(xx, yy, H, W, f, a1, a2);
         if (flow) {
             flow[((int64_t)(b * 2 + 0) * N + n) * plane + (int64_t)yy * W + xx] = wp.fx;

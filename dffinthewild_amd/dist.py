@@ -51,7 +51,18 @@ def all_gather_depth(local, total=None):
         return local
     world = dist.get_world_size()
     b = local.shape[0]
-    if total is None or total == b * world:
+    if total is None:
+        # shard sizes unknown: one small collective settles them (a mismatched all_gather_into_tensor would hang or
+        # return garbage instead of failing)
+        sizes = torch.zeros(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(sizes, torch.tensor([b], dtype=torch.int64, device=local.device))
+        sizes = sizes.tolist()
+        total = int(sum(sizes))
+        expect = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
+        if sizes != expect:
+            raise ValueError(f"all_gather_depth: per-rank batch sizes {sizes} are not the contiguous split {expect} of "
+                             f"{total} stacks that shard_bounds() deals out")
+    if total == b * world:
         out = local.new_empty((world * b,) + tuple(local.shape[1:]))
         dist.all_gather_into_tensor(out, local.contiguous())
         return out

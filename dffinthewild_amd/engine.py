@@ -160,7 +160,18 @@ class Engine:
         self._h = c_void_p()
         _check(lib.dffw_engine_create(self.index, net, arr, i, PRECISIONS[precision], byref(self._h)), "dffw_engine_create")
         self._ws = {}
+        self._ws_stream = None      # torch stream the cached workspace was last used on
         self._lock = threading.Lock()
+
+    # an Engine owns a dffw_engine* and a device workspace: a second owner would free the handle twice
+    def __copy__(self):
+        raise TypeError("dffinthewild_amd.engine.Engine cannot be copied: build a new one from the state dict")
+
+    def __deepcopy__(self, memo):
+        raise TypeError("dffinthewild_amd.engine.Engine cannot be copied: build a new one from the state dict")
+
+    def __reduce__(self):
+        raise TypeError("dffinthewild_amd.engine.Engine cannot be pickled: save the model's state_dict instead")
 
     def __del__(self, _destroy=lib.dffw_engine_destroy):
         h = getattr(self, "_h", None)
@@ -196,8 +207,19 @@ class Engine:
         """Run ``call(ws)`` (a C-ABI forward returning its status) on the cached workspace.  The size is cached per shape, but
         the engine's allocation path also depends on its DFFW_* switches (read per call): if it reports the workspace too
         small (-3) the size is asked for again under the present switches and the forward repeated once."""
+        cur = torch.cuda.current_stream(self.index)
+        if self._ws_stream is not None and self._ws_stream != cur and self._ws:
+            # the workspace is one buffer shared by successive forwards: a forward issued under another torch stream must
+            # not start before the previous one (on the old stream) is done with it
+            ev = torch.cuda.Event()
+            ev.record(self._ws_stream)
+            cur.wait_event(ev)
+        self._ws_stream = cur
         rc = call(self._workspace(B, N, H, W, extra))
         if rc == -3:
+            # kernels of the failed attempt (main and internal side streams were joined by the engine) may still be running:
+            # let them finish before the block goes back to the allocator
+            cur.synchronize()
             self._ws.clear()
             rc = call(self._workspace(B, N, H, W, extra))
         return rc

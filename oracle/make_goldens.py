@@ -31,6 +31,9 @@ CASES = [
     ("ddff_5x224",  1, 5, 224, 224, "bcast", "smooth", 0, 1005, False),
     ("full_10x256", 1, 10, 256, 256, "dense", "smooth", 0, 1006, False),
     ("he_10x256",   1, 10, 256, 256, "bcast", "he", 0, 1007, False),
+    # a second full-size stack under the weights of "full_10x256": the two sit at different positions of the batch-32
+    # test of BASELINE config 3 (tests/test_gpu_forward.py::test_config3_batch32_...)
+    ("full2_10x256", 1, 10, 256, 256, "dense", "smooth", 0, 1008, False),
 ]
 
 
@@ -54,7 +57,10 @@ def main():
     for k, shape, *_ in entries:
         assert tuple(ref_sd[k].shape) == tuple(shape), (k, ref_sd[k].shape, shape)
 
+    only = set(sys.argv[1:])          # optional: regenerate the named cases only
     for name, B, N, H, W, layout, profile, wseed, iseed, want_taps in CASES:
+        if only and name not in only:
+            continue
         sd = synth.state_dict_numpy(entries, seed=wseed, profile=profile)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
         FS, fd = case_inputs(B, N, H, W, layout, iseed)

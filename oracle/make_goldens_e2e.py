@@ -36,7 +36,10 @@ NET_CASES = [
     ("smooth_64x96", 64, 96, "smooth", 0, 3001, True),
     ("he_64x64", 64, 64, "he", 0, 3002, True),
     ("seed1_96x128", 96, 128, "smooth", 1, 3003, False),
+    # BASELINE config 5's stack size (the batch-8 test places it at two batch positions): pred3 whole, aligned stack sampled
+    ("smooth_480x640", 480, 640, "smooth", 0, 3004, False),
 ]
+ALIGNED_SAMPLE = (slice(None), slice(None), slice(0, 10, 3), slice(0, None, 16), slice(0, None, 16))   # of (1,3,10,H,W)
 
 
 def net_inputs(H, W, seed, N=10):
@@ -61,7 +64,10 @@ def network_goldens(out_dir):
     for tag, mod in (("head3", fa.conv1), ("head2", fa.conv2), ("head1", fa.conv3)):
         # the reference damps the head output in place afterwards (End_to_End.py:86): clone in the hook
         mod.register_forward_hook(lambda m, i, o, tag=tag: heads.__setitem__(tag, o.detach().clone()))
+    only = set(sys.argv[1:])          # optional: regenerate the named network cases only
     for name, H, W, profile, wseed, iseed, keep_all in NET_CASES:
+        if only and name not in only:
+            continue
         sd = synth.state_dict_numpy(entries, seed=wseed, profile=profile)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
         FS, fd, fov = net_inputs(H, W, iseed)
@@ -72,6 +78,8 @@ def network_goldens(out_dir):
         for nm, t in zip(("mid_out", "pred1", "pred2", "pred3", "aligned"), outs):
             if keep_all or nm == "pred3":
                 payload[nm] = t.numpy().astype(np.float32)
+        if H * W >= 480 * 640:
+            payload["aligned_sample"] = outs[4].numpy().astype(np.float32)[ALIGNED_SAMPLE]
         path = os.path.join(out_dir, f"e2e_net_{name}.npz")
         np.savez_compressed(path, **payload)
         print(name, tuple(outs[3].shape), "head1", payload["head1"][:, 0], os.path.getsize(path) // 1024, "KiB")
@@ -82,6 +90,8 @@ def main():
     warnings.filterwarnings("ignore")
     from End_to_End import FlowNetwork  # the reference, imported in place
     network_goldens(os.path.join(ROOT, "tests", "golden"))
+    if len(sys.argv) > 1:
+        return
     net = FlowNetwork(8).eval()
     out_dir = os.path.join(ROOT, "tests", "golden")
     for name, C, N, H, W, seed in CASES:
@@ -91,6 +101,26 @@ def main():
         path = os.path.join(out_dir, f"e2e_fov_warp_{name}.npz")
         np.savez_compressed(path, C=C, N=N, H=H, W=W, seed=seed, out=out.numpy(), flow=flow.numpy())
         print(name, out.shape, flow.shape, float(out.abs().mean()), os.path.getsize(path) // 1024, "KiB")
+    batch2_quirk_golden(out_dir)
+
+
+def batch2_inputs():
+    """Two different samples (inputs, warp parameters AND fields of view differ) for the batch>1 quirk golden."""
+    x0, a0, f0 = case_inputs(3, 10, 16, 32, 2004)
+    x1, a1, f1 = case_inputs(3, 10, 16, 32, 2005)
+    return np.concatenate([x0, x1]), np.concatenate([a0, 0.5 * a1]), np.concatenate([f0, (f1 * 1.01).astype(np.float32)])
+
+
+def batch2_quirk_golden(out_dir):
+    """The reference's FOV_warp called with batch 2 (End_to_End.py:112 broadcasts sample 0's scale offset to every sample,
+    each sample keeps its own FOV): what dffw_op_fov_warp(alpha_from_sample0=1) must reproduce."""
+    from End_to_End import FlowNetwork
+    x, alpha, fov = batch2_inputs()
+    with torch.no_grad():
+        out, flow = FlowNetwork(8).eval().FOV_warp(torch.from_numpy(x), torch.from_numpy(alpha), torch.from_numpy(fov))
+    path = os.path.join(out_dir, "e2e_fovwarp_batch2_quirk.npz")
+    np.savez_compressed(path, out=out.numpy(), flow=flow.numpy())
+    print("batch2 quirk", out.shape, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -117,3 +117,48 @@ def test_c_abi_argument_errors_without_gpu(eng):
     h = ctypes.c_void_p()
     assert lib.dffw_engine_create(0, 0, None, 0, 0, ctypes.byref(h)) == -1
     assert lib.dffw_workspace_bytes(None, 1, 1, 32, 32) < 0
+
+
+def test_network_deepcopy_and_pickle(eng, tmp_path):
+    """The usual nn.Module idioms (EMA / SWA clone, torch.save(model)): a copy carries the parameters only — never the lock
+    or the cache of ctypes engine handles — and has its own empty engine cache."""
+    import copy
+    import io
+    import pickle
+    from dffinthewild_amd import Network
+    from dffinthewild_amd.End_to_End import Network as E2E
+    for cls in (Network, E2E):
+        m = cls().eval()
+        m._engines[99] = ("fingerprint", object())        # stands for a packed engine: must not travel
+        c = copy.deepcopy(m)
+        assert c is not m and c._engines == {} and c._engines is not m._engines and c._guard is not m._guard
+        assert c._token is not m._token and c._inherited_fp is None and not c.training and c.precision == m.precision
+        for (k1, v1), (k2, v2) in zip(m.state_dict().items(), c.state_dict().items()):
+            assert k1 == k2 and v1.data_ptr() != v2.data_ptr() and torch.equal(v1, v2)
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        r = torch.load(buf, weights_only=False)
+        assert isinstance(r, cls) and r._engines == {} and list(r.state_dict()) == list(m.state_dict())
+        r.load_state_dict(m.state_dict())                  # a restored module is fully functional (token, lock recreated)
+        assert r._token[0] == 1
+        assert pickle.loads(pickle.dumps(m))._engines == {}
+    # the engine wrapper itself refuses: a second owner of the dffw_engine* would free it twice
+    e = eng.Engine.__new__(eng.Engine)
+    for op in (copy.copy, copy.deepcopy, pickle.dumps):
+        with pytest.raises(TypeError):
+            op(e)
+
+
+def test_comm_entry_points_fail_cleanly_without_gpu(eng):
+    """dffw_comm_* / dffw_allgather (RCCL, bound with dlopen at first use): bad arguments and a missing GPU give error codes
+    and messages, never a crash."""
+    lib = eng.lib
+    assert lib.dffw_allgather(None, None, None, 0, None) == -1 and b"null" in lib.dffw_last_error()
+    assert lib.dffw_comm_rank(None) == -1 and lib.dffw_comm_size(None) == -1
+    lib.dffw_comm_destroy(None)
+    h = ctypes.c_void_p()
+    assert lib.dffw_comm_init_rank(0, 2, 5, b"\0" * eng.COMM_ID_BYTES, ctypes.byref(h)) == -1 and not h.value
+    if not torch.cuda.is_available():
+        rc = lib.dffw_comm_init_rank(0, 1, 0, b"\0" * eng.COMM_ID_BYTES, ctypes.byref(h))
+        assert rc < 0 and not h.value and lib.dffw_last_error()

@@ -48,6 +48,13 @@ def _worker(rank, world, port, total, q):
     fov = 100.0 * torch.arange(total, dtype=torch.float32).reshape(total, 1, 1, 1, 1).expand(total, 1, 2, 1, 1).contiguous()
     outs5, g5 = ddist.sharded_depth(_fake_e2e_model, full[s:e], fd[s:e], fov[s:e], total=total)
     assert len(outs5) == 5 and g5[:, 0, 0].tolist() == [101.0 * i for i in range(total)]
+    # shard sizes not announced (total=None): the sizes are settled by one small collective first, equal and ragged alike
+    again = ddist.all_gather_depth(outs[3])
+    assert torch.equal(again, gathered)
+    # ... and sizes that are not the contiguous split raise on every rank instead of hanging in a mismatched collective
+    bad = outs[3][:1] if rank == 0 else torch.cat([outs[3], outs[3]])[: (e - s) + 1]
+    with pytest.raises(ValueError, match="contiguous split"):
+        ddist.all_gather_depth(bad)
     q.put((rank, gathered[:, 0, 0].tolist()))
     dist.barrier()
     dist.destroy_process_group()

@@ -17,7 +17,8 @@ from oracle.make_goldens_e2e import net_inputs
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "e2e_net_*.npz")))
 OUT_NAMES = ("mid_out", "pred1", "pred2", "pred3", "aligned")
-SMOOTH = [p for p in GOLDEN if "smooth" in p]
+SMOOTH = [p for p in GOLDEN if "smooth_64x96" in p]
+BIG = [p for p in GOLDEN if "480x640" in p]
 
 
 def load(path):
@@ -29,7 +30,7 @@ def load(path):
 
 
 def test_e2e_goldens_present():
-    assert len(GOLDEN) == 3
+    assert len(GOLDEN) == 4 and len(SMOOTH) == 1 and len(BIG) == 1
 
 
 def test_e2e_weight_contract():
@@ -118,6 +119,41 @@ def test_hip_e2e_matches_reference(lib_built, path):
             assert cpu_ref.rel_l2(o.cpu(), g[name]) <= 1e-3, name
             checked += 1
     assert checked >= 1
+
+
+@pytest.mark.gpu
+def test_hip_e2e_config5_batch8_480x640(lib_built):
+    """BASELINE config 5 at its stated size: 8 stacks of 10x3x480x640 in one call.  The stack of the reference golden
+    (End_to_End.Network run by oracle/make_goldens_e2e.py at 1x10x480x640) sits at batch positions 1 and 6 among six other
+    stacks; both must match the reference (pred3 whole, aligned stack on the golden's sample grid) and each other bit for
+    bit, and equal the batch-1 call (per-sample batch independence)."""
+    from oracle.make_goldens_e2e import ALIGNED_SAMPLE
+    g, sd, FS1, fd1, fov1 = load(BIG[0])
+    B, H, W = 8, int(g["H"]), int(g["W"])
+    assert (H, W) == (480, 640)
+    FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=555))
+    FS[1] = FS1[0]
+    FS[6] = FS1[0]
+    fov = fov1.expand(B, -1, -1, -1, -1).clone()
+    fov[2] = 1.0 + (fov1[0] - 1.0) * 0.5                     # other samples carry other warp geometry
+    fov[5] = 1.0 + (fov1[0] - 1.0) * 1.5
+    fd = fd1.expand(B, -1, -1, -1).contiguous()
+    m = _model(sd)
+    with torch.no_grad():
+        outs = m(FS.cuda(), fd.cuda(), fov.cuda())
+        single = m(FS1.cuda(), fd1.cuda(), fov1.cuda())
+    torch.cuda.synchronize()
+    for o in outs[:4]:
+        assert tuple(o.shape) == (B, H, W) and torch.isfinite(o).all()
+    for pos in (1, 6):
+        assert cpu_ref.rel_l2(outs[3][pos:pos + 1].cpu(), g["pred3"]) <= 1e-3, pos
+        assert cpu_ref.rel_l2(outs[4][pos:pos + 1].cpu().numpy()[ALIGNED_SAMPLE], g["aligned_sample"]) <= 1e-3, pos
+    for k in range(5):
+        assert torch.equal(outs[k][1], outs[k][6]), OUT_NAMES[k]
+        assert cpu_ref.rel_l2(outs[k][1:2].cpu(), single[k].cpu()) <= 1e-6, OUT_NAMES[k]      # bitwise in practice
+    assert not torch.equal(outs[3][1], outs[3][2])
+    lo, hi = float(fd1.min()), float(fd1.max())
+    assert float(outs[3].min()) >= lo - 1e-5 and float(outs[3].max()) <= hi + 1e-5
 
 
 @pytest.mark.gpu

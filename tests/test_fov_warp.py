@@ -44,21 +44,36 @@ def test_hip_fov_warp_matches_reference(lib_built, path):
     assert cpu_ref.rel_l2(out.cpu(), g["out"]) <= 1e-5
 
 
+def _leak_inputs():
+    from oracle.make_goldens_e2e import batch2_inputs
+    x, alpha, fov = (torch.from_numpy(a) for a in batch2_inputs())
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_fovwarp_batch2_quirk.npz"))
+    # what the reference's broadcast amounts to (End_to_End.py:112): sample 0's scale offset, each sample's own FOV
+    alpha_leak = alpha.clone()
+    alpha_leak[1, 0] = alpha[0, 0]
+    return x, alpha, fov, alpha_leak, g
+
+
+def test_oracle_reproduces_reference_batch2_quirk():
+    """Golden = the reference's own FOV_warp called with batch 2: equals per-sample warps with alpha[0]'s scale offset."""
+    x, alpha, fov, alpha_leak, g = _leak_inputs()
+    out, flow = cpu_ref.fov_warp(x, alpha_leak, fov)
+    assert float((flow - torch.from_numpy(g["flow"])).abs().max()) <= 1e-5
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-5
+    out_ps, _ = cpu_ref.fov_warp(x, alpha, fov)          # the per-sample semantics differ from it for sample 1 only
+    assert torch.equal(out_ps[0], out[0]) and not torch.allclose(out_ps[1], out[1], atol=1e-3)
+
+
 @pytest.mark.gpu
 def test_hip_fov_warp_batch_semantics(lib_built):
-    """Per-sample semantics for batch > 1 (= stack of batch-1 reference calls); the compat switch reproduces
-    the reference's alpha broadcast (every sample takes sample 0's scale offset and FOV)."""
+    """Per-sample semantics for batch > 1 (= stack of batch-1 reference calls); the compat switch reproduces the reference's
+    batch>1 broadcast as the reference itself computes it (golden from its FOV_warp at batch 2): sample 0's scale offset,
+    every sample's own FOV."""
     from dffinthewild_amd import engine
-    parts = [load(p) for p in GOLDEN if "rgb" in p or "wide" in p]
-    _, x0, a0, f0 = parts[0]
-    x = torch.cat([x0, x0.flip(-1)], 0)
-    alpha = torch.cat([a0, a0 * 0.5], 0)
-    fov = torch.cat([f0, f0 * 1.01], 0)
+    x, alpha, fov, alpha_leak, g = _leak_inputs()
     ref, _ = cpu_ref.fov_warp(x, alpha, fov)
     out, _ = engine.op_fov_warp(x.cuda(), alpha.cuda(), fov.cuda())
     assert cpu_ref.rel_l2(out.cpu(), ref) <= 1e-5
-    alpha_leak = alpha.clone(); alpha_leak[1, 0] = alpha[0, 0]
-    fov_leak = fov.clone(); fov_leak[1] = fov[0]
-    ref_leak, _ = cpu_ref.fov_warp(x, alpha_leak, fov_leak)
-    out_leak, _ = engine.op_fov_warp(x.cuda(), alpha.cuda(), fov.cuda(), compat_batch_alpha0=True)
-    assert cpu_ref.rel_l2(out_leak.cpu(), ref_leak) <= 1e-5
+    out_leak, flow_leak = engine.op_fov_warp(x.cuda(), alpha.cuda(), fov.cuda(), compat_batch_alpha0=True)
+    assert float((flow_leak.cpu() - torch.from_numpy(g["flow"])).abs().max()) <= 2e-5
+    assert cpu_ref.rel_l2(out_leak.cpu(), g["out"]) <= 1e-5

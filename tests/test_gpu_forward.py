@@ -216,7 +216,53 @@ def test_full_size_properties(lib_built):
     assert cpu_ref.rel_l2(outs2[3].cpu(), (outs[3] * 3.0).cpu()) <= 1e-6
 
 
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_STREAM", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
+def test_config3_batch32_two_goldens_and_properties(lib_built, monkeypatch):
+    """BASELINE config 3 at its stated batch: 32 stacks of 10x3x256x256 in one call (3.5 GB arena; at this size the
+    confidence branch stays on the main stream and the pyramid's concurrency thresholds differ from the small-batch
+    tests).  Two DIFFERENT reference goldens (den_full_10x256, den_full2_10x256: same weights, different stacks) sit at
+    batch positions 3 and 29, an identical pair at 7 / 19; size-independent properties over all 32 maps: depth inside
+    [min fd, max fd] (convex combination), identical stacks -> identical maps, linear in focus_dists.  Then the same
+    batch with the side streams off (DFFW_NO_CONCURRENT) and with the confidence branch un-forked (DFFW_NO_CONF_FORK)."""
+    ga, meta, FSa, fda, sd = case([p for p in GOLDEN if "den_full_10x256" in p][0])
+    gb, metab, FSb, fdb, _ = case([p for p in GOLDEN if "den_full2_10x256" in p][0])
+    assert (meta["wseed"], meta["profile"]) == (metab["wseed"], metab["profile"]) and meta["iseed"] != metab["iseed"]
+    B, N, H, W = 32, 10, 256, 256
+    model = model_for(sd, (meta["wseed"], meta["profile"]))
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=4321))
+    FS[3] = FSa[0]
+    FS[29] = FSb[0]
+    FS[19] = FS[7]
+    fd = fda.expand(B, -1, -1, -1).contiguous()          # dense (B,N,H,W), as the golden's layout
+    FSd, fdd = FS.cuda(), fd.cuda()
+
+    def check(outs):
+        for o in outs:
+            assert tuple(o.shape) == (B, H, W) and torch.isfinite(o).all()
+            assert float(o.min()) >= 0.1 - 1e-5 and float(o.max()) <= 1.5 + 1e-5
+            assert torch.equal(o[7], o[19])
+        assert cpu_ref.rel_l2(outs[3][3].cpu(), ga["pred3"][0]) <= OUT_TOL["bf16x3"]
+        assert cpu_ref.rel_l2(outs[3][29].cpu(), gb["pred3"][0]) <= OUT_TOL["bf16x3"]
+        assert not torch.equal(outs[3][3], outs[3][29])
+
+    with torch.no_grad():
+        outs = model(FSd, fdd)
+        outs3 = model(FSd, fdd * 3.0)
+    torch.cuda.synchronize()
+    check(outs)
+    for a, b in zip(outs3, outs):
+        assert cpu_ref.rel_l2(a.cpu(), (b * 3.0).cpu()) <= 1e-6
+    for env in ("DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK"):
+        monkeypatch.setenv(env, "1")
+        with torch.no_grad():
+            alt = model(FSd, fdd)
+        torch.cuda.synchronize()
+        monkeypatch.delenv(env)
+        check(alt)
+        for a, b in zip(alt, outs):
+            assert torch.equal(a, b), env              # same kernels, only their stream placement differs
+
+
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK", "DFFW_NO_PP", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
                                  "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
