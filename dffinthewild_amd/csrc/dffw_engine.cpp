@@ -19,6 +19,9 @@
 #include "dffw_conv_roll.h"
 #include "dffw_srd_roll.h"
 #include "dffw_conv_tile.h"
+#ifdef DFFW_WITH_PP
+#include "dffw_conv_pp.h"
+#endif
 #include "dffw_internal.h"
 
 namespace dffw {
@@ -1009,7 +1012,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(NO_PP)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1018,7 +1021,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1034,6 +1037,7 @@ struct Switches {
         };
         s.roll_wgs = geti("DFFW_ROLL_WGS", 8, 0);
         s.srd_wgs = geti("DFFW_SRD_WGS", 8, 0);
+        s.pp_wgs = geti("DFFW_PP_WGS", 8, 0);
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
         { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
@@ -1246,7 +1250,7 @@ struct Run {
         a.relu = o.relu;
         if (!dry && e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
-        a.dbg = sw.debug_flags & 7;
+        a.dbg = sw.debug_flags & (7 | 48 | 64);
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
@@ -1438,6 +1442,29 @@ struct Run {
                     if (t.nsplit >= want) break;
                 }
             }
+            // ping-pong kernel (dffw_conv_pp.hip; rejected experiment, built only with `make PP=1` and selected with DFFW_PP=1:
+            // measured 8 % SLOWER than conv_tile on dres2.conv0): persistent workgroups whose wave groups
+            // alternate contraction and fill / epilogue
+            bool use_pp = false;
+#ifdef DFFW_WITH_PP
+            if (sw.on(SW_PP) && tp.cfg->nw == 4 && tp.nstage >= 2 && !o.outf && !o.cls && !o.res_bcast && !a.fs32 && tp.npass == 1) {
+                // the widest output-channel slab that has an instantiation and leaves at least two units per CU
+                const TileCfg *pcfg = nullptr;
+                int ns = 0;
+                for (int nts = tp.cfg->nt; nts >= 1; nts /= 2) {
+                    const TileCfg *c2 = nts == tp.cfg->nt ? tp.cfg : tile_cfg_find_like(tp.cfg, nts);
+                    if (!c2 || !conv_pp_has(c2)) continue;
+                    pcfg = c2;
+                    ns = tp.cfg->nt / nts;
+                    if (t.total_tiles * ns >= 512) break;
+                }
+                if (pcfg && t.total_tiles * ns >= 256) {
+                    use_pp = true;
+                    cfg = pcfg;
+                    t.nsplit = ns;
+                }
+            }
+#endif
             t.grid = 8 * ((t.total_tiles + 7) / 8);   // one tile per workgroup, grid a multiple of the 8 XCDs
             // split-K: when even the channel split leaves most CUs idle and the contraction is several channel-group
             // stages deep, the stages are dealt to grid.z workgroups (fp32 partials, summed in fixed order by
@@ -1448,7 +1475,18 @@ struct Run {
             // transposed conv on few tiles: its 4 sub-pixel passes as 4 workgroups (no reduction, any epilogue)
             const int thr = sw.split_wg;
             t.pass_split = (L.transposed && t.total_tiles * t.nsplit <= thr && !sw.on(SW_NO_SPLITK)) ? 1 : 0;
-            if (!t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
+#ifdef DFFW_WITH_PP
+            if (use_pp) {
+                t.pass_split = 0;
+                { const char *z = getenv("DFFW_PP_PACE"); t.ksplit = z ? atoi(z) : 1; }     // experiment knobs (not switches)
+                { const char *z = getenv("DFFW_PP_PRIO"); t.pass_split = z ? atoi(z) : 0; }
+                const int ng = conv_pp_groups(cfg);
+                const int sets = (t.total_tiles * t.nsplit + ng - 1) / ng;
+                t.grid = std::min(256, 8 * ((sets + 7) / 8));   // persistent: at most one workgroup (ng wave groups) per CU
+                if (sw.pp_wgs) t.grid = std::min(t.grid, sw.pp_wgs / 8 * 8);   // test knob: longer unit streams per workgroup
+            }
+#endif
+            if (!use_pp && !t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
                 !sw.on(SW_NO_SPLITK)) {
                 const int want = 256 / (t.total_tiles * t.nsplit);
                 t.ksplit = std::max(1, std::min(std::min(tp.nstage, want), 8));
@@ -1479,6 +1517,9 @@ struct Run {
                 if (use_stream) return conv_stream_kernel_name(e->prec, scfg, kn, n);
 #endif
                 (void)scfg;
+#ifdef DFFW_WITH_PP
+                if (use_pp) return conv_pp_kernel_name(e->prec, cfg, kn, n);
+#endif
                 conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & DFFW_ARGS_RAW), kn, n);
             };
             {
@@ -1500,6 +1541,32 @@ struct Run {
             if (use_stream) {
                 check(launch_conv_stream(e->prec, scfg, a, t, s), name.c_str());
                 prof_end();
+                return out;
+            }
+#endif
+#ifdef DFFW_WITH_PP
+            if (use_pp) {
+                // debug timeline of one layer (make TRACE=1): DFFW_TRACE_LAYER=<layer name> DFFW_TRACE_OUT=<file>; per workgroup
+                // 512 slots x 2 groups x 4 x u64 (tools/trace_pp.py)
+                unsigned long long *trace = nullptr;
+                const size_t tbytes = (size_t)t.grid * 512 * 4 * 4 * 8;
+                if (sw.trace_layer && sw.trace_out && name == sw.trace_layer) {
+                    check(hipMalloc((void **)&trace, tbytes), "trace alloc");
+                    if (ok()) check(hipMemsetAsync(trace, 0, tbytes, s), "trace memset");
+                    a.trace = trace;
+                }
+                check(launch_conv_pp(e->prec, cfg, a, t, s), name.c_str());
+                prof_end();
+                if (trace && ok()) {
+                    std::vector<unsigned long long> host(tbytes / 8);
+                    check(hipStreamSynchronize(s), "trace sync");
+                    check(hipMemcpy(host.data(), trace, tbytes, hipMemcpyDeviceToHost), "trace copy");
+                    if (FILE *f = fopen(sw.trace_out, "wb")) {
+                        fwrite(host.data(), 8, host.size(), f);
+                        fclose(f);
+                    }
+                    (void)hipFree(trace);
+                }
                 return out;
             }
 #endif
