@@ -110,6 +110,17 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
                      "profiling mode the engine runs the pyramid's three scales one after the other (side by side, as in the timed "
                      "steps, small kernels share the chip and a launch's duration is not the kernel's own)",
     }
+    # what this box sustains (the chip clocks to its power budget: a register-resident MFMA loop and a streaming copy, timed with
+    # HIP events like the kernels above): the same fractions against the measured ceilings
+    try:
+        from dffinthewild_amd import engine as _eng
+        m_tf, h_gbs = _eng.probe_peaks(device.index or 0)
+        roof["measured_ceilings"] = {"mfma_tflops": round(m_tf, 1), "hbm_copy_gbs": round(h_gbs, 1),
+                                     "frac_of_measured": round((gbs / h_gbs) if hbm_bound else (tf * issue / m_tf), 4),
+                                     "note": "v_mfma_f32_16x16x32_bf16 back to back out of registers on every SIMD / float4 copy of 1 GiB, on this GPU, "
+                                             "just now; frac_of_measured = this kernel's rate (x MFMA issues per product) over that"}
+    except Exception as exc:   # noqa: BLE001 -- a failed probe must not cost the bench line
+        roof["measured_ceilings"] = {"error": str(exc)}
     # whole forward against its layer-by-layer roofline: sum over launches of max(MFMA time, HBM time) with each launch's
     # algorithmic FLOPs (x3 MFMA issue in the split-bf16 mode) and algorithmic bytes ("the exact ceiling is the
     # per-layer sum of max(.,.)")

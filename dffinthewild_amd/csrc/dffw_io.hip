@@ -328,3 +328,70 @@ int dffw_metrics(int device, const float *est, int B, int H, int W, const float 
 }
 
 }  // extern "C"
+
+// ---- dffw_probe_peaks: what this very GPU sustains, measured the same way bench.py measures the kernels (HIP events) -----------
+// The roofline fractions are quoted against the datasheet (2.5 PFLOP/s dense bf16 MFMA, 8 TB/s HBM3E).  A chip clocks to its
+// power budget, so the sustained ceilings are lower and differ between boxes; this probe reports them for the box the bench runs
+// on: (a) v_mfma_f32_16x16x32_bf16 issued back to back out of registers (10 independent accumulators, 3 waves per SIMD, no
+// memory traffic at all), (b) a float4 streaming copy of 1 GiB (read + write counted).
+namespace dffw {
+typedef __attribute__((ext_vector_type(8))) __bf16 probe_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float probe_f32x4;
+
+__global__ __launch_bounds__(256) void probe_mfma_kernel(float *out, int iters, unsigned seed) {
+    probe_bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) {
+        const unsigned h = (threadIdx.x * 8 + i) * 2654435761u + seed;     // random-looking operands: zeros would clock higher
+        a[i] = (__bf16)((float)((h >> 8) & 255) * 0.01f - 1.f);
+        b[i] = (__bf16)((float)((h >> 16) & 255) * 0.01f - 1.f);
+    }
+    probe_f32x4 acc[10];
+    for (int k = 0; k < 10; ++k) acc[k] = probe_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int k = 0; k < 10; ++k) s += acc[k][0] + acc[k][3];
+    if (s == 12345.678f) out[threadIdx.x] = s;    // never true: keeps the loop alive
+}
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace dffw
+
+extern "C" int dffw_probe_peaks(int device, float *mfma_tflops, float *hbm_gbs, void *hip_stream) {
+    if (!mfma_tflops || !hbm_gbs) return dffw_fail(DFFW_EINVAL, "null argument");
+    IO_HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipEvent_t e0, e1;
+    IO_HIPCHK(hipEventCreate(&e0));
+    IO_HIPCHK(hipEventCreate(&e1));
+    const int64_t bytes = (int64_t)1 << 30;
+    char *buf = nullptr;
+    IO_HIPCHK(hipMalloc((void **)&buf, 2 * bytes));
+    IO_HIPCHK(hipMemsetAsync(buf, 1, 2 * bytes, s));
+    float best_m = 1e30f, best_c = 1e30f, ms = 0.f;
+    const int iters = 4000, blocks = 256 * 3;
+    for (int rep = 0; rep < 4; ++rep) {   // first repetition = warm-up
+        IO_HIPCHK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(dffw::probe_mfma_kernel, dim3(blocks), dim3(256), 0, s, (float *)buf, iters, 7u + rep);
+        IO_HIPCHK(hipEventRecord(e1, s));
+        IO_HIPCHK(hipEventSynchronize(e1));
+        IO_HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms < best_m) best_m = ms;
+        IO_HIPCHK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(dffw::probe_copy_kernel, dim3(256 * 32), dim3(256), 0, s, (const float4 *)buf, (float4 *)(buf + bytes), bytes / 16);
+        IO_HIPCHK(hipEventRecord(e1, s));
+        IO_HIPCHK(hipEventSynchronize(e1));
+        IO_HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms < best_c) best_c = ms;
+    }
+    *mfma_tflops = (float)((double)blocks * 4 * iters * 10 * (2.0 * 16 * 16 * 32) / (best_m * 1e-3) / 1e12);
+    *hbm_gbs = (float)(2.0 * (double)bytes / (best_c * 1e-3) / 1e9);
+    (void)hipFree(buf);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return DFFW_OK;
+}

@@ -13,7 +13,8 @@ from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdffw.so")
+# DFFW_LIB_PATH: load another build of the same library (A/B measurements of kernel variants on one box); in-tree by default
+LIB_PATH = os.environ.get("DFFW_LIB_PATH") or os.path.join(_HERE, "libdffw.so")
 
 PRECISIONS = {"bf16x3": 0, "fp16": 1, "bf16": 2}
 NET_DEPTH = 0   # Depth_Estimation_Network.Network: DFF_net alone
@@ -89,6 +90,7 @@ def _load():
     lib.dffw_comm_rank.argtypes = [c_void_p]
     lib.dffw_comm_size.argtypes = [c_void_p]
     lib.dffw_allgather.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+    lib.dffw_probe_peaks.argtypes = [c_int, POINTER(c_float), POINTER(c_float), c_void_p]
     return lib
 
 
@@ -104,7 +106,7 @@ ABI_SYMBOLS = (
     "dffw_op_fov_warp", "dffw_forward_e2e", "dffw_last_conv_kernel",
     "dffw_forward_raw", "dffw_pack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
     "dffw_comm_unique_id", "dffw_comm_init_rank", "dffw_comm_init_all", "dffw_comm_destroy", "dffw_comm_rank", "dffw_comm_size",
-    "dffw_allgather", "dffw_comm_group_start", "dffw_comm_group_end",
+    "dffw_allgather", "dffw_comm_group_start", "dffw_comm_group_end", "dffw_probe_peaks",
 )
 
 
@@ -337,6 +339,14 @@ def op_conv3d(x, weight, *, stride=1, pad=0, dilation=1, transposed=False, bn=No
                                   c_void_p(res.data_ptr()) if res is not None else None, relu,
                                   c_void_p(y.data_ptr()), _stream_ptr(dev)), "dffw_op_conv3d")
     return y
+
+
+def probe_peaks(device=0):
+    """(sustained bf16 MFMA TFLOP/s, sustained HBM copy GB/s) of this GPU, measured now (dffw_probe_peaks)."""
+    m, h = c_float(), c_float()
+    with torch.cuda.device(device):
+        _check(lib.dffw_probe_peaks(device, byref(m), byref(h), _stream_ptr(device)), "dffw_probe_peaks")
+    return m.value, h.value
 
 
 def last_conv_kernel():

@@ -224,6 +224,11 @@ int64_t dffw_metrics_scratch_bytes(int B);
 int dffw_metrics(int device, const float *est, int B, int H, int W, const float *gt, const uint8_t *mask,
                  const float *conf, int h, int w, double *out, void *scratch, int64_t scratch_bytes, void *hip_stream);
 
+/* ---- measured ceilings of the GPU at hand (bench.py prints them beside the datasheet peaks) -------------------------------
+ * mfma_tflops: v_mfma_f32_16x16x32_bf16 issued back to back out of registers on every SIMD (no memory traffic);
+ * hbm_gbs: float4 streaming copy of 1 GiB, read + write counted.  Synchronises; allocates 2 GiB for the duration of the call. */
+int dffw_probe_peaks(int device, float *mfma_tflops, float *hbm_gbs, void *hip_stream);
+
 /* ---- multi-GPU: RCCL all-gather of the depth maps ---------------------------------------------
  * The forward has no cross-sample operation, so a batch is sharded on dim 0 over the GPUs of a node with no data-path
  * collective; what the reference's nn.DataParallel does after the replicas finish (Depth_Estimation_Test/test.py:32:
