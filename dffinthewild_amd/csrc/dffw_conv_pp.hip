@@ -334,9 +334,15 @@ __global__ __launch_bounds__(NG * 256) void conv_pp(const ConvArgs a, const Tile
 // ---- configurations: the conv_tile configurations (same ids, same packing) that have a ping-pong instantiation ------
 //        id  geo   NT  TZ TY  TX  CG  NG
 #define DFFW_PP_CONFIGS(X)         \
-    X(0, G3S1, 1, 5, 4, 16, 16, 3) \
-    X(2, G3S1, 2, 5, 4, 16, 16, DFFW_PP_NG2) \
-    X(16, G3S1, 2, 4, 4, 8, 16, 3)
+    X(0, G3S1, 1, 5, 4, 16, 16, 2) \
+    X(1, G3S1, 1, 5, 4, 16, 8, 2)  \
+    X(2, G3S1, 2, 5, 4, 16, 16, 2) \
+    X(16, G3S1, 2, 4, 4, 8, 16, 3) \
+    X(5, G3S2, 1, 5, 4, 16, 8, 2)  \
+    X(6, G3S2, 2, 5, 4, 16, 8, 2)  \
+    X(12, G2S1, 1, 5, 4, 16, 8, 2) \
+    X(13, G2S1, 1, 5, 4, 16, 16, 2) \
+    X(18, G2S1, 2, 5, 4, 16, 8, 2)
 
 #ifndef DFFW_PP_NG2
 #define DFFW_PP_NG2 2

@@ -639,7 +639,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(27, G3T, 1, 5, 8, 16, 16, 0)   \
     X(28, G2S1, 1, 5, 8, 16, 8, 0)   \
     X(29, G2S1, 1, 5, 8, 16, 16, 0)  \
-    X(30, G2S1, 2, 5, 8, 16, 16, 1)  \
+    X(30, G2S1, 2, 5, 8, 16, 16, 0)  \
     X(31, G2D, 1, 1, 32, 32, 8, 0)   \
     X(33, G2P, 1, 1, 32, 32, 8, 0)
 

@@ -1447,7 +1447,7 @@ struct Run {
             // alternate contraction and fill / epilogue
             bool use_pp = false;
 #ifdef DFFW_WITH_PP
-            if (sw.on(SW_PP) && tp.cfg->nw == 4 && tp.nstage >= 2 && !o.outf && !o.cls && !o.res_bcast && !a.fs32 && tp.npass == 1) {
+            if (sw.on(SW_PP) && tp.cfg->nw == 4 && !o.outf && !o.cls && !o.res_bcast && !a.fs32 && tp.npass == 1) {
                 // the widest output-channel slab that has an instantiation and leaves at least two units per CU
                 const TileCfg *pcfg = nullptr;
                 int ns = 0;

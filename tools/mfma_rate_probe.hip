@@ -70,6 +70,13 @@ void run(int waves_per_simd, float *out) {
 int main() {
     float *out;
     hipMalloc(&out, 4096);
+    // dependent chains: ACC = 1 is one accumulator fed back to back (what a 3-product split-bf16 tile loop does when a wave owns
+    // ONE operand tile), 2 / 3 = that many independent chains
+    for (int w = 1; w <= 3; ++w) {
+        run<16, 1>(w, out);
+        run<16, 2>(w, out);
+        run<16, 3>(w, out);
+    }
     for (int w = 1; w <= 3; ++w) {
         run<16, 4>(w, out);
         run<16, 10>(w, out);
