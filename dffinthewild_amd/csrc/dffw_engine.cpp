@@ -513,6 +513,9 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         // transposed conv: its 4 sub-pixel passes share one LDS image only when the whole contraction depth is
         // staged at once, so 32-channel groups (one fill instead of 4 x 2) where an instantiation exists
         if (geo == G3T && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;
+        // per-slice 1x3x3 over 32 channels: ONE 32-channel stage per tile (each 128-byte pixel line is fetched once instead of
+        // half of it per 16-channel stage -- the memory side moves whole 128-byte lines, profiles/r02_fetch_size_calibration.txt)
+        if (geo == G2S1 && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;   // +4..14 % on those layers
         // wide (8-wave, 640-point) tile wherever an instantiation exists (dffw_conv_tile.hip lists what was measured)
         const bool wide = !getenv("DFFW_NO_WIDE");
         // pair: the stem's pixel-pair form (G2P) -- result rows 8-15 carry the filter as pixel x+2 sees the same records, and the
