@@ -285,7 +285,9 @@ def launch_ranks(n):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's stdout also carries the communication library's banner lines: pass on the JSON line only (the rest to stderr)
+    for line in out.decode().splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 
@@ -305,7 +307,8 @@ def measure_allgather(local, world, iters=20):
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     sec = float(t.item())
     nbytes = local.numel() * local.element_size()
-    return {"collective": "all_gather_into_tensor (backend nccl = RCCL over xGMI)", "ranks": torch.distributed.get_world_size(),
+    return {"collective": f"all_gather_into_tensor (backend {torch.distributed.get_backend()}" + (" = RCCL over xGMI)" if torch.distributed.get_backend() == "nccl" else ", test rig)"),
+            "ranks": torch.distributed.get_world_size(),
             "bytes_per_rank": nbytes, "result_bytes": nbytes * world, "us_per_call": round(sec * 1e6, 1),
             "algbw_GBs": round(nbytes * world / sec / 1e9, 2), "busbw_GBs": round(nbytes * (world - 1) / sec / 1e9, 2),
             "sample": f"{iters} back-to-back calls after 3 warm-ups, outside the timed steps (each timed step also contains one)"}
@@ -342,10 +345,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DFFW_BENCH_ONE_DEVICE=1 (test rig for the multi-process path on a one-GPU box): every rank on cuda:0, gloo instead of RCCL
+    one_dev = os.environ.get("DFFW_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        ddist.init_process_group("nccl")
+        ddist.init_process_group("gloo" if one_dev else "nccl", set_device=not one_dev)
 
     e2e = args.workload == "e2e"
     B, N = args.batch or (8 if e2e else 32), args.slices
@@ -413,7 +419,7 @@ def main():
                                     f"(BASELINE.json config 3{'/4' if world > 1 else ''}), dense focus_dists, "
                                     f"synthetic weights seed 0"),
                        "batch_per_gpu": B, "global_batch": B * world, "slices": N, "height": Hh, "width": Ww,
-                       "parallelism": f"batch-sharded x{world}, RCCL all-gather of pred3" if world > 1 else "single GPU",
+                       "parallelism": (f"batch-sharded x{world}, RCCL all-gather of pred3" if not one_dev else f"TEST RIG: {world} ranks on one GPU, gloo") if world > 1 else "single GPU",
                        "precision": args.precision, "input": "uint8 (B,N,H,W,3), normalised in the stem kernel" if raw_u8 is not None
                        else "float32 (B,3,N,H,W), the reference's tensor contract"},
             "forward_tflops_algorithmic": round(value * GFLOP_PER_STACK * scale / 1e3, 2),   # DFF_net's convs only

@@ -19,7 +19,7 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, set_device=True):
     """Join the job's process group (no-op for a single process).  ``nccl`` is RCCL on ROCm."""
     rank, local_rank, world = env_world()
     if world == 1 or dist.is_initialized():
@@ -28,7 +28,7 @@ def init_process_group(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    if backend == "nccl":
+    if backend == "nccl" and set_device:
         torch.cuda.set_device(local_rank)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
@@ -51,6 +51,9 @@ def all_gather_depth(local, total=None):
         return local
     world = dist.get_world_size()
     b = local.shape[0]
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # test configuration only (several ranks sharing one GPU, no RCCL): gloo gathers host tensors
+        return all_gather_depth(local.cpu(), total).to(local.device)
     if total is None:
         # shard sizes unknown: one small collective settles them (a mismatched all_gather_into_tensor would hang or
         # return garbage instead of failing)
