@@ -113,11 +113,13 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
     # what this box sustains (the chip clocks to its power budget: a register-resident MFMA loop and a streaming copy, timed with
     # HIP events like the kernels above): the same fractions against the measured ceilings
     try:
+        if os.environ.get("DFFW_NO_PROBE") == "1":       # (profiler runs: keep the probe kernels out of the kernel statistics)
+            raise RuntimeError("skipped (DFFW_NO_PROBE=1)")
         from dffinthewild_amd import engine as _eng
         m_tf, h_gbs = _eng.probe_peaks(device.index or 0)
         roof["measured_ceilings"] = {"mfma_tflops": round(m_tf, 1), "hbm_copy_gbs": round(h_gbs, 1),
                                      "frac_of_measured": round((gbs / h_gbs) if hbm_bound else (tf * issue / m_tf), 4),
-                                     "note": "v_mfma_f32_16x16x32_bf16 back to back out of registers on every SIMD / float4 copy of 1 GiB, on this GPU, "
+                                     "note": "v_mfma_f32_16x16x32_bf16 back to back out of registers on every SIMD / float4 streaming (copy or read, the better), on this GPU, "
                                              "just now; frac_of_measured = this kernel's rate (x MFMA issues per product) over that"}
     except Exception as exc:   # noqa: BLE001 -- a failed probe must not cost the bench line
         roof["measured_ceilings"] = {"error": str(exc)}

@@ -226,7 +226,8 @@ int dffw_metrics(int device, const float *est, int B, int H, int W, const float 
 
 /* ---- measured ceilings of the GPU at hand (bench.py prints them beside the datasheet peaks) -------------------------------
  * mfma_tflops: v_mfma_f32_16x16x32_bf16 issued back to back out of registers on every SIMD (no memory traffic);
- * hbm_gbs: float4 streaming copy of 1 GiB, read + write counted.  Synchronises; allocates 2 GiB for the duration of the call. */
+ * hbm_gbs: float4 streaming (copy of 1 GiB with read + write counted, or a pure read of 2 GiB: the better).  Synchronises;
+ * allocates 2 GiB for the duration of the call. */
 int dffw_probe_peaks(int device, float *mfma_tflops, float *hbm_gbs, void *hip_stream);
 
 /* ---- multi-GPU: RCCL all-gather of the depth maps ---------------------------------------------

@@ -12,3 +12,5 @@ cp $src/bench_e2e_b1.json $dst/${tag}_bench_e2e_b1_480x640.json
 cp $src/layers_e2e.tsv $dst/${tag}_layers_e2e_b8_480x640.tsv
 python tools/hbm_traffic.py $src/pmc_fetch/pmc_counter_collection.csv $src/pmc_write/pmc_counter_collection.csv $src/bench_default.json $dst/${tag}_hbm_traffic.json
 python tools/pmc_summary.py $src/pmc_fetch/pmc_counter_collection.csv $src/pmc_write/pmc_counter_collection.csv > $dst/${tag}_pmc_hbm_traffic.txt
+python tools/pmc_summary.py $src/pmc_sq1/pmc_counter_collection.csv $src/pmc_sq2/pmc_counter_collection.csv > $dst/${tag}_pmc_conv_kernels.txt
+python tools/pmc_derive.py $src/pmc_sq1/pmc_counter_collection.csv $src/pmc_sq2/pmc_counter_collection.csv >> $dst/${tag}_pmc_conv_kernels.txt

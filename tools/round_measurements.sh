@@ -15,9 +15,12 @@ python bench.py --workload e2e --dump-layers $out/layers_e2e.tsv > $out/bench_e2
 python bench.py --workload e2e --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > $out/bench_e2e_b1.json 2>/dev/null
 # kernel durations: with the pyramid branches serialised, as in bench.py's own profiled forward (side by side, three small kernels
 # share the chip and each one's duration says nothing about the kernel)
-export DFFW_NO_CONCURRENT=1
+export DFFW_NO_CONCURRENT=1 DFFW_NO_PROBE=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/rocprof_bench.json 2> $out/rocprof.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-unset DFFW_NO_CONCURRENT
+# wave-state / matrix-pipe / LDS counters of the conv kernels (two passes: 8 SQ slots each), batch 32
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_sq1 -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $out/pmc_sq2 -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+unset DFFW_NO_CONCURRENT DFFW_NO_PROBE
 for f in $out/bench_*.json; do echo "$f: $(cut -c1-110 $f)"; done
