@@ -1015,7 +1015,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1024,7 +1024,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1041,6 +1041,7 @@ struct Switches {
         s.roll_wgs = geti("DFFW_ROLL_WGS", 8, 0);
         s.srd_wgs = geti("DFFW_SRD_WGS", 8, 0);
         s.pp_wgs = geti("DFFW_PP_WGS", 8, 0);
+        s.small_max_units = geti("DFFW_SMALL_MAX_UNITS", 0, 0);
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
         { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
@@ -1404,8 +1405,12 @@ struct Run {
                 return out;
             }
         }
+        // small grids (the low-resolution pyramid at batch 1): conv_small's one-workgroup-per-(16 points, 16 channels) split of the
+        // whole layer beats an LDS tile that a few workgroups walk stage by stage (+ a split-K finish launch)
+        const int64_t small_units = ((int64_t)in0.B * (L.transposed ? in0.N : No) * gH * gW + 15) / 16 * pc.nt;
+        const bool prefer_small = small_units <= sw.small_max_units && !o.cls && !o.fs32 && !sw.on(SW_NO_SMALL) && !stem_pair;
         const bool use_tile = tp.cfg && !sw.on(SW_NO_TILE) && gW * 2 >= tp.cfg->tx && gH * 2 >= tp.cfg->ty &&
-                              in0.C % 8 == 0 && (!o.in1 || o.in1->C % 8 == 0);
+                              in0.C % 8 == 0 && (!o.in1 || o.in1->C % 8 == 0) && !prefer_small;
         if (use_tile) {
             const TileCfg *cfg = tp.cfg;   // may be replaced by a narrower instantiation of the same tile (channel split)
             a.Ng = L.transposed ? in0.N : No;
@@ -1621,14 +1626,15 @@ struct Run {
                 a.ooy = a.oox = 0;
             }
             a.M = (int64_t)a.B * a.Ng * a.Hg * a.Wg;
+            if (sw.on(SW_NO_SMALL)) a.dbg |= 32;   // (bit 5 of dbg: conv_igemm also for small grids)
             {
                 char kn[64];
-                conv_kernel_name(e->prec, L.cout, kn, sizeof kn);
+                conv_kernel_name_for(e->prec, a, kn, sizeof kn);
                 g_last_kernel = kn;
             }
             if (e->profiling) {
                 char kn[64];
-                conv_kernel_name(e->prec, L.cout, kn, sizeof kn);
+                conv_kernel_name_for(e->prec, a, kn, sizeof kn);
                 const double nv = (double)pc.variants.size();
                 const double opx = (double)a.M;  // output pixels written by this launch
                 double bytes = (double)in0.pixels() * L.cin * elem_bytes() / nv   // input volume read once per layer

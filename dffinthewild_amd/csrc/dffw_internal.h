@@ -79,6 +79,7 @@ struct ConvArgs {
 int conv_nt_for(int cout);  // 16-channel output tiles the conv kernel picked for `cout` iterates over
 hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s);
 void conv_kernel_name(int prec, int cout, char *buf, int n);  // name of the instantiation launch_conv picks
+void conv_kernel_name_for(int prec, const ConvArgs &a, char *buf, int n);   // name of the kernel launch_conv picks for `a` (conv_small for small grids)
 hipError_t launch_set_raw(const RawStack &rs, RawStack *dst, hipStream_t s);   // writes the descriptor into device memory (enqueue-only)
 hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int N, int H, int W, hipStream_t s);
 hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s);

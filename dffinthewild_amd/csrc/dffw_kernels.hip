@@ -117,6 +117,119 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a) {
     }
 }
 
+// ---- conv_small: the same implicit GEMM for SMALL grids (the 1/16 .. 1/32-resolution pyramid at batch 1: a few hundred to a
+// few thousand grid points, 64 .. 128 output channels, contraction depth up to 27 x 192) ------------------------------------------
+// conv_igemm gives a wave 64 grid points, ALL output channels and the whole contraction: a 5 x 7 x 7 layer is ONE workgroup walking
+// 54 chunks with a dependent gather in each (86 us for 54 MFLOP).  Here a workgroup owns ONE operand tile (16 grid points) and ONE
+// 16-channel output tile; its KS waves split the contraction depth between them, each wave requests ALL operand and weight
+// fragments of its share up front (tap entries first, then every gather in flight at once: one L2 round trip instead of one per
+// chunk), contracts, and the partial tiles are summed through LDS by wave 0, which runs the shared epilogue.  Grid = operand
+// tiles x output tiles, so even a 245-point layer spreads over 64 workgroups x KS waves.  No LDS staging of the input: at these
+// sizes the whole volume lives in L2.
+template <int PREC, int KS>
+__global__ __launch_bounds__(KS * 64) void conv_small(const ConvArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int BATCH = 8;                       // chunks whose fragments are in flight together (16 VGPRs each in split-bf16)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int nt = blockIdx.y;
+    const int NT = gridDim.y;
+    __shared__ f32x4 red[KS][64];
+
+    const int ps0 = PARTS * a.C0, ps1 = PARTS * a.C1;
+    const int64_t p = (int64_t)blockIdx.x * 16 + r;
+    const bool pv = p < a.M;
+    const int64_t pp = pv ? p : 0;
+    const int x = (int)(pp % a.Wg);
+    int64_t tq = pp / a.Wg;
+    const int y = (int)(tq % a.Hg);
+    tq /= a.Hg;
+    const int n = (int)(tq % a.Ng);
+    const int b = (int)(tq / a.Ng);
+    const int py = y * a.sy, px = x * a.sx;
+    const int pbase = (n * a.Hi + py) * a.Wi + px;
+    const uint16_t *s0 = a.in0 + (int64_t)b * a.Ni * a.Hi * a.Wi * ps0;
+    const uint16_t *s1 = a.in1 + (int64_t)b * a.Ni * a.Hi * a.Wi * ps1;
+    const int64_t opix = (((int64_t)b * a.No + n) * a.Ho + (y * a.osy + a.ooy)) * a.Wo + (x * a.osx + a.oox);
+
+    // this wave's share of the contraction: chunks [k0, k1)
+    const int k0 = (int)((int64_t)a.KC * wave / KS), k1 = (int)((int64_t)a.KC * (wave + 1) / KS);
+    const short8 *wbase = reinterpret_cast<const short8 *>(a.wpk) + lane;
+    const short8 zero8 = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+    for (int kb = k0; kb < k1; kb += BATCH) {
+        TapEntry te[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) te[i] = a.tab[(kb + i < k1 ? kb + i : k1 - 1) * 4 + g];
+        short8 xh[BATCH], xl[BATCH], wf[BATCH][PARTS];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int kc = kb + i < k1 ? kb + i : k1 - 1;      // (past the end: the last chunk again, its products are skipped below)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) wf[i][pt] = wbase[((int64_t)kc * NT * PARTS + nt * PARTS + pt) * 64];
+            const bool tvalid = te[i].coff >= 0;
+            const bool second = te[i].coff >= a.C0;
+            const int cc = tvalid ? (second ? te[i].coff - a.C0 : te[i].coff) : 0;
+            const int iz = n + te[i].dz, iy = py + te[i].dy, ix = px + te[i].dx;
+            const bool ok = pv && tvalid && (unsigned)iz < (unsigned)a.Ni && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const int delta = (te[i].dz * a.Hi + te[i].dy) * a.Wi + te[i].dx;
+            const uint16_t *src = (second ? s1 : s0) + ((int64_t)(pbase + delta) * (second ? ps1 : ps0) + cc);
+            xh[i] = zero8;
+            xl[i] = zero8;
+            if (ok) {
+                xh[i] = *reinterpret_cast<const short8 *>(src);
+                if constexpr (PARTS == 2) xl[i] = *reinterpret_cast<const short8 *>(src + (second ? a.C1 : a.C0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            if (kb + i < k1) {   // two accumulators alternately: a lone dependent chain issues an MFMA every ~36 cycles instead of 16
+                f32x4 &pa = (i & 1) ? acc2 : acc, &qa = (i & 1) ? acc : acc2;
+                if constexpr (PARTS == 2) {
+                    pa = mma<F16>(wf[i][1], xh[i], pa);
+                    qa = mma<F16>(wf[i][0], xl[i], qa);
+                }
+                pa = mma<F16>(wf[i][0], xh[i], pa);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += acc2[i];
+    if constexpr (KS > 1) {
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < KS; ++w) {   // fixed order: deterministic
+            const f32x4 o = red[w][lane];
+            acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
+        }
+    }
+    float cls = 0.f;
+    epilogue_quad<PREC, false>(a, acc, nt, g, opix, pv, cls, uint4{}, uint4{});
+}
+
+// true when conv_small serves this launch better than conv_igemm: few operand tiles (conv_igemm would start fewer than ~64
+// workgroups) and no fused classifier (its dot product spans all output tiles of a pixel, which conv_small deals to workgroups)
+static bool conv_small_wanted(const ConvArgs &a) {
+    const int64_t tiles = (a.M + 15) / 16;
+    return !a.cls_w && tiles <= 4096 && a.KC >= 1;
+}
+
+template <int PREC>
+static hipError_t launch_conv_small(const ConvArgs &a, hipStream_t s) {
+    const int nt = conv_nt_for(a.Cout);           // weights are packed for this many 16-channel output tiles
+    const int nt_live = (a.Cout + 15) / 16;       // ... of which these carry channels
+    const dim3 grid((unsigned)((a.M + 15) / 16), (unsigned)nt);
+    (void)nt_live;
+    if (a.KC >= 8) hipLaunchKernelGGL((conv_small<PREC, 8>), grid, dim3(512), 0, s, a);
+    else if (a.KC >= 4) hipLaunchKernelGGL((conv_small<PREC, 4>), grid, dim3(256), 0, s, a);
+    else if (a.KC >= 2) hipLaunchKernelGGL((conv_small<PREC, 2>), grid, dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((conv_small<PREC, 1>), grid, dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int PREC, int NT, int MT>
 static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
     const int64_t per_wg = 4 * MT * 16;
@@ -127,6 +240,7 @@ static hipError_t launch_conv_t(const ConvArgs &a, hipStream_t s) {
 
 template <int PREC>
 static hipError_t launch_conv_p(const ConvArgs &a, hipStream_t s) {
+    if (conv_small_wanted(a) && !(a.dbg & 32)) return launch_conv_small<PREC>(a, s);
     const int nt = (a.Cout + 15) / 16;
     if (nt <= 1) return launch_conv_t<PREC, 1, 4>(a, s);
     if (nt <= 2) return launch_conv_t<PREC, 2, 4>(a, s);
@@ -144,6 +258,12 @@ int conv_nt_for(int cout) {
 void conv_kernel_name(int prec, int cout, char *buf, int n) {
     const int nt = conv_nt_for(cout);
     snprintf(buf, n, "dffw::conv_igemm<%d, %d, %d>", prec, nt, nt == 8 ? 2 : 4);
+}
+
+// name of the kernel launch_conv picks for these arguments (conv_small for small grids, else conv_igemm)
+void conv_kernel_name_for(int prec, const ConvArgs &a, char *buf, int n) {
+    if (conv_small_wanted(a) && !(a.dbg & 32)) snprintf(buf, n, "dffw::conv_small<%d, %d>", prec, a.KC >= 8 ? 8 : a.KC >= 4 ? 4 : a.KC >= 2 ? 2 : 1);
+    else conv_kernel_name(prec, a.Cout, buf, n);
 }
 
 hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s) {

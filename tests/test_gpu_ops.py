@@ -74,6 +74,58 @@ def test_conv_families(eng, case, prec):
     assert rel(got, ref) <= TOL[prec], (name, prec, rel(got, ref))
 
 
+SMALL_CASES = [
+    # name, Cin, Cout, kernel, stride, pad, transposed, B, N, H, W, residual
+    ("c3_64_64_7x7", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, 1, 5, 7, 7, True),
+    ("c3_192_128_3x3", 192, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, 1, 5, 3, 3, False),
+    ("c3_32_64_7x7", 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, 2, 3, 7, 5, False),
+    ("p1_64_64_14x14", 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, 1, 5, 14, 14, False),
+    ("p1_32_32_28x28", 32, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), False, 1, 5, 28, 28, False),
+    ("t3_128_64_7to14", 128, 64, (3, 3, 3), (1, 2, 2), (1, 1, 1), True, 1, 5, 7, 7, True),
+    ("s2_64_128_6to3", 64, 128, (3, 3, 3), (1, 2, 2), (1, 1, 1), False, 1, 5, 6, 6, False),
+    ("score_32_1_4x4", 32, 1, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, 1, 2, 4, 4, False),
+    ("c3_one_point", 16, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, 1, 1, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("case", SMALL_CASES, ids=lambda c: c[0])
+def test_conv_small_grids(eng, case, prec, monkeypatch):
+    """conv_small (dffw_kernels.hip): grids too small for an LDS tile -- the 1/32-resolution pyramid scale of a 224 x 224 stack is
+    5 x 7 x 7 (DEN.py:212-238 at BASELINE config 2) -- as one workgroup per (16 grid points, 16 output channels) whose waves split
+    the contraction depth and sum through LDS.  3x3x3 at stride 1 and (1,2,2), the four sub-pixel phases of the transposed conv,
+    1x1x1 (depth 1-2 chunks: fewer waves), a one-channel score output, a single grid point; residual + ReLU epilogue; against the
+    PyTorch operator and against conv_igemm (DFFW_NO_SMALL) on the same input."""
+    name, cin, cout, k, st, pd, transposed, B, N, H, W, residual = case
+    x = rnd(B, cin, N, H, W, seed=41)
+    wshape = (cin, cout, *k) if transposed else (cout, cin, *k)
+    w = rnd(*wshape, seed=42, scale=(2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5 * 1.7)
+    bn = bn_params(cout, 43) if cout > 1 else None
+    if transposed:
+        ref = F.conv_transpose3d(x, w, None, st, pd, (0, 1, 1))
+    else:
+        ref = F.conv3d(x, w, None, st, pd)
+    if bn:
+        ref = ref_bn(ref, bn)
+    res = rnd(*ref.shape, seed=44) if residual else None
+    if residual:
+        ref = ref + res
+    if bn:
+        ref = F.relu(ref)
+    kw = dict(stride=st, pad=pd, transposed=transposed, bn=bn, residual=res.cuda() if residual else None, relu=1 if bn else 0, precision=prec)
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_small<"), eng.last_conv_kernel()
+    if cout == 1:
+        ref = ref.squeeze(1)
+    assert got.shape == ref.shape
+    assert rel(got, ref) <= TOL[prec], (name, rel(got, ref))
+    monkeypatch.setenv("DFFW_NO_SMALL", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_igemm<"), eng.last_conv_kernel()
+    assert rel(alt, ref) <= TOL[prec]
+    assert rel(got, alt) <= TOL[prec] * 0.2
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("cin,cout,B,N,H,W,residual,wgs", [(64, 32, 4, 10, 64, 64, False, 0), (32, 64, 2, 7, 64, 80, True, 0), (32, 32, 4, 5, 36, 64, True, 40),
                                                            (64, 64, 8, 3, 32, 32, False, 16), (192, 128, 16, 10, 8, 8, False, 0), (128, 64, 16, 10, 16, 16, True, 8)])
