@@ -1068,6 +1068,188 @@ __global__ __launch_bounds__(256) void conv_roll_efd(const ConvArgs a, const Rol
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
 }
 
+// ---- conv_roll_s2: 3x3x3 stride (1,2,2) over 16 input channels as a rolling window (`FM_conv2.0.stride_conv`, `dres3.conv1`:
+// 16 -> 32; `dres4.conv3`: 16 -> 16; DEN.py:306-315, 252-256) -------------------------------------------------------------------------
+// On conv_tile these layers stage their 5 x 4 x 16 tile as TWO 8-channel stages of a 7 x 9 x 34-pixel footprint: every 128-byte
+// line is fetched once per stage, the slice halo 7/5 and the in-plane halo 1.7x on top -- measured 2.1x the algorithmic HBM bytes,
+// 2.5 TB/s algorithmic (profiles/r01_hbm_traffic.json, r02_fetch_size_calibration.txt).  Here, as in conv_roll_efd for the 8-channel
+// stage: a workgroup walks the output slices of a column; a ring slot holds ONE input slice of the column's (2 TY + 1) x (2 TX + 1)
+// footprint with ALL 16 channels (whole 64-byte pixel records: every line is fetched once), even columns first so that the stride-2
+// operand reads stay contiguous; the filter lives in registers -- 3 slices x 5 chunks of (2 taps x 16 channels) for ONE 16-channel
+// output tile per wave (120 VGPRs).  NT = 2 (32 output channels): the four waves are (output tile, operand tile) pairs over a
+// 4 x 8 column; NT = 1: wave w = output row w of a 4 x 16 column.  Streaming skeleton (column stream, counted vmcnt, raw s_barrier,
+// inline-asm operand reads) as conv_roll.
+template <int PREC, int NT, int RING>
+__global__ __launch_bounds__(256) void conv_roll_s2(const ConvArgs a, const RollArgs t) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int TY = 4, TX = NT == 2 ? 8 : 16, NWAVES = 4, PIXB = 32;
+    constexpr int XY = 2 * TY + 1, XX = 2 * TX + 1, XPIX = XY * XX, XEV = TX + 1;   // footprint of a slice; XEV even columns per row
+    constexpr int NPIECE = (XPIX * 2 + 63) / 64;                                     // 1 KiB wave instructions per plane (64 x (pixel, octet))
+    constexpr int PLANEB = NPIECE * 1024, SLOTB = PARTS * PLANEB;
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    constexpr int NCH = 15;
+    static_assert(RING >= 4, "3 slices being read + at least one being filled");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOTB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {   // columns of the OUTPUT grid
+        Unit c;
+        const int txi = u % t.tiles_x;
+        const int tt = u / t.tiles_x;
+        c.b = tt / t.tiles_y;
+        c.gy0 = (tt % t.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+
+    const int rec = PARTS * 16;
+    const int xslice = a.Hi * a.Wi * rec;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0;
+    const int fslices = a.No + 2;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int ci = i * 64 + lane, sl = ci >> 1, oct = ci & 1;
+            const int fy = sl / XX, pos = sl - fy * XX;
+            const int cx = pos < XEV ? 2 * pos : 2 * (pos - XEV) + 1;   // even columns first, then the odd ones
+            const int iy = 2 * c.gy0 - 1 + fy, ix = 2 * c.gx0 - 1 + cx;
+            fok[k] = p < NP && sl < XPIX && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            fsrc[k] = a.in0 + (int64_t)c.b * a.Ni * xslice + (int64_t)(iy * a.Wi + ix) * rec + part * 16 + oct * 8;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const int iz = fq - 1;
+        const bool zin = (unsigned)iz < (unsigned)a.Ni && fu < uend;
+        unsigned char *slot = smem + fslot * SLOTB;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + (int64_t)iz * xslice : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RING) ? 0 : fslot + 1;
+        if (++fq == fslices && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // this wave's output tile `nt` and operand tile: NT = 1: row `wave`, column r; NT = 2: rows 2*(wave >> 1) + (r >> 3), column r & 7
+    const int nt = NT == 2 ? (wave & 1) : 0;
+    const int orow = NT == 2 ? 2 * (wave >> 1) + (r >> 3) : wave, ocol = NT == 2 ? (r & 7) : r;
+    // K octet g of chunk k5 = (in-slice tap 2*k5 + (g >> 1), channel octet g & 1); tap 9 carries zero weights
+    int tapo[5];
+#pragma unroll
+    for (int k5 = 0; k5 < 5; ++k5) {
+        const int tap = 2 * k5 + (g >> 1);
+        const int ky = tap < 9 ? tap / 3 : 0, kx = tap < 9 ? tap % 3 : 0;
+        tapo[k5] = (ky * XX + (kx == 1 ? XEV : (kx == 2 ? 1 : 0))) * PIXB + (g & 1) * 16;
+    }
+    const int base = (2 * orow * XX + ocol) * PIXB;
+    const int Cout = a.Cout;
+    const int lanepart = (PARTS == 2) ? (g & 1) * Cout + (g >> 1) * 8 : g * 4;
+    const int voff = (orow * a.Wo + ocol) * (PARTS * Cout) + lanepart;
+
+    constexpr int INFLIGHT = (RING - 4) * PPW;
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) issue_next();
+
+    short8 w[NCH][PARTS];
+    {
+        const short8 *wa = reinterpret_cast<const short8 *>(t.wroll) + (int64_t)nt * NCH * PARTS * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) w[c][pt] = wa[(c * PARTS + pt) * 64];
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    int sidx = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        const int64_t obase0 = (((int64_t)U.b * a.No) * a.Ho + U.gy0) * a.Wo + U.gx0;
+        for (int st = 0; st < a.No + 2; ++st) {
+            const bool live = st < a.No;
+            const int64_t obase = obase0 + (int64_t)st * a.Ho * a.Wo;
+            const int64_t ubase = obase * (PARTS * Cout);
+            if (!(a.dbg & 1)) issue_next();
+
+            f32x4 acc = bias4;
+            if (live && !(a.dbg & 2)) {
+                int sb[3];
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    int sl = sidx + dz;
+                    if (sl >= RING) sl -= RING;
+                    sb[dz] = sl * SLOTB;
+                }
+                constexpr int DEPTH = 2;
+                short8 x[DEPTH + 1][PARTS];
+                auto fetch = [&](int c, short8 (&dst)[PARTS]) {
+                    const unsigned ad = lds0 + sb[c / 5] + base + tapo[c % 5];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
+                    if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "n"(PLANEB));
+                };
+#pragma unroll
+                for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + DEPTH < NCH) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
+                    auto &xc = x[c % (DEPTH + 1)];
+                    const int ahead = (NCH - 1 - c < DEPTH ? NCH - 1 - c : DEPTH) * PARTS;
+                    if (ahead == 2 * PARTS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0]) : "n"(2 * PARTS));
+                    else if (ahead == PARTS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xc[0]) : "n"(PARTS));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0]));
+                    if constexpr (PARTS == 2) {
+                        asm volatile("" : "+v"(xc[1]));
+                        acc = mma<F16>(w[c][1], xc[0], acc);
+                        acc = mma<F16>(w[c][0], xc[1], acc);
+                    }
+                    acc = mma<F16>(w[c][0], xc[0], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
+            if (!live) continue;
+            if ((a.dbg & 4) && acc[0] != 12345.f) continue;
+            const int64_t opix = obase + (int64_t)orow * a.Wo + ocol;
+            float cls = 0.f;
+            epilogue_quad<PREC, false, true, false>(a, acc, nt, g, opix, true, cls, uint4{}, uint4{}, ubase, voff);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 #define DFFW_ROLL_TY 8
 #define DFFW_ROLL_TX 16
@@ -1164,6 +1346,33 @@ hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, 
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_EFD_LAUNCH
+    return hipGetLastError();
+}
+
+void s2_roll_tile(int nt, int *ty, int *tx) {
+    *ty = 4;
+    *tx = nt == 2 ? 8 : 16;
+}
+
+void conv_roll_s2_kernel_name(int prec, int nt, char *buf, int n) { snprintf(buf, n, "dffw::conv_roll_s2<%d, %d, %d>", prec, nt, nt == 2 ? 6 : 4); }
+
+hipError_t launch_conv_roll_s2(int prec, int nt, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    // ring depth by LDS: 4 x 8 column: 10 KiB per slice -> 6 slots = 60 KiB (two workgroups per CU); 4 x 16 column: 20 KiB -> 4 slots
+    const int want = t.wgs > 0 ? t.wgs : 512;
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+#define DFFW_S2_LAUNCH(P)                                                                    \
+    do {                                                                                     \
+        if (nt == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 6>), grid, block, 0, s, a, t);  \
+        else hipLaunchKernelGGL((conv_roll_s2<P, 1, 4>), grid, block, 0, s, a, t);          \
+    } while (0)
+    switch (prec) {
+        case P_BF16X3: DFFW_S2_LAUNCH(P_BF16X3); break;
+        case P_FP16: DFFW_S2_LAUNCH(P_FP16); break;
+        case P_BF16: DFFW_S2_LAUNCH(P_BF16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_S2_LAUNCH
     return hipGetLastError();
 }
 

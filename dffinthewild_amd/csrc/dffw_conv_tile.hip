@@ -631,6 +631,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(24, G3T, 2, 5, 4, 16, 32, 1)   \
     X(25, G3T, 4, 5, 4, 16, 32, 1)   \
     X(34, G2S1, 2, 5, 4, 16, 32, 1)  \
+    X(37, G3S2, 4, 4, 4, 8, 16, 1)   \
     X(32, G2P, 1, 1, 16, 32, 8, 0)
 // 8-wave "wide" variants: 640-point tiles, same work per wave.  Measured +8..17 % on the bandwidth-bound
 // single-stage layers with <= 16 output channels (one more resident wave per SIMD for the same LDS, 17 % less

@@ -310,6 +310,7 @@ struct PackedConv {
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
+    uint16_t *wroll_s2 = nullptr;  // device: a 3x3x3 stride-(1,2,2) 16 -> 16 / 32 filter in conv_roll_s2's order (15 chunks per 16-channel output tile)
     uint16_t *wroll_t32 = nullptr; // device: a transposed 3x3x3 32 -> 16 filter in conv_roll_t32's order (row phase 0: 9 chunks, then phase 1: 18)
     uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
     uint16_t *watt = nullptr;      // device: an 8 -> 8 attention conv (3x1x1 or 1x1x1) as srd_roll's stage-C fragments
@@ -345,6 +346,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll8 = nullptr;
     if (pc.wroll_t32) (void)hipFree(pc.wroll_t32);
     pc.wroll_t32 = nullptr;
+    if (pc.wroll_s2) (void)hipFree(pc.wroll_s2);
+    pc.wroll_s2 = nullptr;
     if (pc.wsrd) (void)hipFree(pc.wsrd);
     pc.wsrd = nullptr;
     if (pc.watt) (void)hipFree(pc.watt);
@@ -513,6 +516,10 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         // transposed conv: its 4 sub-pixel passes share one LDS image only when the whole contraction depth is
         // staged at once, so 32-channel groups (one fill instead of 4 x 2) where an instantiation exists
         if (geo == G3T && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;
+        // stride-(1,2,2) 3x3x3 over 64 channels (dres2.conv3): 16-channel stages on a 4 x 4 x 8 tile instead of eight 8-channel
+        // stages on 5 x 4 x 16 (every stage re-fetches the 128-byte lines it takes a piece of): -18 %.  Measured on the 16- and
+        // 32-channel stride-2 layers too: +25 % / +9 % SLOWER (smaller tile, more halo, 4-slice tiles on 10 slices) -- not used there.
+        if (geo == G3S2 && cin_t % 64 == 0 && tile_cfg_find(geo, pc.nt, 16) && !getenv("DFFW_NO_S2_CG16")) cg = 16;
         // per-slice 1x3x3 over 32 channels: ONE 32-channel stage per tile (each 128-byte pixel line is fetched once instead of
         // half of it per 16-channel stage -- the memory side moves whole 128-byte lines, profiles/r02_fetch_size_calibration.txt)
         if (geo == G2S1 && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;   // +4..14 % on those layers
@@ -840,6 +847,28 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 }
         HIPCHK(hipMalloc((void **)&pc.wroll8, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll8, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- conv_roll_s2: 3x3x3 stride (1,2,2), 16 -> 16 / 32 channels: per 16-channel output tile 15 chunks [dz][k5], K octet g =
+    // (in-slice tap 2*k5 + (g >> 1), channel octet g & 1), as conv_roll's plain form
+    if (geo == G3S2 && cin_pad == 16 && (L.cout == 16 || L.cout == 32) && !shortcut_w) {
+        const int ntl = L.cout / 16;
+        std::vector<uint16_t> wr((size_t)ntl * ROLL_CHUNKS * parts * 512, 0);
+        for (int nt = 0; nt < ntl; ++nt)
+            for (int c = 0; c < ROLL_CHUNKS; ++c)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = lane & 15, gq = lane >> 4;
+                        const int dz = c / 5, k5 = c % 5, tap9 = 2 * k5 + (gq >> 1);
+                        float val = 0.f;
+                        if (tap9 < 9) val = (float)wval(nt * 16 + row, (gq & 1) * 8 + j, Tap{dz - 1, tap9 / 3 - 1, tap9 % 3 - 1, dz, tap9 / 3, tap9 % 3});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)nt * ROLL_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        if (parts == 2) wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wroll_s2, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wroll_s2, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- conv_roll_t32: transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one fragment set per output row phase py.  A chunk = one
     // tap x 32 channels (K octet g = channel octet g).  Enumeration (must match the kernel): x phase 0 first: (window slice d,
@@ -1288,6 +1317,38 @@ struct Run {
                 prof_end();
             }
             return out;
+        }
+        // strided 3x3x3 16 -> 16 / 32 (FM_conv2.0.stride_conv, dres3.conv1, dres4.conv3): rolling window with whole pixel records
+        if (pc.wroll_s2 && !L.transposed && L.sh == 2 && in0.C == 16 && !o.in1 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre && !o.cls &&
+            !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_S2)) {
+            const int ntl = L.cout / 16;
+            int sty, stx;
+            s2_roll_tile(ntl, &sty, &stx);
+            if (Ho % sty == 0 && Wo % stx == 0 && in0.H == 2 * Ho && in0.W == 2 * Wo && (int64_t)in0.B * (Ho / sty) * (Wo / stx) >= 256) {
+                if (dry) return out;
+                a.Ng = No; a.Hg = Ho; a.Wg = Wo;
+                a.M = (int64_t)a.B * No * Ho * Wo;
+                a.dbg &= 6;
+                RollArgs t;
+                memset(&t, 0, sizeof t);
+                t.wroll = pc.wroll_s2;
+                t.tiles_y = Ho / sty;
+                t.tiles_x = Wo / stx;
+                t.zsplit = 1;
+                t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
+                t.wgs = sw.roll_wgs;
+                char kn[96];
+                conv_roll_s2_kernel_name(e->prec, ntl, kn, sizeof kn);
+                g_last_kernel = kn;
+                if (e->profiling) {
+                    const double opx = (double)out.B * No * Ho * Wo;
+                    prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout,
+                               ((double)in0.pixels() * L.cin + opx * L.cout * (1 + (o.res0 ? 1 : 0))) * elem_bytes() + 27.0 * L.cin * L.cout * elem_bytes());
+                }
+                check(launch_conv_roll_s2(e->prec, ntl, a, t, s), name.c_str());
+                prof_end();
+                return out;
+            }
         }
         // strided 3x3x3 8 -> 16 (dres4.conv1): the single-branch form of conv_roll_efd
         {

@@ -74,6 +74,33 @@ def test_conv_families(eng, case, prec):
     assert rel(got, ref) <= TOL[prec], (name, prec, rel(got, ref))
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("cout,B,N,H,W,relu,wgs", [(32, 2, 10, 128, 128, 1, 0), (32, 4, 1, 128, 64, 0, 16), (32, 2, 2, 128, 128, 1, 40),
+                                                   (16, 4, 10, 128, 128, 1, 0), (16, 4, 3, 256, 64, 0, 24), (16, 8, 1, 64, 128, 1, 8)])
+def test_conv_roll_strided_16_channels(eng, cout, B, N, H, W, relu, wgs, prec, monkeypatch):
+    """conv_roll_s2 (dffw_conv_roll.hip): 3x3x3 stride (1,2,2) over 16 input channels (`FM_conv2.0.stride_conv`, `dres3.conv1`:
+    16 -> 32; `dres4.conv3`: 16 -> 16; DEN.py:306-315, 252-256) as a rolling window over whole pixel records.  Slice counts 1, 2, 3,
+    10, non-square maps, one column per workgroup and long column streams, with and without the ReLU epilogue, three arithmetics;
+    against F.conv3d and against conv_tile (DFFW_NO_ROLL_S2) on the same input."""
+    cin = 16
+    x = rnd(B, cin, N, H, W, seed=51)
+    w = rnd(cout, cin, 3, 3, 3, seed=52, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 53)
+    ref = ref_bn(F.conv3d(x, w, None, (1, 2, 2), 1), bn)
+    if relu:
+        ref = F.relu(ref)
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    got = eng.op_conv3d(x.cuda(), w, stride=(1, 2, 2), pad=1, bn=bn, relu=relu, precision=prec)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_s2<"), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL[prec], rel(got, ref)
+    monkeypatch.setenv("DFFW_NO_ROLL_S2", "1")
+    alt = eng.op_conv3d(x.cuda(), w, stride=(1, 2, 2), pad=1, bn=bn, relu=relu, precision=prec)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(alt, ref) <= TOL[prec]
+    assert rel(got, alt) <= TOL[prec] * 0.2
+
+
 SMALL_CASES = [
     # name, Cin, Cout, kernel, stride, pad, transposed, B, N, H, W, residual
     ("c3_64_64_7x7", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), False, 1, 5, 7, 7, True),
