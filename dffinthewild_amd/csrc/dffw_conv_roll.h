@@ -35,11 +35,12 @@ constexpr int ROLL_CHUNKS_8 = 9;
 void efd_roll_tile(int *ty, int *tx);
 hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_roll_efd_kernel_name(int prec, bool dual, char *buf, int n);
-// strided 3x3x3, 16 -> 16 (nt = 1: columns of 4 x 16 output pixels) or 16 -> 32 channels (nt = 2: 4 x 8); filter packed per
-// 16-channel output tile as ROLL_CHUNKS chunks [dz][5 chunks of 2 in-slice taps x 16 channels], tile after tile
+// strided 3x3x3 over 16 (kh = 1) or 32 (kh = 2) input channels: 16 -> 16 (nt = 1: columns of 4 x 16 output pixels), 16 / 32 -> 32
+// (nt = 2: 4 x 8; 64 output channels = two launches with RollArgs::pair = first output tile).  Filter packed per (16-channel output
+// tile, 16-channel input half) as ROLL_CHUNKS chunks [dz][5 chunks of 2 in-slice taps x 16 channels]: [output tile][half][chunk]
 void s2_roll_tile(int nt, int *ty, int *tx);
-hipError_t launch_conv_roll_s2(int prec, int nt, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_s2_kernel_name(int prec, int nt, char *buf, int n);
+hipError_t launch_conv_roll_s2(int prec, int nt, int kh, const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_roll_s2_kernel_name(int prec, int nt, int kh, char *buf, int n);
 hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_roll_t_kernel_name(int prec, bool res, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
 

@@ -1079,18 +1079,26 @@ __global__ __launch_bounds__(256) void conv_roll_efd(const ConvArgs a, const Rol
 // output tile per wave (120 VGPRs).  NT = 2 (32 output channels): the four waves are (output tile, operand tile) pairs over a
 // 4 x 8 column; NT = 1: wave w = output row w of a 4 x 16 column.  Streaming skeleton (column stream, counted vmcnt, raw s_barrier,
 // inline-asm operand reads) as conv_roll.
-template <int PREC, int NT, int RING>
-__global__ __launch_bounds__(256) void conv_roll_s2(const ConvArgs a, const RollArgs t) {
+// KH = 2: 32 input channels.  The filter of one output tile no longer fits a wave (27 taps x 32 channels = 216 VGPRs), so the
+// contraction is split between wave pairs by channel half: the workgroup has 8 waves = (channel half, output tile, operand tile),
+// each with its half filter (120 VGPRs); the odd half hands its partial tile to its partner through LDS in front of the step's
+// barrier (double-buffered by step parity) and the partner runs the epilogue.  t.pair = first 16-channel output tile of this launch
+// (64 output channels = two launches over the same input).
+template <int PREC, int NT, int KH, int RING>
+__global__ __launch_bounds__(NT * KH == 4 ? 512 : 256) void conv_roll_s2(const ConvArgs a, const RollArgs t) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
-    constexpr int TY = 4, TX = NT == 2 ? 8 : 16, NWAVES = 4, PIXB = 32;
+    constexpr int CIN = 16 * KH, NWAVES = (NT * KH == 4) ? 8 : 4;
+    static_assert(KH == 1 || NT == 2, "the channel-split form is built for two output tiles (8 waves)");
+    constexpr int TY = 4, TX = NT == 2 ? 8 : 16, PIXB = 2 * CIN, OCT = 2 * KH;
     constexpr int XY = 2 * TY + 1, XX = 2 * TX + 1, XPIX = XY * XX, XEV = TX + 1;   // footprint of a slice; XEV even columns per row
-    constexpr int NPIECE = (XPIX * 2 + 63) / 64;                                     // 1 KiB wave instructions per plane (64 x (pixel, octet))
+    constexpr int NPIECE = (XPIX * OCT + 63) / 64;                                   // 1 KiB wave instructions per plane (64 x (pixel, octet))
     constexpr int PLANEB = NPIECE * 1024, SLOTB = PARTS * PLANEB;
-    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;             // wave w issues pieces [w * PPW, min(NP, (w + 1) * PPW))
     constexpr int NCH = 15;
     static_assert(RING >= 4, "3 slices being read + at least one being filled");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOTB];
+    constexpr int XCHB = KH == 2 ? 2 * (NWAVES / 2) * 1024 : 0;                      // partial tiles of the odd channel halves, two step parities
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOTB + XCHB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
@@ -1117,7 +1125,7 @@ __global__ __launch_bounds__(256) void conv_roll_s2(const ConvArgs a, const Roll
         return c;
     };
 
-    const int rec = PARTS * 16;
+    const int rec = PARTS * CIN;
     const int xslice = a.Hi * a.Wi * rec;
     const uint16_t *fsrc[PPW];
     bool fok[PPW];
@@ -1129,12 +1137,12 @@ __global__ __launch_bounds__(256) void conv_roll_s2(const ConvArgs a, const Roll
         for (int k = 0; k < PPW; ++k) {
             const int p = wave * PPW + k;
             const int part = p / NPIECE, i = p % NPIECE;
-            const int ci = i * 64 + lane, sl = ci >> 1, oct = ci & 1;
+            const int ci = i * 64 + lane, sl = ci / OCT, oct = ci % OCT;
             const int fy = sl / XX, pos = sl - fy * XX;
             const int cx = pos < XEV ? 2 * pos : 2 * (pos - XEV) + 1;   // even columns first, then the odd ones
             const int iy = 2 * c.gy0 - 1 + fy, ix = 2 * c.gx0 - 1 + cx;
             fok[k] = p < NP && sl < XPIX && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-            fsrc[k] = a.in0 + (int64_t)c.b * a.Ni * xslice + (int64_t)(iy * a.Wi + ix) * rec + part * 16 + oct * 8;
+            fsrc[k] = a.in0 + (int64_t)c.b * a.Ni * xslice + (int64_t)(iy * a.Wi + ix) * rec + part * CIN + oct * 8;
         }
     };
     setup_fill();
@@ -1160,40 +1168,53 @@ __global__ __launch_bounds__(256) void conv_roll_s2(const ConvArgs a, const Roll
         }
     };
 
-    // this wave's output tile `nt` and operand tile: NT = 1: row `wave`, column r; NT = 2: rows 2*(wave >> 1) + (r >> 3), column r & 7
-    const int nt = NT == 2 ? (wave & 1) : 0;
-    const int orow = NT == 2 ? 2 * (wave >> 1) + (r >> 3) : wave, ocol = NT == 2 ? (r & 7) : r;
-    // K octet g of chunk k5 = (in-slice tap 2*k5 + (g >> 1), channel octet g & 1); tap 9 carries zero weights
+    // this wave's channel half `kh`, output tile `nt` and operand tile `tl`: KH = 1, NT = 1: row `wave`, column r;
+    // NT = 2: rows 2*tl + (r >> 3), column r & 7 with (nt, tl) = (wave & 1, wave >> 1), or (kh, nt, tl) = (wave & 1, (wave >> 1) & 1, wave >> 2)
+    const int kh = KH == 2 ? (wave & 1) : 0;
+    const int ntl = NT == 2 ? ((KH == 2 ? wave >> 1 : wave) & 1) : 0;
+    const int tl = NT == 2 ? (KH == 2 ? wave >> 2 : wave >> 1) : wave;
+    const int nt = t.pair + ntl;
+    const int orow = NT == 2 ? 2 * tl + (r >> 3) : tl, ocol = NT == 2 ? (r & 7) : r;
+    // K octet g of chunk k5 = (in-slice tap 2*k5 + (g >> 1), channel octet g & 1 of this wave's half); tap 9 carries zero weights
     int tapo[5];
 #pragma unroll
     for (int k5 = 0; k5 < 5; ++k5) {
         const int tap = 2 * k5 + (g >> 1);
         const int ky = tap < 9 ? tap / 3 : 0, kx = tap < 9 ? tap % 3 : 0;
-        tapo[k5] = (ky * XX + (kx == 1 ? XEV : (kx == 2 ? 1 : 0))) * PIXB + (g & 1) * 16;
+        tapo[k5] = (ky * XX + (kx == 1 ? XEV : (kx == 2 ? 1 : 0))) * PIXB + kh * 32 + (g & 1) * 16;
     }
     const int base = (2 * orow * XX + ocol) * PIXB;
     const int Cout = a.Cout;
     const int lanepart = (PARTS == 2) ? (g & 1) * Cout + (g >> 1) * 8 : g * 4;
     const int voff = (orow * a.Wo + ocol) * (PARTS * Cout) + lanepart;
 
-    constexpr int INFLIGHT = (RING - 4) * PPW;
+    // counted wait for this wave's own fill pieces: everything but the pieces of the newest RING - 4 slices has landed.  The
+    // waves do not all issue the same number of pieces per slice, so the count is per wave (wave-uniform branch).
+    const int mine = max(0, min(PPW, NP - wave * PPW));
+    auto fill_wait = [&]() {
+        if (mine == PPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 4) * PPW) : "memory");
+        else if (PPW >= 2 && mine == PPW - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 4) * (PPW > 1 ? PPW - 1 : 0)) : "memory");
+        else if (PPW >= 3 && mine == PPW - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 4) * (PPW > 2 ? PPW - 2 : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // any other count: wait for everything (always sufficient)
+    };
 #pragma unroll
     for (int q = 0; q < RING - 1; ++q) issue_next();
 
     short8 w[NCH][PARTS];
     {
-        const short8 *wa = reinterpret_cast<const short8 *>(t.wroll) + (int64_t)nt * NCH * PARTS * 64 + lane;
+        const short8 *wa = reinterpret_cast<const short8 *>(t.wroll) + ((int64_t)nt * KH + kh) * NCH * PARTS * 64 + lane;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int pt = 0; pt < PARTS; ++pt) w[c][pt] = wa[(c * PARTS + pt) * 64];
     }
-    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+    f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+    if (kh) bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_waitcnt(0x0F70);
     asm volatile("s_barrier" ::: "memory");
 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    int sidx = 0;
+    int sidx = 0, parity = 0;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         const int64_t obase0 = (((int64_t)U.b * a.No) * a.Ho + U.gy0) * a.Wo + U.gx0;
@@ -1238,9 +1259,24 @@ __global__ __launch_bounds__(256) void conv_roll_s2(const ConvArgs a, const Roll
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+            if constexpr (KH == 2) {   // the odd channel half hands its partial tile to its partner (the wave below it)
+                const unsigned xo = lds0 + RING * SLOTB + (parity * (NWAVES / 2) + (wave >> 1)) * 1024 + lane * 16;
+                if (kh) asm volatile("ds_write_b128 %0, %1" ::"v"(xo), "v"(acc) : "memory");
+                fill_wait();
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (!kh && live) {
+                    f32x4 o;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(xo) : "memory");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] += o[i];
+                }
+                parity ^= 1;
+            } else {
+                fill_wait();
+                asm volatile("s_barrier" ::: "memory");
+            }
             sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
-            if (!live) continue;
+            if (!live || kh) continue;
             if ((a.dbg & 4) && acc[0] != 12345.f) continue;
             const int64_t opix = obase + (int64_t)orow * a.Wo + ocol;
             float cls = 0.f;
@@ -1354,17 +1390,21 @@ void s2_roll_tile(int nt, int *ty, int *tx) {
     *tx = nt == 2 ? 8 : 16;
 }
 
-void conv_roll_s2_kernel_name(int prec, int nt, char *buf, int n) { snprintf(buf, n, "dffw::conv_roll_s2<%d, %d, %d>", prec, nt, nt == 2 ? 6 : 4); }
+void conv_roll_s2_kernel_name(int prec, int nt, int kh, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll_s2<%d, %d, %d, %d>", prec, nt, kh, kh == 2 ? 5 : (nt == 2 ? 6 : 4));
+}
 
-hipError_t launch_conv_roll_s2(int prec, int nt, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
-    // ring depth by LDS: 4 x 8 column: 10 KiB per slice -> 6 slots = 60 KiB (two workgroups per CU); 4 x 16 column: 20 KiB -> 4 slots
-    const int want = t.wgs > 0 ? t.wgs : 512;
+hipError_t launch_conv_roll_s2(int prec, int nt, int kh, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    // ring depth by LDS: 16 channels, 4 x 8 column: 10 KiB per slice -> 6 slots = 60 KiB (two workgroups per CU); 4 x 16 column:
+    // 20 KiB -> 4 slots (two workgroups); 32 channels, 4 x 8 column, 8 waves: 24 KiB -> 5 slots + the exchange area = 128 KiB (one)
+    const int want = t.wgs > 0 ? t.wgs : (kh == 2 ? 256 : 512);
     const int per_xcd = (t.total_tiles + 7) / 8;
-    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
-#define DFFW_S2_LAUNCH(P)                                                                    \
-    do {                                                                                     \
-        if (nt == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 6>), grid, block, 0, s, a, t);  \
-        else hipLaunchKernelGGL((conv_roll_s2<P, 1, 4>), grid, block, 0, s, a, t);          \
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8))));
+#define DFFW_S2_LAUNCH(P)                                                                                   \
+    do {                                                                                                    \
+        if (kh == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 2, 5>), grid, dim3(512), 0, s, a, t);          \
+        else if (nt == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 1, 6>), grid, dim3(256), 0, s, a, t);     \
+        else hipLaunchKernelGGL((conv_roll_s2<P, 1, 1, 4>), grid, dim3(256), 0, s, a, t);                  \
     } while (0)
     switch (prec) {
         case P_BF16X3: DFFW_S2_LAUNCH(P_BF16X3); break;

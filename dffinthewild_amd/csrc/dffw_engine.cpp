@@ -848,25 +848,26 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.wroll8, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll8, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    // ---- conv_roll_s2: 3x3x3 stride (1,2,2), 16 -> 16 / 32 channels: per 16-channel output tile 15 chunks [dz][k5], K octet g =
-    // (in-slice tap 2*k5 + (g >> 1), channel octet g & 1), as conv_roll's plain form
-    if (geo == G3S2 && cin_pad == 16 && (L.cout == 16 || L.cout == 32) && !shortcut_w) {
-        const int ntl = L.cout / 16;
-        std::vector<uint16_t> wr((size_t)ntl * ROLL_CHUNKS * parts * 512, 0);
+    // ---- conv_roll_s2: 3x3x3 stride (1,2,2), 16 / 32 -> 16 / 32 / 64 channels: per (16-channel output tile, 16-channel input half) 15 chunks
+    // [dz][k5], K octet g = (in-slice tap 2*k5 + (g >> 1), channel octet g & 1 of the half), as conv_roll's plain form
+    if (geo == G3S2 && (cin_pad == 16 || cin_pad == 32) && L.cout % 16 == 0 && L.cout <= 64 && !(cin_pad == 16 && L.cout == 64) && !shortcut_w) {
+        const int ntl = L.cout / 16, khn = cin_pad / 16;
+        std::vector<uint16_t> wr((size_t)ntl * khn * ROLL_CHUNKS * parts * 512, 0);
         for (int nt = 0; nt < ntl; ++nt)
-            for (int c = 0; c < ROLL_CHUNKS; ++c)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int row = lane & 15, gq = lane >> 4;
-                        const int dz = c / 5, k5 = c % 5, tap9 = 2 * k5 + (gq >> 1);
-                        float val = 0.f;
-                        if (tap9 < 9) val = (float)wval(nt * 16 + row, (gq & 1) * 8 + j, Tap{dz - 1, tap9 / 3 - 1, tap9 % 3 - 1, dz, tap9 / 3, tap9 % 3});
-                        uint16_t hi, lo;
-                        host_split(prec, val, hi, lo);
-                        const size_t base = (((size_t)nt * ROLL_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
-                        wr[base] = hi;
-                        if (parts == 2) wr[base + 512] = lo;
-                    }
+            for (int kh = 0; kh < khn; ++kh)
+                for (int c = 0; c < ROLL_CHUNKS; ++c)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = lane & 15, gq = lane >> 4;
+                            const int dz = c / 5, k5 = c % 5, tap9 = 2 * k5 + (gq >> 1);
+                            float val = 0.f;
+                            if (tap9 < 9) val = (float)wval(nt * 16 + row, kh * 16 + (gq & 1) * 8 + j, Tap{dz - 1, tap9 / 3 - 1, tap9 % 3 - 1, dz, tap9 / 3, tap9 % 3});
+                            uint16_t hi, lo;
+                            host_split(prec, val, hi, lo);
+                            const size_t base = ((((size_t)nt * khn + kh) * ROLL_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
+                            wr[base] = hi;
+                            if (parts == 2) wr[base + 512] = lo;
+                        }
         HIPCHK(hipMalloc((void **)&pc.wroll_s2, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll_s2, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
@@ -1044,7 +1045,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1318,35 +1319,44 @@ struct Run {
             }
             return out;
         }
-        // strided 3x3x3 16 -> 16 / 32 (FM_conv2.0.stride_conv, dres3.conv1, dres4.conv3): rolling window with whole pixel records
-        if (pc.wroll_s2 && !L.transposed && L.sh == 2 && in0.C == 16 && !o.in1 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre && !o.cls &&
-            !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_S2)) {
-            const int ntl = L.cout / 16;
+        // strided 3x3x3 over 16 / 32 channels (FM_conv2.0.stride_conv, dres3.conv1, dres4.conv3; dres3.conv3, dres2.conv1, SPP conv1):
+        // rolling window with whole pixel records
+        if (pc.wroll_s2 && !L.transposed && L.sh == 2 && (in0.C == 16 || in0.C == 32) && !o.in1 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre &&
+            !o.cls && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_S2) && !(in0.C == 32 && sw.on(SW_NO_ROLL_S2K)) &&
+            (L.cout <= 32 || sw.on(SW_ROLL_S2_WIDE))) {   // 32 -> 64 as two launches measures level with conv_tile (r02): opt-in
+            const int khn = in0.C / 16;
+            const int ntk = (khn == 2 || L.cout >= 32) ? 2 : 1;     // output tiles per launch
+            const int nlaunch = (L.cout / 16 + ntk - 1) / ntk;
             int sty, stx;
-            s2_roll_tile(ntl, &sty, &stx);
-            if (Ho % sty == 0 && Wo % stx == 0 && in0.H == 2 * Ho && in0.W == 2 * Wo && (int64_t)in0.B * (Ho / sty) * (Wo / stx) >= 256) {
+            s2_roll_tile(ntk, &sty, &stx);
+            if ((L.cout / 16) % ntk == 0 && Ho % sty == 0 && Wo % stx == 0 && in0.H == 2 * Ho && in0.W == 2 * Wo &&
+                (int64_t)in0.B * (Ho / sty) * (Wo / stx) >= 256) {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
                 a.dbg &= 6;
-                RollArgs t;
-                memset(&t, 0, sizeof t);
-                t.wroll = pc.wroll_s2;
-                t.tiles_y = Ho / sty;
-                t.tiles_x = Wo / stx;
-                t.zsplit = 1;
-                t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
-                t.wgs = sw.roll_wgs;
-                char kn[96];
-                conv_roll_s2_kernel_name(e->prec, ntl, kn, sizeof kn);
-                g_last_kernel = kn;
-                if (e->profiling) {
-                    const double opx = (double)out.B * No * Ho * Wo;
-                    prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout,
-                               ((double)in0.pixels() * L.cin + opx * L.cout * (1 + (o.res0 ? 1 : 0))) * elem_bytes() + 27.0 * L.cin * L.cout * elem_bytes());
+                for (int li = 0; li < nlaunch; ++li) {
+                    RollArgs t;
+                    memset(&t, 0, sizeof t);
+                    t.wroll = pc.wroll_s2;
+                    t.tiles_y = Ho / sty;
+                    t.tiles_x = Wo / stx;
+                    t.zsplit = 1;
+                    t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
+                    t.wgs = sw.roll_wgs;
+                    t.pair = li * ntk;     // first 16-channel output tile of this launch
+                    char kn[96];
+                    conv_roll_s2_kernel_name(e->prec, ntk, khn, kn, sizeof kn);
+                    g_last_kernel = kn;
+                    if (e->profiling) {
+                        const double opx = (double)out.B * No * Ho * Wo;
+                        prof_begin(kn, nlaunch > 1 ? name + (li ? " (upper output channels)" : " (lower output channels)") : name,
+                                   2.0 * opx * 27.0 * L.cin * L.cout / nlaunch,
+                                   ((double)in0.pixels() * L.cin + opx * L.cout / nlaunch * (1 + (o.res0 ? 1 : 0))) * elem_bytes() + 27.0 * L.cin * L.cout / nlaunch * elem_bytes());
+                    }
+                    check(launch_conv_roll_s2(e->prec, ntk, khn, a, t, s), name.c_str());
+                    prof_end();
                 }
-                check(launch_conv_roll_s2(e->prec, ntl, a, t, s), name.c_str());
-                prof_end();
                 return out;
             }
         }

@@ -75,14 +75,18 @@ def test_conv_families(eng, case, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
-@pytest.mark.parametrize("cout,B,N,H,W,relu,wgs", [(32, 2, 10, 128, 128, 1, 0), (32, 4, 1, 128, 64, 0, 16), (32, 2, 2, 128, 128, 1, 40),
-                                                   (16, 4, 10, 128, 128, 1, 0), (16, 4, 3, 256, 64, 0, 24), (16, 8, 1, 64, 128, 1, 8)])
-def test_conv_roll_strided_16_channels(eng, cout, B, N, H, W, relu, wgs, prec, monkeypatch):
-    """conv_roll_s2 (dffw_conv_roll.hip): 3x3x3 stride (1,2,2) over 16 input channels (`FM_conv2.0.stride_conv`, `dres3.conv1`:
-    16 -> 32; `dres4.conv3`: 16 -> 16; DEN.py:306-315, 252-256) as a rolling window over whole pixel records.  Slice counts 1, 2, 3,
-    10, non-square maps, one column per workgroup and long column streams, with and without the ReLU epilogue, three arithmetics;
-    against F.conv3d and against conv_tile (DFFW_NO_ROLL_S2) on the same input."""
-    cin = 16
+@pytest.mark.parametrize("cin,cout,B,N,H,W,relu,wgs", [(16, 32, 2, 10, 128, 128, 1, 0), (16, 32, 4, 1, 128, 64, 0, 16), (16, 32, 2, 2, 128, 128, 1, 40),
+                                                       (16, 16, 4, 10, 128, 128, 1, 0), (16, 16, 4, 3, 256, 64, 0, 24), (16, 16, 8, 1, 64, 128, 1, 8),
+                                                       (32, 32, 2, 10, 128, 128, 1, 0), (32, 32, 4, 1, 128, 64, 0, 16), (32, 32, 2, 3, 128, 128, 0, 40),
+                                                       (32, 64, 2, 10, 128, 128, 1, 0), (32, 64, 8, 2, 64, 128, 0, 24)])
+def test_conv_roll_strided_16_channels(eng, cin, cout, B, N, H, W, relu, wgs, prec, monkeypatch):
+    """conv_roll_s2 (dffw_conv_roll.hip): 3x3x3 stride (1,2,2) as a rolling window over whole pixel records.  16 input channels
+    (`FM_conv2.0.stride_conv`, `dres3.conv1`: 16 -> 32; `dres4.conv3`: 16 -> 16; DEN.py:306-315, 252-256) and 32 with the
+    contraction split between wave pairs (`dres3.conv3`: 32 -> 32; `dres2.conv1`, SPP `conv1`: 32 -> 64 as two launches over the output
+    channel halves).  Slice counts 1, 2, 3, 10, non-square maps, one column per workgroup and long column streams, with and without
+    the ReLU epilogue, three arithmetics; against F.conv3d and against conv_tile (DFFW_NO_ROLL_S2) on the same input."""
+    if cout == 64:
+        monkeypatch.setenv("DFFW_ROLL_S2_WIDE", "1")    # two launches over the output channel halves: off by default (no faster than conv_tile)
     x = rnd(B, cin, N, H, W, seed=51)
     w = rnd(cout, cin, 3, 3, 3, seed=52, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
     bn = bn_params(cout, 53)
