@@ -69,6 +69,25 @@ def test_oracle_metrics_known_answers():
     assert np.isclose(m[7], 14.0 / 15) and np.isclose(m[8], 14.0 / 15) and np.isclose(m[9], 14.0 / 15) and np.isclose(m[10], m[3])
 
 
+METRIC_CASES = ["ddff_like", "fs6_like", "ragged", "one_pixel"]
+
+
+def metrics_golden(name):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "io_metrics.npz"))
+    return [z[f"{name}/{k}"] for k in ("est", "gt", "mask", "conf", "want")]
+
+
+@pytest.mark.parametrize("name", METRIC_CASES)
+def test_oracle_metrics_match_the_reference_functions(name):
+    """tests/golden/io_metrics.npz = outputs of the reference's own mask_* functions (metrics.py:90-127), produced by
+    oracle/make_goldens_metrics.py; the restatement does the same float32 NumPy arithmetic, so it agrees to rounding of the
+    pairwise float32 sums."""
+    est, gt, mask, conf, want = metrics_golden(name)
+    got = ref.masked_metrics(est, gt, mask, conf)
+    assert got[0] == want[0] == mask.sum()
+    assert np.allclose(got, want, rtol=1e-6, atol=0), (got, want)
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def pl(lib_built):
@@ -159,6 +178,22 @@ def test_masked_metrics_match_numpy(pl, with_conf):
         assert np.allclose(got[b, :n], want[:n], rtol=2e-6, atol=0), (b, got[b], want)
         if not with_conf:
             assert np.isnan(got[b, 10]) and np.isnan(got[b, 11])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", METRIC_CASES)
+def test_masked_metrics_match_the_reference_functions(pl, name):
+    """dffw_metrics against the reference's own mask_* functions (tests/golden/io_metrics.npz).  The prediction arrives padded
+    (test.py:124-126 crops it), here by 3 rows / 5 columns of junk.  Per-pixel terms are float32 on both sides; the reference sums
+    them pairwise in float32, dffw_metrics in float64: 2e-6."""
+    est, gt, mask, conf, want = metrics_golden(name)
+    h, w = gt.shape
+    padded = np.full((1, h + 3, w + 5), 7.0, np.float32)
+    padded[0, :h, :w] = est
+    got = pl.masked_metrics(torch.from_numpy(padded).cuda(), torch.from_numpy(gt)[None].cuda(), torch.from_numpy(mask)[None].cuda(),
+                            torch.from_numpy(conf)[None].cuda()).cpu().numpy()[0]
+    assert got[0] == want[0]
+    assert np.allclose(got, want, rtol=2e-6, atol=0), (got, want)
 
 
 @pytest.mark.gpu
