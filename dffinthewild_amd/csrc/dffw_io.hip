@@ -98,6 +98,28 @@ __global__ void minmax_finish_kernel(int *mm, int B) {
     if (i < 2 * B) reinterpret_cast<float *>(mm)[i] = ord2f(mm[i]);
 }
 
+// warped stack -> uint8 slice images (test_real_scenes.py:42-47).  One thread per output pixel: three planar reads (coalesced over
+// x), one 3-byte interleaved store.
+__global__ __launch_bounds__(256) void unpack_stack_kernel(const float *__restrict__ warp, int B, int N, int H, int W, int h, int w,
+                                                          uint8_t *__restrict__ img) {
+    const int64_t total = (int64_t)B * N * h * w, plane = (int64_t)N * H * W;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w);
+        const int64_t t = i / w;
+        const int y = (int)(t % h);
+        const int64_t bn = t / h;
+        const int n = (int)(bn % N), b = (int)(bn / N);
+        const float *src = warp + (int64_t)b * 3 * plane + ((int64_t)n * H + y) * W + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = __fmul_rn(127.5f, __fadd_rn(src[c * plane], 1.0f));
+            // x86 NumPy: cvttss2si to int32 (NaN / out of range -> 0x80000000), low byte kept
+            const int q = (v > -2147483648.0f && v < 2147483648.0f) ? (int)v : 0;
+            img[i * 3 + c] = (uint8_t)(q & 255);
+        }
+    }
+}
+
 // rgb[b][y][x][:] = lut[index((depth - lo) / (hi - lo))], y < h, x < w: the crop of test.py:124-126 / TRS.py:52, the
 // normalisation of test.py:132 (fixed range) or TRS.py:40 (the map's own range), and matplotlib's colour-map lookup
 // (float32 x*256 truncated; x == 1 -> 255; below 0 / above 1 clamp to the end colours; NaN -> black).
@@ -307,6 +329,17 @@ int dffw_colorize(int device, const float *depth, int B, int H, int W, int h, in
     const int64_t total = (int64_t)B * h * w;
     hipLaunchKernelGGL(colorize_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16)), dim3(256), 0, s, depth, H, W, h, w, range, 2,
                        lut_dev[device], rgb, B);
+    IO_HIPCHK(hipGetLastError());
+    return DFFW_OK;
+}
+
+int dffw_unpack_stack(int device, const float *warp, int B, int N, int H, int W, int h, int w, uint8_t *images, void *hip_stream) {
+    if (!warp || !images) return dffw_fail(DFFW_EINVAL, "null argument");
+    if (B < 1 || N < 1 || h < 1 || w < 1 || h > H || w > W) return dffw_fail(DFFW_EINVAL, "crop %dx%d does not fit the %dx%d stack", h, w, H, W);
+    IO_HIPCHK(hipSetDevice(device));
+    const int64_t total = (int64_t)B * N * h * w;
+    hipLaunchKernelGGL(unpack_stack_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32)), dim3(256), 0, (hipStream_t)hip_stream, warp,
+                       B, N, H, W, h, w, images);
     IO_HIPCHK(hipGetLastError());
     return DFFW_OK;
 }

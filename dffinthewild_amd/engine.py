@@ -76,6 +76,7 @@ def _load():
                                     POINTER(c_int64), c_void_p, c_void_p]
     c_u8p = POINTER(ctypes.c_uint8)
     lib.dffw_pack_stack.argtypes = [c_int, c_void_p, c_int, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.dffw_unpack_stack.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.dffw_colorize.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]
     lib.dffw_jet_lut.argtypes = [c_u8p]
     lib.dffw_metrics_scratch_bytes.argtypes = [c_int]
@@ -104,7 +105,7 @@ ABI_SYMBOLS = (
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
     "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
     "dffw_op_fov_warp", "dffw_forward_e2e", "dffw_last_conv_kernel",
-    "dffw_forward_raw", "dffw_pack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
+    "dffw_forward_raw", "dffw_pack_stack", "dffw_unpack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
     "dffw_comm_unique_id", "dffw_comm_init_rank", "dffw_comm_init_all", "dffw_comm_destroy", "dffw_comm_rank", "dffw_comm_size",
     "dffw_allgather", "dffw_comm_group_start", "dffw_comm_group_end", "dffw_probe_peaks",
 )

@@ -11,6 +11,7 @@ Everything stays in device memory; the kernels live in libdffw.so (csrc/dffw_io.
 (include/dffw.h: dffw_pack_stack, dffw_colorize, dffw_metrics).  No CPU fallback: CPU tensors raise."""
 from ctypes import c_void_p, c_int64
 
+import numpy as np
 import torch
 
 from . import engine
@@ -77,6 +78,45 @@ def focus_dists(values, batch=1, device="cuda"):
     test_Dataloader.py:24,71,113,166 is never materialised."""
     v = torch.as_tensor(values, dtype=torch.float32, device=device).reshape(1, -1, 1, 1)
     return v.expand(batch, -1, -1, -1).contiguous()
+
+
+def real_scene_crop(height, width):
+    """(y0, x0, h, w) of the border crop End_to_End/Test_dataloader.py:20-23 applies to every slice (1/12 of each side, integer
+    division) - the `crop=` argument of pack_stack."""
+    cy, cx = height // 12, width // 12
+    if cy < 1 or cx < 1:
+        raise ValueError(f"the loader's [c:-c] crop is empty for a {height}x{width} image")    # NumPy: x[0:-0] is empty
+    return cy, cx, height - 2 * cy, width - 2 * cx
+
+
+def real_scene_inputs(focus_distances, focal_length, device="cuda"):
+    """The two small inputs of End_to_End.Network besides the stack, from the values of a scene's focus_distance.txt /
+    focal_length.txt, as End_to_End/Test_dataloader.py:37-53 builds them (float64 arithmetic, rounded to float32 by torch.Tensor)
+    and the batch-1 DataLoader of test_real_scenes.py:24 stacks them:
+        focus_dists  (1,N,1,1) float32 = 1 / d          relative_fov  (1,1,N,1,1) float32 = (1/f - 1/d) / min(1/f - 1/d)"""
+    d = np.asarray([float(v) for v in focus_distances], dtype=np.float64)
+    if d.ndim != 1 or d.size < 1:
+        raise ValueError("focus_distances must be a non-empty sequence")
+    rel = 1 / float(focal_length) - 1 / d
+    rel = rel / np.min(rel)
+    fd = torch.from_numpy((1 / d).astype(np.float32)).reshape(1, -1, 1, 1).to(device)
+    fov = torch.from_numpy(rel.astype(np.float32)).reshape(1, 1, -1, 1, 1).to(device)
+    return fd, fov
+
+
+def unpack_stack(warp, size=None):
+    """The aligned stack End_to_End.Network returns, (B,3,N,H,W) float32 CUDA in [-1,1] -> uint8 (B,N,h,w,3) slice images:
+    `127.5 * (warp + 1.0)` truncated to uint8, cropped to size=(h, w), channel order kept (test_real_scenes.py:42-47)."""
+    dev = _dev(warp, "warp")
+    if warp.dim() != 5 or warp.shape[1] != 3 or warp.dtype != torch.float32:
+        raise ValueError(f"warp must be float32 (B,3,N,H,W), got {warp.dtype} {tuple(warp.shape)}")
+    x = warp.contiguous()
+    B, _, N, H, W = x.shape
+    h, w = (H, W) if size is None else size
+    img = torch.empty((B, N, h, w, 3), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(dev):
+        _check(lib.dffw_unpack_stack(dev, c_void_p(x.data_ptr()), B, N, H, W, h, w, c_void_p(img.data_ptr()), _stream_ptr(dev)), "dffw_unpack_stack")
+    return img
 
 
 def colorize(depth, size=None, vrange=None, return_range=False):

@@ -212,6 +212,15 @@ int dffw_colorize(int device, const float *depth, int B, int H, int W, int h, in
                   float *range, uint8_t *rgb, void *hip_stream);
 int dffw_jet_lut(uint8_t *lut768);
 
+/* dffw_unpack_stack replaces the warped-stack export of End_to_End/test_real_scenes.py:42-47:
+ *     np.squeeze(127.5 * (warp + 1.0)).astype(np.uint8), transposed to (H,W,3,N) and written slice by slice cropped to (h,w).
+ *   warp     device fp32 (B,3,N,H,W): the aligned stack dffw_forward returns in out[4] for DFFW_NET_E2E engines
+ *   images   device uint8 (B,N,h,w,3): slice n of stack b as an interleaved image in the channel order of the input (the
+ *            reference reads BGR with cv2 and writes it back with cv2)
+ * Arithmetic: float32 `127.5f * (v + 1.0f)`, truncated toward zero; values in [-1,1] land in 0..255.  Outside that NumPy's cast is
+ * platform-defined; this entry point follows x86 NumPy (conversion to int32, low byte kept; NaN and |t| >= 2^31 give 0). */
+int dffw_unpack_stack(int device, const float *warp, int B, int N, int H, int W, int h, int w, uint8_t *images, void *hip_stream);
+
 /* dffw_metrics replaces the masked NumPy metrics of Depth_Estimation_Test/metrics.py:90-127 as called from
  * test.py:144-158: est = pred3 (B,H,W) cropped to (h,w) (test.py:124-126); gt fp32 (B,h,w); mask uint8 (B,h,w)
  * (non-zero = valid); conf fp32 (B,h,w) or NULL (Smartphone confidence, test.py:145-146).

@@ -242,6 +242,40 @@ def test_hip_e2e_call_contract(lib_built):
 
 
 @pytest.mark.gpu
+def test_real_scenes_driver_sequence(lib_built):
+    """The whole of End_to_End/test_real_scenes.py:24-52 on device for a synthetic scene of the `balls` kind (10 uint8 images,
+    focus_distance.txt / focal_length.txt values of the reference's scene): loader contract (1/12 border crop, /127.5 - 1, -1 padding
+    to x32, 1/d, relative FOV) -> Network -> warped slices as uint8 images cropped back + jet map of the min-max normalised depth.
+    Each stage against the oracle on the same numbers."""
+    from dffinthewild_amd import pipeline
+    from oracle import pipeline_ref
+    from tests.test_pipeline import BALLS_FOCUS, BALLS_FOCAL
+    g, sd, _, _, _ = load(SMOOTH[0])
+    rs = np.random.default_rng(77)
+    Hs, Ws = 96, 132                                             # source size: crop 8 / 11 per side -> 80 x 110 -> padded 96 x 128
+    yy, xx = np.mgrid[0:Hs, 0:Ws]
+    imgs = np.stack([np.stack([127.5 + 100 * np.sin(0.11 * xx + 0.07 * yy * (c + 1) + 0.3 * n) for c in range(3)], -1) for n in range(10)])
+    imgs = np.clip(imgs + rs.normal(0, 4, imgs.shape), 0, 255).astype(np.uint8)                     # (N,H,W,3) like cv2.imread per slice
+    crop = pipeline.real_scene_crop(Hs, Ws)
+    assert crop == (8, 11, 80, 110)
+    raw = torch.from_numpy(imgs)[None].cuda()                                                        # (1,N,H,W,3)
+    FS = pipeline.pack_stack(raw, layout="NHWC", crop=crop)
+    want_FS = pipeline_ref.pack_stack(imgs, "NHWC", crop=crop)[None]
+    assert FS.shape == (1, 3, 10, 96, 128) and np.array_equal(FS.cpu().numpy(), want_FS)
+    fd, fov = pipeline.real_scene_inputs(BALLS_FOCUS, BALLS_FOCAL)
+    model = _model(sd, "bf16x3")
+    with torch.no_grad():
+        _, _, _, depth, warped = model(FS, fd, fov)                                                  # TRS.py:34
+    ref = cpu_ref.e2e_forward(cpu_ref.to_torch_state(sd), torch.from_numpy(want_FS), fd.cpu(), fov.cpu())
+    assert cpu_ref.rel_l2(warped.cpu(), ref[4]) <= 1e-4 and cpu_ref.rel_l2(depth.cpu(), ref[3]) <= 1e-3
+    slices = pipeline.unpack_stack(warped, size=crop[2:])                                            # TRS.py:42-47
+    assert slices.shape == (1, 10, 80, 110, 3)
+    assert np.array_equal(slices.cpu().numpy(), pipeline_ref.unpack_stack(warped.cpu().numpy(), size=crop[2:]))
+    rgb = pipeline.colorize(depth, size=crop[2:])                                                    # TRS.py:40,48-52
+    assert np.array_equal(rgb.cpu().numpy()[0], pipeline_ref.colorize(depth[0].cpu().numpy(), size=crop[2:]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_hip_e2e_reduced_precision_runs(lib_built, precision):
     """Single-product arithmetic: reported, not a parity claim (measured: fp16 1.7e-3, bf16 1.2e-2 on pred3)."""

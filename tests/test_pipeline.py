@@ -88,6 +88,47 @@ def test_oracle_metrics_match_the_reference_functions(name):
     assert np.allclose(got, want, rtol=1e-6, atol=0), (got, want)
 
 
+# the one real scene the reference ships (End_to_End/Datasets/balls/focus_distance.txt, focal_length.txt; 10 JPEGs of 1280x720)
+BALLS_FOCUS = [7223525.792447, 208.130591, 58.335774, 39.112869, 27.335806, 22.975371, 17.020994, 15.317949, 12.74398, 10.0]
+BALLS_FOCAL = 0.2
+
+
+def test_real_scene_inputs_follow_the_loader():
+    """pipeline.real_scene_inputs / real_scene_crop against the loader's own NumPy lines (End_to_End/Test_dataloader.py:20-23,
+    37-53,75) executed here on the `balls` scene's values, and against the oracle."""
+    from dffinthewild_amd import pipeline
+    focus_dists = np.asarray(BALLS_FOCUS)
+    relative_Fov = (1 / BALLS_FOCAL - 1 / focus_dists)
+    relative_Fov = relative_Fov / np.min(relative_Fov)
+    relative_Fov = np.expand_dims(np.expand_dims(np.expand_dims(relative_Fov, axis=0), axis=2), axis=2)
+    fd_want = torch.Tensor(1 / np.expand_dims(np.expand_dims(focus_dists, axis=1), axis=2))          # (N,1,1)
+    fov_want = torch.Tensor(relative_Fov)                                                             # (1,N,1,1)
+    fd, fov = pipeline.real_scene_inputs(BALLS_FOCUS, BALLS_FOCAL, device="cpu")
+    assert fd.shape == (1, 10, 1, 1) and fov.shape == (1, 1, 10, 1, 1) and fd.dtype == fov.dtype == torch.float32
+    assert torch.equal(fd[0], fd_want) and torch.equal(fov[0], fov_want)                              # DataLoader(batch_size=1) adds dim 0
+    ofd, ofov = ref.real_scene_inputs(BALLS_FOCUS, BALLS_FOCAL)
+    assert np.array_equal(ofd, fd_want.numpy()) and np.array_equal(ofov, fov_want.numpy())
+    assert float(fov.min()) == 1.0 and float(fov[0, 0, 0]) > 1.0
+    # 720 x 1280 JPEGs: crop 60 / 106 per side -> 600 x 1068, padded to 608 x 1088 by pack_stack
+    assert pipeline.real_scene_crop(720, 1280) == (60, 106, 600, 1068)
+    with pytest.raises(ValueError):
+        pipeline.real_scene_crop(11, 640)
+
+
+def test_oracle_unpack_stack_follows_the_driver():
+    """oracle unpack_stack == test_real_scenes.py:44-47 executed literally for one stack."""
+    rng = np.random.default_rng(3)
+    x = (rng.random((1, 3, 4, 10, 12), dtype=np.float32) * 2 - 1).astype(np.float32)
+    x[0, :, 0, 0, :4] = np.array([-1.0, 1.0, 0.0, np.float32(1.0) - np.float32(2 ** -24)], np.float32)
+    test_warp_FS = np.squeeze(127.5 * (x + 1.0)).astype(np.uint8)
+    test_warp_FS = np.transpose(test_warp_FS, (2, 3, 0, 1))[:, :, :, :]
+    got = ref.unpack_stack(x, size=(9, 7))
+    assert got.shape == (1, 4, 9, 7, 3) and got.dtype == np.uint8
+    for i in range(4):
+        assert np.array_equal(got[0, i], test_warp_FS[:9, :7, :, i])
+    assert got[0, 0, 0, 0].tolist() == [0, 0, 0] and got[0, 0, 0, 1].tolist() == [255, 255, 255] and got[0, 0, 0, 2].tolist() == [127, 127, 127]
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def pl(lib_built):
@@ -194,6 +235,33 @@ def test_masked_metrics_match_the_reference_functions(pl, name):
                             torch.from_numpy(conf)[None].cuda()).cpu().numpy()[0]
     assert got[0] == want[0]
     assert np.allclose(got, want, rtol=2e-6, atol=0), (got, want)
+
+
+@pytest.mark.gpu
+def test_unpack_stack_bit_exact(pl):
+    """dffw_unpack_stack == the oracle byte for byte: random stacks in [-1,1] with the exact end points, values just inside the byte
+    boundaries, two stacks, crops; and the documented out-of-range behaviour (x86 NumPy: int32 conversion, low byte)."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 3, 5, 40, 72, generator=g) * 2 - 1
+    k = torch.arange(0, 256, dtype=torch.float32)
+    x[0, 0, 0, 0, :64] = (k[:64] / 127.5 - 1.0)                      # byte boundaries from below / above
+    x[0, 1, 0, 1, :64] = torch.nextafter(k[64:128] / 127.5 - 1.0, torch.tensor(2.0))
+    x[1, 2, 4, 2, :64] = torch.nextafter(k[192:] / 127.5 - 1.0, torch.tensor(-2.0))
+    x[1, 0, 0, 3, :2] = torch.tensor([-1.0, 1.0])
+    for size in (None, (33, 70), (1, 1)):
+        got = pl.unpack_stack(x.cuda(), size=size).cpu().numpy()
+        assert np.array_equal(got, ref.unpack_stack(x.numpy(), size=size)), size
+    wild = torch.tensor([1.5, -1.25, 3.0, -3.0, 1000.0, float("nan"), float("inf"), -float("inf"), 1e20]).reshape(1, 1, 1, 1, 9).repeat(1, 3, 1, 1, 1)
+    got = pl.unpack_stack(wild.cuda()).cpu().numpy()[0, 0, 0, :, 0]
+    t = (127.5 * (wild[0, 0, 0, 0].numpy().astype(np.float32) + np.float32(1.0))).astype(np.float32)
+    want = [(int(v) & 255) if np.isfinite(v) and abs(v) < 2.0 ** 31 else 0 for v in t]
+    assert got.tolist() == want, (got.tolist(), want)
+    with pytest.raises(ValueError):
+        pl.unpack_stack(x[:, :2].cuda())
+    with pytest.raises(ValueError):
+        pl.unpack_stack(x.cuda(), size=(41, 72))
+    with pytest.raises(RuntimeError):
+        pl.unpack_stack(x)                              # CPU tensor: no fallback
 
 
 @pytest.mark.gpu
