@@ -306,6 +306,8 @@ struct PackedConv {
     TilePack tile_pair;     // the stem once more, for the pixel-pair kernel (G2P); bias_pair = its BatchNorm shift for both pixels' rows
     float *bias_pair = nullptr;
     float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
+    float *whead = nullptr;   // device fp32: the last conv of an alpha head (biased 1x3x3, 3 outputs) as [3][cin][9] weights then [3] bias,
+                              // for head_tail_finish_kernel (conv + plane mean collapsed into plane sums)
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
@@ -338,6 +340,8 @@ static void free_packed(PackedConv &pc) {
     pc.bias_pair = nullptr;
     if (pc.w32) (void)hipFree(pc.w32);
     pc.w32 = nullptr;
+    if (pc.whead) (void)hipFree(pc.whead);
+    pc.whead = nullptr;
     if (pc.wroll) (void)hipFree(pc.wroll);
     pc.wroll = nullptr;
     if (pc.wroll_t) (void)hipFree(pc.wroll_t);
@@ -481,6 +485,15 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 for (int co = 0; co < L.cout; ++co) w32[((size_t)kz * L.cin + ci) * L.cout + co] = (float)wval(co, ci, Tap{0, 0, 0, kz, 0, 0});
         HIPCHK(hipMalloc((void **)&pc.w32, w32.size() * sizeof(float)));
         HIPCHK(hipMemcpy(pc.w32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    if (!L.transposed && L.bias && !bn && conv_bias && L.cout == 3 && L.kd == 1 && L.kh == 3 && L.kw == 3 && L.sh == 1 && L.ph == 1 && L.pw == 1 &&
+        L.dh == 1 && L.cin % 8 == 0 && L.cin <= 64 && !shortcut_w) {
+        std::vector<float> wh((size_t)3 * L.cin * 9 + 3);
+        memcpy(wh.data(), weight, (size_t)3 * L.cin * 9 * sizeof(float));      // PyTorch (3, cin, 1, 3, 3) is already [c][ci][dy][dx]
+        memcpy(wh.data() + (size_t)3 * L.cin * 9, conv_bias, 3 * sizeof(float));
+        HIPCHK(hipMalloc((void **)&pc.whead, wh.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(pc.whead, wh.data(), wh.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
     // ---- second packing for the LDS-tiled kernel, when a configuration covers this geometry ----------
@@ -1045,7 +1058,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -2309,16 +2322,33 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             }
         }
         const int64_t hw = (int64_t)y2.H * y2.W;
-        float *hf = (float *)r.raw(na * hw * sizeof(float));
-        ConvOpt of; of.outf = hf; of.outf_ch = 3;
-        r.conv(hp + ".6", y2, of);
-        r.drop(y2);
-        if (r.ok() && !r.dry) {
-            r.prof_begin("dffw::alpha_mean_kernel", std::string("flow") + lv.head + ".mean", 0.0, (double)na * hw * 4.0);
-            r.check(launch_alpha_mean(hf, alpha, rawh, B, N, hw, r.s), "alpha_mean");
-            r.prof_end();
+        auto c6 = r.e->convs.find(hp + ".6");
+        if (c6 != r.e->convs.end() && c6->second.whead && c6->second.def.cin == y2.C && !r.sw.on(SW_NO_HEAD_SUMS)) {
+            // last conv + plane mean collapsed into plane sums of y2 (dffw_kernels.hip, "alpha head tail"): y2 is read once, the
+            // 3-plane fp32 head output is never formed
+            const int nchunk = head_tail_chunks(B, N, hw);
+            double *partial = (double *)r.raw((int64_t)B * N * nchunk * y2.C * sizeof(double));
+            if (r.ok() && !r.dry) {
+                char kn6[64];
+                snprintf(kn6, sizeof kn6, "dffw::plane_sums_kernel<%d>", prec);
+                r.prof_begin(kn6, hp + ".6+mean", 2.0 * (double)y2.pixels() * 9.0 * y2.C * 3, (double)y2.pixels() * y2.C * r.elem_bytes());
+                r.check(launch_head_tail(prec, y2.p, partial, c6->second.whead, alpha, rawh, B, N, y2.H, y2.W, y2.C, r.s), "head_tail");
+                r.prof_end();
+            }
+            r.drop_raw(partial);
+            r.drop(y2);
+        } else {
+            float *hf = (float *)r.raw(na * hw * sizeof(float));
+            ConvOpt of; of.outf = hf; of.outf_ch = 3;
+            r.conv(hp + ".6", y2, of);
+            r.drop(y2);
+            if (r.ok() && !r.dry) {
+                r.prof_begin("dffw::alpha_mean_kernel", std::string("flow") + lv.head + ".mean", 0.0, (double)na * hw * 4.0);
+                r.check(launch_alpha_mean(hf, alpha, rawh, B, N, hw, r.s), "alpha_mean");
+                r.prof_end();
+            }
+            r.drop_raw(hf);
         }
-        r.drop_raw(hf);
         r.tap_f32(lv.tap, rawh, na);
     }
     r.tap_f32("alpha", alpha, na);

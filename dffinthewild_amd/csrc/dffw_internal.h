@@ -97,6 +97,11 @@ hipError_t launch_from_ncdhw_pad(int prec, const float *x, uint16_t *out, int B,
 hipError_t launch_flow_volume(int prec, const uint16_t *fe, uint16_t *out, const float *alpha, const float *fov, int B, int N,
                               int H, int W, int C, int mode, hipStream_t s);
 hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B, int N, int64_t hw, hipStream_t s);
+// alpha head tail (last conv + plane mean as plane sums of the head's last activation volume v (B,N,H,W,C)); partial: device scratch of
+// B*N*head_tail_chunks()*C doubles; w: PackedConv::whead
+int head_tail_chunks(int B, int N, int64_t hw);
+hipError_t launch_head_tail(int prec, const uint16_t *v, double *partial, const float *w, float *alpha, float *raw, int B, int N, int H, int W,
+                            int C, hipStream_t s);
 hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,
                            int H, int W, int alpha_from_sample0, hipStream_t s);
 hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd,

@@ -844,6 +844,137 @@ hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B,
     return hipGetLastError();
 }
 
+// ---- alpha head tail: Conv3d(C, 3, (1,3,3), padding (0,1,1)) + AdaptiveAvgPool3d((10,1,1)) as plane sums -----------------
+// (End_to_End.py:44-46,55-57,66-68.)  The head's last conv is linear and its result is only ever averaged over the whole
+// plane of a slice, so the pair collapses exactly (in real arithmetic):
+//     mean_{y,x} conv(v)[c] = bias[c] + 1/(H*W) * sum_{ci,dy,dx} w[c][ci][dy][dx] * S[dy][dx][ci],
+//     S[dy][dx][ci] = sum of v[ci] over the H x W window the tap (dy,dx) sees = total - (one border row) - (one border column)
+//                     + (the corner both removed): tap row dy = 0 reads rows -1..H-2 (row H-1 never), dy = 2 rows 1..H (row 0 never).
+// So instead of a 16/32/64 -> 3 channel conv over the full volume (13 dead rows of every MFMA result tile, 3 fp32 planes written and
+// read back by the mean) the volume is read ONCE by a streaming sum:
+//   plane_sums_kernel: grid (chunks, B*N); a workgroup adds up a contiguous range of pixel records of one slice, every thread a
+//     fixed 16-byte piece position of the record (8 channels of one part), float partial per thread, combined in a fixed order
+//     -> partial[(plane * chunks + chunk) * C + ci] (double).
+//   head_tail_finish_kernel: one workgroup per (b, slice): partials -> totals (fixed order), the two border rows / columns and four
+//     corners read from the volume itself, the 27 x C multiply-adds in double, then the update of alpha_mean_kernel (raw mean out,
+//     scale term damped by 0.001, accumulated).  Deterministic and independent of the batch position.
+template <int PREC>
+__global__ __launch_bounds__(256) void plane_sums_kernel(const uint16_t *__restrict__ v, double *__restrict__ partial, int C, int64_t hw,
+                                                         int64_t px_per_chunk) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int PR = PARTS * C / 8;                       // 16-byte pieces per pixel record; 256 % PR == 0
+    const int64_t plane = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * px_per_chunk, p1 = p0 + px_per_chunk < hw ? p0 + px_per_chunk : hw;
+    const uint4 *src = reinterpret_cast<const uint4 *>(v + (plane * hw + p0) * (int64_t)(PARTS * C));
+    const int64_t n = (p1 - p0) * PR;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add = [&](const uint4 q) {
+        float a, b;
+        Fmt<PREC>::join2(q.x, 0u, a, b); s[0] += a; s[1] += b;
+        Fmt<PREC>::join2(q.y, 0u, a, b); s[2] += a; s[3] += b;
+        Fmt<PREC>::join2(q.z, 0u, a, b); s[4] += a; s[5] += b;
+        Fmt<PREC>::join2(q.w, 0u, a, b); s[6] += a; s[7] += b;
+    };
+    int64_t i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) {                     // four loads in flight per thread
+        const uint4 q0 = src[i], q1 = src[i + 256], q2 = src[i + 512], q3 = src[i + 768];
+        add(q0); add(q1); add(q2); add(q3);
+    }
+    for (; i < n; i += 256) add(src[i]);
+    __shared__ float red[256][9];
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = s[k];
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        // channel ci lives in the pieces (part * C/8 + ci/8) of a record, i.e. in the threads t with t % PR == that; hi and lo add up
+        const int ci = threadIdx.x, o = ci >> 3, e = ci & 7, C8 = C >> 3;
+        double acc = 0.0;
+        for (int t = 0; t < 256; ++t)
+            if ((t % PR) % C8 == o) acc += (double)red[t][e];
+        partial[(plane * gridDim.x + blockIdx.x) * C + ci] = acc;
+    }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void head_tail_finish_kernel(const uint16_t *__restrict__ v, const double *__restrict__ partial, int nchunk,
+                                                               const float *__restrict__ w, float *__restrict__ alpha, float *__restrict__ raw,
+                                                               int N, int H, int W, int C) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    // sums[k][ci]: 0 total, 1 row 0, 2 row H-1, 3 column 0, 4 column W-1, 5..8 corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
+    __shared__ double sums[9][64];
+    __shared__ double red[256];
+    const int plane = blockIdx.x, b = plane / N, n = plane % N;
+    const int tid = threadIdx.x;
+    const int64_t hw = (int64_t)H * W;
+    const uint16_t *vp = v + (int64_t)plane * hw * (PARTS * C);
+    auto val = [&](int y, int x, int ci) -> double { return (double)Fmt<PREC>::load(vp + ((int64_t)y * W + x) * (PARTS * C), C, ci); };
+    if (tid < C) {
+        double t = 0.0;
+        for (int k = 0; k < nchunk; ++k) t += partial[((int64_t)plane * nchunk + k) * C + tid];
+        sums[0][tid] = t;
+        sums[5][tid] = val(0, 0, tid);
+        sums[6][tid] = val(0, W - 1, tid);
+        sums[7][tid] = val(H - 1, 0, tid);
+        sums[8][tid] = val(H - 1, W - 1, tid);
+    }
+    // border lines: thread = (position phase, channel); a channel's 256 / C partial sums are combined in thread order
+    const int ci = tid % C, ph = tid / C, nph = 256 / C;
+    for (int line = 0; line < 4; ++line) {
+        const int len = line < 2 ? W : H;
+        double t = 0.0;
+        for (int p = ph; p < len; p += nph) t += line == 0 ? val(0, p, ci) : line == 1 ? val(H - 1, p, ci) : line == 2 ? val(p, 0, ci) : val(p, W - 1, ci);
+        __syncthreads();
+        red[tid] = t;
+        __syncthreads();
+        if (tid < C) {
+            double a = 0.0;
+            for (int k = 0; k < nph; ++k) a += red[k * C + tid];
+            sums[1 + line][tid] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const int c = tid;
+        const float *wc = w + (int64_t)c * C * 9;
+        double acc = 0.0;
+        for (int k = 0; k < C; ++k) {
+            const double T = sums[0][k], R0 = sums[1][k], RL = sums[2][k], C0 = sums[3][k], CL = sums[4][k];
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    double S = T - (dy == 0 ? RL : dy == 2 ? R0 : 0.0) - (dx == 0 ? CL : dx == 2 ? C0 : 0.0);
+                    if (dy == 0 && dx == 0) S += sums[8][k];
+                    if (dy == 0 && dx == 2) S += sums[7][k];
+                    if (dy == 2 && dx == 0) S += sums[6][k];
+                    if (dy == 2 && dx == 2) S += sums[5][k];
+                    acc += (double)wc[k * 9 + dy * 3 + dx] * S;
+                }
+        }
+        const float m = (float)((double)w[3 * C * 9 + c] + acc / (double)hw);
+        const int idx = (b * 3 + c) * N + n;
+        if (raw) raw[idx] = m;
+        alpha[idx] += (c == 0) ? 0.001f * m : m;
+    }
+}
+
+int head_tail_chunks(int B, int N, int64_t hw) {
+    int nchunk = (int)((2560 + (int64_t)B * N - 1) / ((int64_t)B * N));   // ~10 workgroups per CU over the launch
+    if (nchunk < 1) nchunk = 1;
+    if ((int64_t)nchunk * 256 > hw) nchunk = (int)((hw + 255) / 256);
+    return nchunk;
+}
+
+hipError_t launch_head_tail(int prec, const uint16_t *v, double *partial, const float *w, float *alpha, float *raw, int B, int N, int H, int W,
+                            int C, hipStream_t s) {
+    const int64_t hw = (int64_t)H * W;
+    const int nchunk0 = head_tail_chunks(B, N, hw);
+    const int64_t ppc = (hw + nchunk0 - 1) / nchunk0;
+    const int nchunk = (int)((hw + ppc - 1) / ppc);      // no empty chunk; <= head_tail_chunks()
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((plane_sums_kernel<PR>), dim3(nchunk, B * N), dim3(256), 0, s, v, partial, C, hw, ppc));
+    hipError_t h = hipGetLastError();
+    if (h != hipSuccess) return h;
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((head_tail_finish_kernel<PR>), dim3(B * N), dim3(256), 0, s, v, partial, nchunk, w, alpha, raw, N, H, W, C));
+    return hipGetLastError();
+}
+
 // ---- depth regression --------------------------------------------------------------------------
 // One thread per output pixel; the N <= ~15 per-slice scores of a pixel are consumed in a register
 // loop (for fixed slice n consecutive lanes read consecutive x: coalesced), so the soft-argmin

@@ -174,10 +174,11 @@ def test_hip_e2e_batch_is_per_sample(lib_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK"])
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS"])
 def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     """The gather kernel (no LDS tiles), the unsplit alignment heads (reference slice carried in every slice's volume
-    instead of entering as a slice-broadcast residual) and the unsplit few-tile launches must give the same result."""
+    instead of entering as a slice-broadcast residual), the unsplit few-tile launches and the heads' last conv + plane mean as
+    launched operators (instead of plane sums) must give the same result."""
     g, sd, FS, fd, fov = load(GOLDEN[0])
     with torch.no_grad():
         base = _model(sd)(FS.cuda(), fd.cuda(), fov.cuda())
@@ -186,6 +187,44 @@ def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     for name, a, b in zip(OUT_NAMES, alt, base):
         assert cpu_ref.rel_l2(a.cpu(), b.cpu()) <= 2e-4, name
         assert cpu_ref.rel_l2(a.cpu(), g[name]) <= 1e-3, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("B,H,W", [(1, 64, 96), (2, 128, 256), (3, 32, 32)])
+def test_hip_e2e_head_tail_as_plane_sums(lib_built, monkeypatch, B, H, W, precision):
+    """End_to_End.py:44-46: Conv3d(C,3,(1,3,3)) + AdaptiveAvgPool3d((10,1,1)) at the end of every alpha head = bias + weights x
+    (plane sums minus border rows / columns plus corners) of the head's last activation volume (plane_sums_kernel +
+    head_tail_finish_kernel): every head's raw output against the launched conv + mean (DFFW_NO_HEAD_SUMS) and, in the default
+    arithmetic, against the oracle; bit-identical run to run and between batch positions holding the same stack."""
+    g, sd, FS, fd, fov = load(GOLDEN[0])
+    from dffinthewild_amd import synth
+    FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=17))
+    if B > 1:
+        FS[B - 1] = FS[0]
+    fd = fd[:1].expand(B, -1, -1, -1).contiguous()
+    fov = fov[:1].expand(B, -1, -1, -1, -1).contiguous()
+    tags = ["head3", "head2", "head1", "alpha"]
+    with torch.no_grad():
+        m = _model(sd, precision)
+        outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+        outs_b, taps_b = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+        monkeypatch.setenv("DFFW_NO_HEAD_SUMS", "1")
+        outs2, taps2 = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+    tol = {"bf16x3": 2e-5, "fp16": 2e-2, "bf16": 1e-1}[precision]
+    for tag in tags:
+        assert torch.equal(taps[tag], taps_b[tag]), tag
+        t = taps[tag].cpu().reshape(B, 3, 10)
+        if B > 1:
+            assert torch.equal(t[0], t[B - 1]), tag
+        err = cpu_ref.rel_l2(t, taps2[tag].cpu().reshape(B, 3, 10))
+        assert err <= tol, (tag, err)
+    assert not torch.equal(taps["head1"], taps2["head1"])          # equal would mean both runs took the same path
+    if precision == "bf16x3":
+        with torch.no_grad():
+            ref = cpu_ref.e2e_forward(cpu_ref.to_torch_state(sd), FS, fd, fov)
+        for name, o, r in zip(OUT_NAMES, outs, ref):
+            assert cpu_ref.rel_l2(o.cpu(), r) <= 1e-3, name
 
 
 @pytest.mark.gpu
