@@ -282,4 +282,59 @@ __device__ __forceinline__ void epilogue_cls(const ConvArgs &a, float partial, i
     if ((g & (rows - 1)) == 0 && pvalid) a.cls_out[opix] = partial;
 }
 
+// ---- FOV warp of the alignment network (End_to_End.py:106-134), shared by fov_warp_kernel, flow_volume_kernel and conv_tile's
+// warp-fill variant -------------------------------------------------------------------------------------------------------
+// flow of grid point (xx,yy) of a slice with scale f = FOV + a0 and shifts a1, a2, and the un-normalised sample
+// position (sx,sy) grid_sample(align_corners=True) derives from it
+struct WarpPoint {
+    float fx, fy, sx, sy;
+};
+__device__ __forceinline__ WarpPoint warp_point(int xx, int yy, int H, int W, float f, float a1, float a2) {
+    const float stepx = 2.0f / (float)(W > 1 ? W - 1 : 1), stepy = 2.0f / (float)(H > 1 ? H - 1 : 1);
+    // torch.linspace(-1, 1, steps): start + i*step in the first half, end - (steps-1-i)*step in the second
+    const float lx = xx < W / 2 ? -1.0f + (float)xx * stepx : 1.0f - (float)(W - 1 - xx) * stepx;
+    const float ly = yy < H / 2 ? -1.0f + (float)yy * stepy : 1.0f - (float)(H - 1 - yy) * stepy;
+    WarpPoint p;
+    p.fx = (float)(W / 2) * (f - 1.0f) * lx + a1;
+    p.fy = (float)(H / 2) * (f - 1.0f) * ly + a2;
+    // normalised grid, then grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
+    const float gx = 2.0f * ((float)xx - p.fx) / (float)(W > 1 ? W - 1 : 1) - 1.0f;
+    const float gy = 2.0f * ((float)yy - p.fy) / (float)(H > 1 ? H - 1 : 1) - 1.0f;
+    p.sx = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
+    p.sy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
+    return p;
+}
+
+
+// bilinear sample (zeros outside, grid_sample align_corners=True) of 8 consecutive channels of a channels-last slice at the
+// warped position of `wp`; `slice` points at channel octet's first element of pixel (0,0).  v must be zero-initialised.
+template <int PREC>
+__device__ __forceinline__ void warp_octet(const uint16_t *__restrict__ slice, int C, int H, int W, const WarpPoint &wp, float (&v)[8]) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const float x0f = floorf(wp.sx), y0f = floorf(wp.sy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = wp.sx - x0f, wy1 = wp.sy - y0f;
+    const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int yc = y0 + dy;
+        if (yc < 0 || yc >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xc = x0 + dx;
+            if (xc < 0 || xc >= W) continue;
+            const uint16_t *rec = slice + ((int64_t)yc * W + xc) * (PARTS * C);
+            const uint4 h = *reinterpret_cast<const uint4 *>(rec);
+            uint4 l = make_uint4(0, 0, 0, 0);
+            if constexpr (PARTS == 2) l = *reinterpret_cast<const uint4 *>(rec + C);
+            const float wgt = wx[dx] * wy[dy];
+            float a, c;
+            Fmt<PREC>::join2(h.x, l.x, a, c); v[0] += a * wgt; v[1] += c * wgt;
+            Fmt<PREC>::join2(h.y, l.y, a, c); v[2] += a * wgt; v[3] += c * wgt;
+            Fmt<PREC>::join2(h.z, l.z, a, c); v[4] += a * wgt; v[5] += c * wgt;
+            Fmt<PREC>::join2(h.w, l.w, a, c); v[6] += a * wgt; v[7] += c * wgt;
+        }
+    }
+}
+
 }  // namespace dffw

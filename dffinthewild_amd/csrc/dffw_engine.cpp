@@ -2327,7 +2327,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             // last conv + plane mean collapsed into plane sums of y2 (dffw_kernels.hip, "alpha head tail"): y2 is read once, the
             // 3-plane fp32 head output is never formed
             const int nchunk = head_tail_chunks(B, N, hw);
-            double *partial = (double *)r.raw((int64_t)B * N * nchunk * y2.C * sizeof(double));
+            double *partial = (double *)r.raw((int64_t)B * N * (nchunk + 4) * y2.C * sizeof(double));
             if (r.ok() && !r.dry) {
                 char kn6[64];
                 snprintf(kn6, sizeof kn6, "dffw::plane_sums_kernel<%d>", prec);

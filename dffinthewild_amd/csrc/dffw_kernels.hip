@@ -638,27 +638,7 @@ hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, c
 // to the device on every call; here the grid is analytic, one thread per (b,n,y,x) computes the four
 // bilinear corners once and reuses them for every channel.  The fp32 operation order of the reference
 // (normalise to [-1,1], then grid_sample's un-normalise) is kept so the result matches to rounding.
-// flow of grid point (xx,yy) of a slice with scale f = FOV + a0 and shifts a1, a2, and the un-normalised sample
-// position (sx,sy) grid_sample(align_corners=True) derives from it
-struct WarpPoint {
-    float fx, fy, sx, sy;
-};
-__device__ __forceinline__ WarpPoint warp_point(int xx, int yy, int H, int W, float f, float a1, float a2) {
-    const float stepx = 2.0f / (float)(W > 1 ? W - 1 : 1), stepy = 2.0f / (float)(H > 1 ? H - 1 : 1);
-    // torch.linspace(-1, 1, steps): start + i*step in the first half, end - (steps-1-i)*step in the second
-    const float lx = xx < W / 2 ? -1.0f + (float)xx * stepx : 1.0f - (float)(W - 1 - xx) * stepx;
-    const float ly = yy < H / 2 ? -1.0f + (float)yy * stepy : 1.0f - (float)(H - 1 - yy) * stepy;
-    WarpPoint p;
-    p.fx = (float)(W / 2) * (f - 1.0f) * lx + a1;
-    p.fy = (float)(H / 2) * (f - 1.0f) * ly + a2;
-    // normalised grid, then grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
-    const float gx = 2.0f * ((float)xx - p.fx) / (float)(W > 1 ? W - 1 : 1) - 1.0f;
-    const float gy = 2.0f * ((float)yy - p.fy) / (float)(H > 1 ? H - 1 : 1) - 1.0f;
-    p.sx = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
-    p.sy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
-    return p;
-}
-
+// (WarpPoint / warp_point / warp_octet: dffw_device.h, shared with conv_tile's warp-fill variant)
 __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__ x, const float *__restrict__ alpha,
                                                        const float *__restrict__ fov, float *__restrict__ out,
                                                        float *__restrict__ flow, int B, int C, int N, int H, int W,
@@ -763,31 +743,7 @@ __global__ __launch_bounds__(256) void flow_volume_kernel(const uint16_t *__rest
             v[1] = wp.fy;
         } else {
             const int cg = (mode == 0 && g >= CG) ? g - CG : g;
-            const float x0f = floorf(wp.sx), y0f = floorf(wp.sy);
-            const int x0 = (int)x0f, y0 = (int)y0f;
-            const float wx1 = wp.sx - x0f, wy1 = wp.sy - y0f;
-            const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1};
-            const uint16_t *slice = fe + ((int64_t)(b * N + src) * H * W) * (PARTS * C) + cg * 8;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int yc = y0 + dy;
-                if (yc < 0 || yc >= H) continue;
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int xc = x0 + dx;
-                    if (xc < 0 || xc >= W) continue;
-                    const uint16_t *rec = slice + ((int64_t)yc * W + xc) * (PARTS * C);
-                    const uint4 h = *reinterpret_cast<const uint4 *>(rec);
-                    uint4 l = make_uint4(0, 0, 0, 0);
-                    if constexpr (PARTS == 2) l = *reinterpret_cast<const uint4 *>(rec + C);
-                    const float wgt = wx[dx] * wy[dy];
-                    float a, c;
-                    Fmt<PREC>::join2(h.x, l.x, a, c); v[0] += a * wgt; v[1] += c * wgt;
-                    Fmt<PREC>::join2(h.y, l.y, a, c); v[2] += a * wgt; v[3] += c * wgt;
-                    Fmt<PREC>::join2(h.z, l.z, a, c); v[4] += a * wgt; v[5] += c * wgt;
-                    Fmt<PREC>::join2(h.w, l.w, a, c); v[6] += a * wgt; v[7] += c * wgt;
-                }
-            }
+            warp_octet<PREC>(fe + ((int64_t)(b * N + src) * H * W) * (PARTS * C) + cg * 8, C, H, W, wp, v);
         }
         uint4 h, l;
         Fmt<PREC>::split2(v[0], v[1], h.x, l.x);
@@ -854,16 +810,44 @@ hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B,
 // read back by the mean) the volume is read ONCE by a streaming sum:
 //   plane_sums_kernel: grid (chunks, B*N); a workgroup adds up a contiguous range of pixel records of one slice, every thread a
 //     fixed 16-byte piece position of the record (8 channels of one part), float partial per thread, combined in a fixed order
-//     -> partial[(plane * chunks + chunk) * C + ci] (double).
-//   head_tail_finish_kernel: one workgroup per (b, slice): partials -> totals (fixed order), the two border rows / columns and four
-//     corners read from the volume itself, the 27 x C multiply-adds in double, then the update of alpha_mean_kernel (raw mean out,
-//     scale term damped by 0.001, accumulated).  Deterministic and independent of the batch position.
+//     -> partial[(plane * (chunks + 4) + chunk) * C + ci] (double); four more workgroups per plane sum the two border rows / columns.
+//   head_tail_finish_kernel: one wave per (b, slice): partials -> totals (fixed order), the four corners read from the volume
+//     itself, the 27 x C multiply-adds in double, then the update of alpha_mean_kernel (raw mean out, scale term damped by 0.001,
+//     accumulated).  Deterministic and independent of the batch position.
 template <int PREC>
-__global__ __launch_bounds__(256) void plane_sums_kernel(const uint16_t *__restrict__ v, double *__restrict__ partial, int C, int64_t hw,
-                                                         int64_t px_per_chunk) {
+__global__ __launch_bounds__(256) void plane_sums_kernel(const uint16_t *__restrict__ v, double *__restrict__ partial, int C, int H, int W,
+                                                         int64_t px_per_chunk, int nchunk) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     const int PR = PARTS * C / 8;                       // 16-byte pieces per pixel record; 256 % PR == 0
-    const int64_t plane = blockIdx.y;
+    const int64_t plane = blockIdx.y, hw = (int64_t)H * W;
+    double *dst = partial + (plane * (nchunk + 4) + blockIdx.x) * C;
+    __shared__ float red[256][9];
+    if ((int)blockIdx.x >= nchunk) {
+        // the last four workgroups of a plane: one border line each (row 0, row H-1, column 0, column W-1); thread = (position
+        // phase, channel), a channel's 256 / C partial sums are combined in thread order
+        const int line = blockIdx.x - nchunk, len = line < 2 ? W : H;
+        const int64_t first = line == 1 ? (int64_t)(H - 1) * W : line == 3 ? W - 1 : 0, step = line < 2 ? 1 : W;
+        const uint16_t *vp = v + (plane * hw + first) * (int64_t)(PARTS * C);
+        const int ci = threadIdx.x % C, ph = threadIdx.x / C, nph = 256 / C;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        int p = ph;
+        for (; p + 3 * nph < len; p += 4 * nph) {
+            const float a0 = Fmt<PREC>::load(vp + (int64_t)p * step * (PARTS * C), C, ci);
+            const float a1 = Fmt<PREC>::load(vp + (int64_t)(p + nph) * step * (PARTS * C), C, ci);
+            const float a2 = Fmt<PREC>::load(vp + (int64_t)(p + 2 * nph) * step * (PARTS * C), C, ci);
+            const float a3 = Fmt<PREC>::load(vp + (int64_t)(p + 3 * nph) * step * (PARTS * C), C, ci);
+            t0 += a0; t1 += a1; t2 += a2; t3 += a3;
+        }
+        for (; p < len; p += nph) t0 += Fmt<PREC>::load(vp + (int64_t)p * step * (PARTS * C), C, ci);
+        red[threadIdx.x][0] = (t0 + t1) + (t2 + t3);
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            double a = 0.0;
+            for (int k = 0; k < nph; ++k) a += (double)red[k * C + threadIdx.x][0];
+            dst[threadIdx.x] = a;
+        }
+        return;
+    }
     const int64_t p0 = (int64_t)blockIdx.x * px_per_chunk, p1 = p0 + px_per_chunk < hw ? p0 + px_per_chunk : hw;
     const uint4 *src = reinterpret_cast<const uint4 *>(v + (plane * hw + p0) * (int64_t)(PARTS * C));
     const int64_t n = (p1 - p0) * PR;
@@ -881,7 +865,6 @@ __global__ __launch_bounds__(256) void plane_sums_kernel(const uint16_t *__restr
         add(q0); add(q1); add(q2); add(q3);
     }
     for (; i < n; i += 256) add(src[i]);
-    __shared__ float red[256][9];
     for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = s[k];
     __syncthreads();
     if ((int)threadIdx.x < C) {
@@ -890,46 +873,32 @@ __global__ __launch_bounds__(256) void plane_sums_kernel(const uint16_t *__restr
         double acc = 0.0;
         for (int t = 0; t < 256; ++t)
             if ((t % PR) % C8 == o) acc += (double)red[t][e];
-        partial[(plane * gridDim.x + blockIdx.x) * C + ci] = acc;
+        dst[ci] = acc;
     }
 }
 
 template <int PREC>
-__global__ __launch_bounds__(256) void head_tail_finish_kernel(const uint16_t *__restrict__ v, const double *__restrict__ partial, int nchunk,
-                                                               const float *__restrict__ w, float *__restrict__ alpha, float *__restrict__ raw,
-                                                               int N, int H, int W, int C) {
+__global__ __launch_bounds__(64) void head_tail_finish_kernel(const uint16_t *__restrict__ v, const double *__restrict__ partial, int nchunk,
+                                                              const float *__restrict__ w, float *__restrict__ alpha, float *__restrict__ raw,
+                                                              int N, int H, int W, int C) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     // sums[k][ci]: 0 total, 1 row 0, 2 row H-1, 3 column 0, 4 column W-1, 5..8 corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
     __shared__ double sums[9][64];
-    __shared__ double red[256];
     const int plane = blockIdx.x, b = plane / N, n = plane % N;
     const int tid = threadIdx.x;
     const int64_t hw = (int64_t)H * W;
     const uint16_t *vp = v + (int64_t)plane * hw * (PARTS * C);
     auto val = [&](int y, int x, int ci) -> double { return (double)Fmt<PREC>::load(vp + ((int64_t)y * W + x) * (PARTS * C), C, ci); };
     if (tid < C) {
+        const double *pp = partial + (int64_t)plane * (nchunk + 4) * C + tid;
         double t = 0.0;
-        for (int k = 0; k < nchunk; ++k) t += partial[((int64_t)plane * nchunk + k) * C + tid];
+        for (int k = 0; k < nchunk; ++k) t += pp[(int64_t)k * C];
         sums[0][tid] = t;
+        for (int k = 0; k < 4; ++k) sums[1 + k][tid] = pp[(int64_t)(nchunk + k) * C];
         sums[5][tid] = val(0, 0, tid);
         sums[6][tid] = val(0, W - 1, tid);
         sums[7][tid] = val(H - 1, 0, tid);
         sums[8][tid] = val(H - 1, W - 1, tid);
-    }
-    // border lines: thread = (position phase, channel); a channel's 256 / C partial sums are combined in thread order
-    const int ci = tid % C, ph = tid / C, nph = 256 / C;
-    for (int line = 0; line < 4; ++line) {
-        const int len = line < 2 ? W : H;
-        double t = 0.0;
-        for (int p = ph; p < len; p += nph) t += line == 0 ? val(0, p, ci) : line == 1 ? val(H - 1, p, ci) : line == 2 ? val(p, 0, ci) : val(p, W - 1, ci);
-        __syncthreads();
-        red[tid] = t;
-        __syncthreads();
-        if (tid < C) {
-            double a = 0.0;
-            for (int k = 0; k < nph; ++k) a += red[k * C + tid];
-            sums[1 + line][tid] = a;
-        }
     }
     __syncthreads();
     if (tid < 3) {
@@ -968,10 +937,10 @@ hipError_t launch_head_tail(int prec, const uint16_t *v, double *partial, const 
     const int nchunk0 = head_tail_chunks(B, N, hw);
     const int64_t ppc = (hw + nchunk0 - 1) / nchunk0;
     const int nchunk = (int)((hw + ppc - 1) / ppc);      // no empty chunk; <= head_tail_chunks()
-    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((plane_sums_kernel<PR>), dim3(nchunk, B * N), dim3(256), 0, s, v, partial, C, hw, ppc));
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((plane_sums_kernel<PR>), dim3(nchunk + 4, B * N), dim3(256), 0, s, v, partial, C, H, W, ppc, nchunk));
     hipError_t h = hipGetLastError();
     if (h != hipSuccess) return h;
-    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((head_tail_finish_kernel<PR>), dim3(B * N), dim3(256), 0, s, v, partial, nchunk, w, alpha, raw, N, H, W, C));
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((head_tail_finish_kernel<PR>), dim3(B * N), dim3(64), 0, s, v, partial, nchunk, w, alpha, raw, N, H, W, C));
     return hipGetLastError();
 }
 
@@ -1073,6 +1042,12 @@ hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H,
 __global__ void set_raw_kernel(RawStack rs, RawStack *dst) { *dst = rs; }
 hipError_t launch_set_raw(const RawStack &rs, RawStack *dst, hipStream_t s) {
     hipLaunchKernelGGL(set_raw_kernel, dim3(1), dim3(1), 0, s, rs, dst);
+    return hipGetLastError();
+}
+
+__global__ void set_warp_kernel(WarpSrc ws, WarpSrc *dst) { *dst = ws; }
+hipError_t launch_set_warp(const WarpSrc &ws, WarpSrc *dst, hipStream_t s) {
+    hipLaunchKernelGGL(set_warp_kernel, dim3(1), dim3(1), 0, s, ws, dst);
     return hipGetLastError();
 }
 
