@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
         constexpr int NITW = (NITEM + NWAVES * 64 - 1) / (NWAVES * 64);
         const int iy0 = c.gy0 + G::MINY, ix0 = c.gx0 + G::MINX;
         const int fc8 = ws.C >> 3;                                       // octet index of the flow record
-#pragma unroll
+#pragma unroll 2   // two items' corner loads in flight per thread (all of them: +80 VGPRs, a resident workgroup lost)
         for (int it = 0; it < NITW; ++it) {
             const int item = tid + it * NWAVES * 64;
             if (item >= NITEM) break;

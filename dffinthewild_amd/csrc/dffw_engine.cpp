@@ -1058,7 +1058,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_WARP_FILL)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1105,6 +1105,8 @@ struct ConvOpt {
     int outf_ch = 1;
     const float *fs32 = nullptr;  // stem: read the fp32 focal stack directly (in0 then only carries the geometry)
     bool raw = false;   // stem: fs32 is a device-side RawStack descriptor (raw uint8 / 0..255 stack, normalised and padded on the fly)
+    const WarpSrc *warp = nullptr;   // per-slice 1x3x3 conv over the FOV-warped volume described by this device-side descriptor (in0 then
+                                     // only carries the geometry): conv_tile's warp-fill variant; Run::warp_conv_ok() says when it exists
     const char *cls = nullptr;  // name of a 1x1x1 C->1 layer to apply to the final value inside the epilogue
     float *cls_out = nullptr;   // its fp32 score volume
     bool discard = false;       // the activation output itself is not needed (only cls_out / out_pre)
@@ -1228,6 +1230,16 @@ struct Run {
         return c && !sw.on(SW_NO_TILE) && gW * 2 >= c->tx && gH * 2 >= c->ty;
     }
 
+    // conv_tile's warp-fill variant serves per-slice layer `name` on a (B,N,H,W) volume: tiled, an instantiation exists, and enough
+    // tiles that conv() will not split the output channels over the grid
+    bool warp_conv_ok(const std::string &name, int B, int N, int H, int W) const {
+        if (!tiled(name, H, W)) return false;
+        const TileCfg *c = e->convs.find(name)->second.tile.cfg;
+        if (!tile_cfg_has_warp(c)) return false;
+        const int64_t tiles = (int64_t)B * ((N + c->tz - 1) / c->tz) * ((H + c->ty - 1) / c->ty) * ((W + c->tx - 1) / c->tx);
+        return tiles >= 256 && sw.small_max_units == 0;
+    }
+
     Act conv(const std::string &name, const Act &in0, const ConvOpt &o = ConvOpt()) {
         Act out;
         if (!ok()) return out;
@@ -1299,6 +1311,14 @@ struct Run {
         a.zero = e->zero_page;
         a.dbg = sw.debug_flags & (7 | 48 | 64);
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
+        if (o.warp) {
+            if (!warp_conv_ok(name, in0.B, in0.N, in0.H, in0.W)) {
+                err = fail(DFFW_EINVAL, "layer %s has no warp-fill kernel for this shape", name.c_str());
+                return out;
+            }
+            a.fs32 = reinterpret_cast<const float *>(o.warp);
+            a.dbg |= DFFW_ARGS_WARP;
+        }
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
             (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= 256 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_T32)) {
@@ -1612,7 +1632,7 @@ struct Run {
 #ifdef DFFW_WITH_PP
                 if (use_pp) return conv_pp_kernel_name(e->prec, cfg, kn, n);
 #endif
-                conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & DFFW_ARGS_RAW), kn, n);
+                conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_WARP)), kn, n);
             };
             {
                 char kn[96];
@@ -2250,15 +2270,31 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             // for all N slices of a sample, so it runs once per sample (1/N of the work, no ref channels in the volume) and
             // enters the per-slice conv over [cur | flow] as a slice-broadcast residual in front of the ReLU
             Act refw = r.act(B, 1, fe.H, fe.W, fe.C);
-            Act vol = r.act(B, N, fe.H, fe.W, fe.C + 8);
+            // [cur | flow] is not materialised when the per-slice conv has a warp-fill kernel for this shape: it samples the warped
+            // features while staging its tiles (conv_tile's WARP variant)
+            const bool fused = r.warp_conv_ok(hp + ".0.0#cur", B, N, fe.H, fe.W) && !r.sw.on(SW_NO_WARP_FILL);
+            Act vol;
+            WarpSrc *wsrc = nullptr;
+            if (fused) {
+                vol.B = B; vol.N = N; vol.H = fe.H; vol.W = fe.W; vol.C = fe.C + 8;
+                wsrc = (WarpSrc *)r.raw(sizeof(WarpSrc));
+            } else {
+                vol = r.act(B, N, fe.H, fe.W, fe.C + 8);
+            }
             if (r.ok() && !r.dry) {
                 r.prof_begin(kn, std::string("flow") + lv.head + ".volume", 0.0,
-                             ((double)fe.pixels() * (2.0 * fe.C + 8) + (double)refw.pixels() * 2.0 * fe.C) * r.elem_bytes());
+                             ((double)(fused ? 0 : fe.pixels()) * (2.0 * fe.C + 8) + (double)refw.pixels() * 2.0 * fe.C) * r.elem_bytes());
                 r.check(launch_flow_volume(prec, fe.p, refw.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 2, r.s), "flow_volume ref");
-                r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 1, r.s), "flow_volume cur");
+                if (fused) {
+                    WarpSrc ws;
+                    ws.fe = fe.p; ws.alpha = alpha; ws.fov = fov; ws.C = fe.C; ws.pad = 0;
+                    r.check(launch_set_warp(ws, wsrc, r.s), "set_warp");
+                } else {
+                    r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 1, r.s), "flow_volume cur");
+                }
                 r.prof_end();
             }
-            r.drop(fe);
+            if (!fused) r.drop(fe);
             // per-slice conv: the B reference slices are presented as the B slices of ONE sample so that the 5-slice tiles
             // are filled (same memory either way)
             Act refw1 = refw;
@@ -2269,8 +2305,14 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             ConvOpt oc = rl;
             oc.res0 = &refpart;
             oc.res_bcast = true;
+            oc.warp = wsrc;
             y0 = r.conv(hp + ".0.0#cur", vol, oc);
-            r.drop(vol);
+            if (fused) {
+                r.drop(fe);
+                r.drop_raw(wsrc);
+            } else {
+                r.drop(vol);
+            }
             r.drop(refpart);
         } else {
             const int Cv = 2 * fe.C + 8;                  // 2C+2 channels of End_to_End.py:81-84, padded to a multiple of 8

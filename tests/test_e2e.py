@@ -174,7 +174,7 @@ def test_hip_e2e_batch_is_per_sample(lib_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS"])
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_WARP_FILL"])
 def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     """The gather kernel (no LDS tiles), the unsplit alignment heads (reference slice carried in every slice's volume
     instead of entering as a slice-broadcast residual), the unsplit few-tile launches and the heads' last conv + plane mean as
@@ -187,6 +187,57 @@ def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     for name, a, b in zip(OUT_NAMES, alt, base):
         assert cpu_ref.rel_l2(a.cpu(), b.cpu()) <= 2e-4, name
         assert cpu_ref.rel_l2(a.cpu(), g[name]) <= 1e-3, name
+
+
+def _profiled_kernels(model, *inputs):
+    eng = model._engine_on(inputs[0].device)
+    eng.profile(True)
+    with torch.no_grad():
+        model(*inputs)
+    rows = eng.profile_collect()
+    eng.profile(False)
+    return [(r[0], r[1]) for r in rows]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+def test_hip_e2e_warp_fill_first_head_conv(lib_built, monkeypatch, precision):
+    """conv_tile's warp-fill variant (first conv of every alpha head samples the FOV-warped features while staging its tiles;
+    End_to_End.py:77-84 without the [cur | flow] volume) against the flow_volume + conv form (DFFW_NO_WARP_FILL) on a batch large
+    enough that all three levels take the fused kernel: same helper, same operation order -> the head outputs agree to rounding
+    noise of the two kernels' FMA contraction; the profile proves which kernels ran; default arithmetic also against the oracle."""
+    g, sd, FS, fd, fov = load(GOLDEN[0])
+    from dffinthewild_amd import synth
+    B, H, W = 4, 128, 256
+    FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=23))
+    fd = fd[:1].expand(B, -1, -1, -1).contiguous()
+    fov = torch.cat([1.0 + (fov[:1] - 1.0) * k for k in (1.0, 0.5, 1.5, -0.7)], 0).contiguous()   # magnifying and shrinking warps
+    tags = ["head3", "head2", "head1", "alpha"]
+    m = _model(sd, precision)
+    with torch.no_grad():
+        outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+    ran = _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda())
+    fused = [k for k, layer in ran if layer.endswith(".0.0#cur")]
+    assert len(fused) == 3 and all(k.endswith("true>") for k in fused), fused
+    vols = [k for k, layer in ran if layer.endswith(".volume")]
+    assert len(vols) == 3
+    monkeypatch.setenv("DFFW_NO_WARP_FILL", "1")
+    m2 = _model(sd, precision)
+    with torch.no_grad():
+        outs2, taps2 = m2.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+    ran2 = _profiled_kernels(m2, FS.cuda(), fd.cuda(), fov.cuda())
+    assert all(k.endswith("false>") for k, layer in ran2 if layer.endswith(".0.0#cur"))
+    tol = {"bf16x3": 2e-6, "fp16": 1e-3, "bf16": 1e-2}[precision]
+    for tag in tags:
+        err = cpu_ref.rel_l2(taps[tag].cpu(), taps2[tag].cpu())
+        assert err <= tol, (tag, err)
+    for name, a, b in zip(OUT_NAMES, outs, outs2):
+        assert cpu_ref.rel_l2(a.cpu(), b.cpu()) <= 50 * tol, name
+    if precision == "bf16x3":
+        with torch.no_grad():
+            ref = cpu_ref.e2e_forward(cpu_ref.to_torch_state(sd), FS[:2], fd[:2], fov[:2])
+        for name, o, r in zip(OUT_NAMES, outs, ref):
+            assert cpu_ref.rel_l2(o[:2].cpu(), r) <= 1e-3, name
 
 
 @pytest.mark.gpu
