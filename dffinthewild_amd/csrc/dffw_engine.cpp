@@ -1058,7 +1058,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_WARP_FILL)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(WARP_FILL) X(NO_HEAD_SUMS_FUSED)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -2272,7 +2272,9 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             Act refw = r.act(B, 1, fe.H, fe.W, fe.C);
             // [cur | flow] is not materialised when the per-slice conv has a warp-fill kernel for this shape: it samples the warped
             // features while staging its tiles (conv_tile's WARP variant)
-            const bool fused = r.warp_conv_ok(hp + ".0.0#cur", B, N, fe.H, fe.W) && !r.sw.on(SW_NO_WARP_FILL);
+            // (opt-in, DFFW_WARP_FILL=1: measured slower than flow_volume + LDS-DMA fill -- 1.64 vs 0.85 + 0.93 ms at level 1 -- the
+            // gathers of a tile are one dependent latency chain per workgroup at two workgroups per CU)
+            const bool fused = r.warp_conv_ok(hp + ".0.0#cur", B, N, fe.H, fe.W) && r.sw.on(SW_WARP_FILL);
             Act vol;
             WarpSrc *wsrc = nullptr;
             if (fused) {
@@ -2327,6 +2329,9 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             r.drop(vol);
         }
         Act y2;
+        auto c6 = r.e->convs.find(hp + ".6");
+        const bool tail_sums = c6 != r.e->convs.end() && c6->second.whead && !r.sw.on(SW_NO_HEAD_SUMS);
+        bool tail_done = false;
         {
             // two 16 -> 16 per-slice convs in a row (level-1 head at full resolution): one streaming kernel, the intermediate in LDS
             auto c2 = r.e->convs.find(hp + ".2.0"), c4 = r.e->convs.find(hp + ".4.0");
@@ -2334,28 +2339,49 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             if (y0.C == 16 && c2 != end && c4 != end && c2->second.wsrd && c4->second.wsrd && c2->second.def.cout == 16 && c4->second.def.cout == 16 &&
                 c2->second.cin_all == 16 && c4->second.cin_all == 16 && y0.H % 8 == 0 && y0.W % 16 == 0 &&
                 (int64_t)y0.B * (y0.H / 8) * (y0.W / 16) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
-                y2 = r.act(y0.B, y0.N, y0.H, y0.W, 16);
+                // ... and when the head's tail runs as plane sums, the pair's output is not stored either: the kernel leaves nine
+                // 16-channel vectors per (slice, column) and head_tail_finish_tiles does the rest
+                const bool sums = tail_sums && c6->second.def.cin == 16 && !r.sw.on(SW_NO_HEAD_SUMS_FUSED);
+                const int tiles_y = y0.H / 8, tiles_x = y0.W / 16;
+                float *tsum = nullptr;
+                double *seg = nullptr;
+                if (sums) {
+                    tsum = (float *)r.raw((int64_t)B * N * tiles_y * tiles_x * 18 * 16 * sizeof(float));
+                    seg = (double *)r.raw(head_tail_tiles_scratch_bytes(B, N, 16));
+                }
+                else y2 = r.act(y0.B, y0.N, y0.H, y0.W, 16);
                 if (r.ok() && !r.dry) {
                     if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return r.err; }
                     SrdArgs a;
                     memset(&a, 0, sizeof a);
-                    a.x = y0.p; a.out = y2.p;
+                    a.x = y0.p; a.out = sums ? (uint16_t *)tsum : y2.p;
                     a.w0 = c2->second.wsrd; a.w2 = c4->second.wsrd;
                     a.b0 = c2->second.bias; a.b2 = c4->second.bias;
                     a.zero = r.e->zero_page;
                     a.B = y0.B; a.N = y0.N; a.H = y0.H; a.W = y0.W;
-                    a.tiles_y = y0.H / 8; a.tiles_x = y0.W / 16;
+                    a.tiles_y = tiles_y; a.tiles_x = tiles_x;
                     a.total_tiles = y0.B * a.tiles_y * a.tiles_x;
                     a.wgs = r.sw.srd_wgs;
                     char kn2[64];
-                    of_roll_kernel_name(prec, false, kn2, sizeof kn2);
+                    of_roll_kernel_name(prec, false, kn2, sizeof kn2, sums);
                     g_last_kernel = kn2;
                     const double px = (double)y0.pixels();
-                    r.prof_begin(kn2, hp + ".2.0+.4.0", 2.0 * px * 2 * 9.0 * 16 * 16, px * 32 * r.elem_bytes());
-                    r.check(launch_of_roll(prec, false, a, r.s), "of_roll (head)");
+                    r.prof_begin(kn2, hp + (sums ? ".2.0+.4.0+.6+mean" : ".2.0+.4.0"), 2.0 * px * (2 * 9.0 * 16 * 16 + (sums ? 9.0 * 16 * 3 : 0.0)),
+                                 px * (sums ? 16 : 32) * r.elem_bytes());
+                    r.check(launch_of_roll(prec, false, a, r.s, sums), "of_roll (head)");
                     r.prof_end();
+                    if (sums) {
+                        r.prof_begin("dffw::head_tail_tiles_reduce_kernel", hp + ".6+mean (finish)", 0.0, (double)B * N * tiles_y * tiles_x * 18 * 16 * 4.0);
+                        r.check(launch_head_tail_tiles(tsum, seg, tiles_y, tiles_x, c6->second.whead, alpha, rawh, B, N, y0.H, y0.W, 16, r.s), "head_tail_tiles");
+                        r.prof_end();
+                    }
                 }
                 r.drop(y0);
+                if (sums) {
+                    r.drop_raw(seg);
+                    r.drop_raw(tsum);
+                    tail_done = true;
+                }
             } else {
                 Act y1 = r.conv(hp + ".2.0", y0, rl);
                 r.drop(y0);
@@ -2363,9 +2389,9 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
                 r.drop(y1);
             }
         }
-        const int64_t hw = (int64_t)y2.H * y2.W;
-        auto c6 = r.e->convs.find(hp + ".6");
-        if (c6 != r.e->convs.end() && c6->second.whead && c6->second.def.cin == y2.C && !r.sw.on(SW_NO_HEAD_SUMS)) {
+        const int64_t hw = (int64_t)fe.H * fe.W;
+        if (tail_done) {
+        } else if (tail_sums && c6->second.def.cin == y2.C) {
             // last conv + plane mean collapsed into plane sums of y2 (dffw_kernels.hip, "alpha head tail"): y2 is read once, the
             // 3-plane fp32 head output is never formed
             const int nchunk = head_tail_chunks(B, N, hw);

@@ -111,6 +111,11 @@ hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B,
 // alpha head tail (last conv + plane mean as plane sums of the head's last activation volume v (B,N,H,W,C)); partial: device scratch of
 // B*N*(head_tail_chunks()+4)*C doubles; w: PackedConv::whead
 int head_tail_chunks(int B, int N, int64_t hw);
+// ... from the per-tile vectors of of_roll_kernel<.., SUMS> (tsum: B*N*tiles_y*tiles_x*18*C floats)
+// seg: device scratch of head_tail_tiles_scratch_bytes()
+int64_t head_tail_tiles_scratch_bytes(int B, int N, int C);
+hipError_t launch_head_tail_tiles(const float *tsum, double *seg, int tiles_y, int tiles_x, const float *w, float *alpha, float *raw, int B,
+                                  int N, int H, int W, int C, hipStream_t s);
 hipError_t launch_head_tail(int prec, const uint16_t *v, double *partial, const float *w, float *alpha, float *raw, int B, int N, int H, int W,
                             int C, hipStream_t s);
 hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,

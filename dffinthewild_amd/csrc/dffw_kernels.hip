@@ -814,6 +814,30 @@ hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B,
 //   head_tail_finish_kernel: one wave per (b, slice): partials -> totals (fixed order), the four corners read from the volume
 //     itself, the 27 x C multiply-adds in double, then the update of alpha_mean_kernel (raw mean out, scale term damped by 0.001,
 //     accumulated).  Deterministic and independent of the batch position.
+// sums[k][ci]: 0 plane total, 1 row 0, 2 row H-1, 3 column 0, 4 column W-1, 5..8 corners (0,0) (0,W-1) (H-1,0) (H-1,W-1);
+// w: [3][C][9] then [3] bias.  Thread c (0..2) computes the mean of output channel c and applies alpha_mean_kernel's update.
+__device__ __forceinline__ void head_tail_apply(const double (*sums)[64], const float *__restrict__ w, float *__restrict__ alpha,
+                                                float *__restrict__ raw, int b, int n, int N, int64_t hw, int C, int c) {
+    const float *wc = w + (int64_t)c * C * 9;
+    double acc = 0.0;
+    for (int k = 0; k < C; ++k) {
+        const double T = sums[0][k], R0 = sums[1][k], RL = sums[2][k], C0 = sums[3][k], CL = sums[4][k];
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                double S = T - (dy == 0 ? RL : dy == 2 ? R0 : 0.0) - (dx == 0 ? CL : dx == 2 ? C0 : 0.0);
+                if (dy == 0 && dx == 0) S += sums[8][k];
+                if (dy == 0 && dx == 2) S += sums[7][k];
+                if (dy == 2 && dx == 0) S += sums[6][k];
+                if (dy == 2 && dx == 2) S += sums[5][k];
+                acc += (double)wc[k * 9 + dy * 3 + dx] * S;
+            }
+    }
+    const float m = (float)((double)w[3 * C * 9 + c] + acc / (double)hw);
+    const int idx = (b * 3 + c) * N + n;
+    if (raw) raw[idx] = m;
+    alpha[idx] += (c == 0) ? 0.001f * m : m;
+}
+
 template <int PREC>
 __global__ __launch_bounds__(256) void plane_sums_kernel(const uint16_t *__restrict__ v, double *__restrict__ partial, int C, int H, int W,
                                                          int64_t px_per_chunk, int nchunk) {
@@ -901,27 +925,72 @@ __global__ __launch_bounds__(64) void head_tail_finish_kernel(const uint16_t *__
         sums[8][tid] = val(H - 1, W - 1, tid);
     }
     __syncthreads();
-    if (tid < 3) {
-        const int c = tid;
-        const float *wc = w + (int64_t)c * C * 9;
-        double acc = 0.0;
-        for (int k = 0; k < C; ++k) {
-            const double T = sums[0][k], R0 = sums[1][k], RL = sums[2][k], C0 = sums[3][k], CL = sums[4][k];
-            for (int dy = 0; dy < 3; ++dy)
-                for (int dx = 0; dx < 3; ++dx) {
-                    double S = T - (dy == 0 ? RL : dy == 2 ? R0 : 0.0) - (dx == 0 ? CL : dx == 2 ? C0 : 0.0);
-                    if (dy == 0 && dx == 0) S += sums[8][k];
-                    if (dy == 0 && dx == 2) S += sums[7][k];
-                    if (dy == 2 && dx == 0) S += sums[6][k];
-                    if (dy == 2 && dx == 2) S += sums[5][k];
-                    acc += (double)wc[k * 9 + dy * 3 + dx] * S;
-                }
-        }
-        const float m = (float)((double)w[3 * C * 9 + c] + acc / (double)hw);
-        const int idx = (b * 3 + c) * N + n;
-        if (raw) raw[idx] = m;
-        alpha[idx] += (c == 0) ? 0.001f * m : m;
+    if (tid < 3) head_tail_apply(sums, w, alpha, raw, b, n, N, hw, C, tid);
+}
+
+// the same finish for of_roll_kernel<.., SUMS>'s per-tile vectors: tsum[(plane * tiles + tile) * 18 * C + k * C + c], k = 3w + {0,1,2} sum
+// over wave w's two rows of the tile / their first pixels / their last pixels, 12 / 13 first / last row of the tile, 14..17 corners (TL,
+// TR, BL, BR); tiles in row-major order.  Two steps, both in a fixed order: head_tail_tiles_reduce_kernel (grid (HT_SEG, planes)) adds up
+// a contiguous range of tiles into seg[(plane * HT_SEG + segment) * 9 * C + k * C + c] (doubles, the nine sums of head_tail_apply);
+// head_tail_tiles_finish_kernel adds the segments and applies the weights.
+constexpr int HT_SEG = 16;
+__global__ __launch_bounds__(256) void head_tail_tiles_reduce_kernel(const float *__restrict__ tsum, double *__restrict__ seg, int tiles_y,
+                                                                     int tiles_x, int C) {
+    __shared__ double red[9][256];
+    const int plane = blockIdx.y;
+    const int tid = threadIdx.x, c = tid % C, j0 = tid / C, nj = 256 / C;
+    const int ntiles = tiles_y * tiles_x;
+    const int per = (ntiles + HT_SEG - 1) / HT_SEG, t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    const float *tp = tsum + (int64_t)plane * ntiles * 18 * C + c;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = t0 + j0; t < t1; t += nj) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const float *q = tp + (int64_t)t * 18 * C;
+        const bool top = ty == 0, bot = ty == tiles_y - 1, lef = tx == 0, rig = tx == tiles_x - 1;
+        acc[0] += ((double)q[0] + (double)q[3 * C]) + ((double)q[6 * C] + (double)q[9 * C]);
+        if (top) acc[1] += (double)q[12 * C];
+        if (bot) acc[2] += (double)q[13 * C];
+        if (lef) acc[3] += ((double)q[1 * C] + (double)q[4 * C]) + ((double)q[7 * C] + (double)q[10 * C]);
+        if (rig) acc[4] += ((double)q[2 * C] + (double)q[5 * C]) + ((double)q[8 * C] + (double)q[11 * C]);
+        if (top && lef) acc[5] += (double)q[14 * C];
+        if (top && rig) acc[6] += (double)q[15 * C];
+        if (bot && lef) acc[7] += (double)q[16 * C];
+        if (bot && rig) acc[8] += (double)q[17 * C];
     }
+    for (int k = 0; k < 9; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    if (tid < C)
+        for (int k = 0; k < 9; ++k) {
+            double a = 0.0;
+            for (int j = 0; j < nj; ++j) a += red[k][j * C + tid];
+            seg[(((int64_t)plane * HT_SEG + blockIdx.x) * 9 + k) * C + tid] = a;
+        }
+}
+
+__global__ __launch_bounds__(64) void head_tail_tiles_finish_kernel(const double *__restrict__ seg, const float *__restrict__ w,
+                                                                    float *__restrict__ alpha, float *__restrict__ raw, int N, int H, int W, int C) {
+    __shared__ double sums[9][64];
+    const int plane = blockIdx.x, b = plane / N, n = plane % N, tid = threadIdx.x;
+    if (tid < C)
+        for (int k = 0; k < 9; ++k) {
+            double a = 0.0;
+            for (int sgi = 0; sgi < HT_SEG; ++sgi) a += seg[(((int64_t)plane * HT_SEG + sgi) * 9 + k) * C + tid];
+            sums[k][tid] = a;
+        }
+    __syncthreads();
+    if (tid < 3) head_tail_apply(sums, w, alpha, raw, b, n, N, (int64_t)H * W, C, tid);
+}
+
+int64_t head_tail_tiles_scratch_bytes(int B, int N, int C) { return (int64_t)B * N * HT_SEG * 9 * C * (int64_t)sizeof(double); }
+
+hipError_t launch_head_tail_tiles(const float *tsum, double *seg, int tiles_y, int tiles_x, const float *w, float *alpha, float *raw, int B,
+                                  int N, int H, int W, int C, hipStream_t s) {
+    if (C < 8 || C > 64 || 256 % C) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_tail_tiles_reduce_kernel, dim3(HT_SEG, B * N), dim3(256), 0, s, tsum, seg, tiles_y, tiles_x, C);
+    hipError_t h = hipGetLastError();
+    if (h != hipSuccess) return h;
+    hipLaunchKernelGGL(head_tail_tiles_finish_kernel, dim3(B * N), dim3(64), 0, s, seg, w, alpha, raw, N, H, W, C);
+    return hipGetLastError();
 }
 
 int head_tail_chunks(int B, int N, int64_t hw) {

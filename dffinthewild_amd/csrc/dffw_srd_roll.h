@@ -31,8 +31,10 @@ void srd_roll16_kernel_name(int prec, bool pool, char *buf, int n);
 // a stride-1 residual block of the alignment network (8 or 16 -> 16 channels, columns of 8 x 16 pixels): a.w0 = conv.0 as 3 (8
 // input channels: 4 taps per chunk) or 5 chunks, a.w2 = conv.2 as 5 chunks + 1 shortcut chunk (pack_conv); a.b0 / a.b2 their shifts
 constexpr int OF_CHUNKS_B = 6;
-hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s);
-void of_roll_kernel_name(int prec, bool cin8, char *buf, int n);
+// sums: the block's output is not stored, a.out receives per (slice, column) 18 fp32 16-channel vectors (per wave: sum / first column / last column of its
+// two rows; first / last row; four corners) for head_tail_finish_tiles (dffw_kernels.hip); 16 input channels only
+hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s, bool sums = false);
+void of_roll_kernel_name(int prec, bool cin8, char *buf, int n, bool sums = false);
 // ... and the 8 -> 8 channel blocks (pixel-pair form): a.w0 = conv.0 as 3 pair-form chunks, a.w2 = conv.2 as 3 chunks + 1 shortcut chunk
 hipError_t launch_of_roll8(int prec, const SrdArgs &a, hipStream_t s);
 void of_roll8_kernel_name(int prec, char *buf, int n);

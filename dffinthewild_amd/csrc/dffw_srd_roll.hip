@@ -910,7 +910,12 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
 // stages + a mostly empty third one).  Here, as in srd_roll16: x slices stream through an LDS FIFO, stage A leaves t in LDS,
 // stage B contracts t (5 chunks) plus ONE extra chunk for the 1x1x1 shortcut (the centre pixel of x, already in LDS) and stores
 // the block's output.  Slices are independent (no attention), so a step is A -> barrier -> B -> barrier.
-template <int PREC, bool CIN8>
+// SUMS (the pair of 16 -> 16 convs in the middle of the level-1 alignment head, whose result only feeds the head's last conv + plane
+// mean = plane sums, dffw_kernels.hip "alpha head tail"): the block's output is not stored; instead every (column, slice) leaves 18
+// 16-channel fp32 vectors in a.out (as float[(plane * tiles + tile) * 288 + k * 16 + c], plane = b * N + slice): k = 3w, 3w+1, 3w+2 the
+// sum over wave w's two rows of the 8 x 16 tile, over their first and over their last pixel; 12 / 13 the tile's first / last row;
+// 14..17 its corner pixels (top-left, top-right, bottom-left, bottom-right); head_tail_finish_tiles_kernel adds them up in a fixed order.
+template <int PREC, bool CIN8, bool SUMS = false>
 __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
@@ -1110,6 +1115,7 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // ---- stage B: out = relu(conv.2(t) + shift + shortcut(x)) -----------------------------------------------------------
+            f32x4 sum_t = {0.f, 0.f, 0.f, 0.f}, sum_c = sum_t;   // SUMS only
 #pragma unroll
             for (int j = 0; j < TB; ++j) {
                 f32x4 acc = tile_mma5(lds0 + T_OFF + pbo[j], tapB, TPLANEB, w2, b2, std::integral_constant<int, NCHB>{});
@@ -1126,16 +1132,48 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
                     }
                     acc = mma<F16>(w2[NCHB][0], sh, acc);
                 }
-                uint32_t h01, h23, l01, l23;
-                Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
-                Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
-                const int64_t pix = (((int64_t)U.b * a.N + s) * a.H + U.gy0 + wave * TB + j) * a.W + U.gx0 + r;
-                if constexpr (PARTS == 2) {
-                    swap16(h01, l01);
-                    swap16(h23, l23);
-                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                if constexpr (SUMS) {
+                    // this lane: channels 4g..4g+3 of pixel (row 2*wave + j, column r).  Row sums over the 16 lanes of the row group by
+                    // DPP (quad xor 1, xor 2, half-row mirror, row mirror: every lane ends up with the sum); lanes r = 0 / r = 15 are
+                    // the tile's first / last column.  Everything leaves straight from registers (16-byte stores of lanes r = 0 / 15).
+                    f32x4 v, rs;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = relu_bits(acc[i]);
+                        float t = v[i];
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x140, 0xF, 0xF, true));   // row_mirror
+                        rs[i] = t;
+                    }
+                    float *trec = reinterpret_cast<float *>(a.out) +
+                                  (((int64_t)U.b * a.N + s) * (a.tiles_y * a.tiles_x) + (U.gy0 / TY) * a.tiles_x + U.gx0 / TX) * (18 * C) + g * 4;
+                    if (j == 0) {
+                        sum_t = rs;
+                        sum_c = v;
+                        if (wave == 0 && r == 0) *reinterpret_cast<f32x4 *>(trec + 12 * C) = rs;          // first row of the tile
+                        if (wave == 0 && (r == 0 || r == 15)) *reinterpret_cast<f32x4 *>(trec + (r == 0 ? 14 : 15) * C) = v;   // TL, TR
+                    } else {
+                        sum_t += rs;
+                        sum_c += v;
+                        if (wave == NWAVES - 1 && r == 0) *reinterpret_cast<f32x4 *>(trec + 13 * C) = rs;  // last row
+                        if (wave == NWAVES - 1 && (r == 0 || r == 15)) *reinterpret_cast<f32x4 *>(trec + (r == 0 ? 16 : 17) * C) = v;   // BL, BR
+                        if (r == 0) *reinterpret_cast<f32x4 *>(trec + (wave * 3 + 0) * C) = sum_t;         // this wave's two rows
+                        if (r == 0 || r == 15) *reinterpret_cast<f32x4 *>(trec + (wave * 3 + (r == 0 ? 1 : 2)) * C) = sum_c;   // ... their first / last column
+                    }
                 } else {
-                    *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+                    uint32_t h01, h23, l01, l23;
+                    Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
+                    Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
+                    const int64_t pix = (((int64_t)U.b * a.N + s) * a.H + U.gy0 + wave * TB + j) * a.W + U.gx0 + r;
+                    if constexpr (PARTS == 2) {
+                        swap16(h01, l01);
+                        swap16(h23, l23);
+                        *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                    } else {
+                        *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+                    }
                 }
             }
             // (3) the x slot is free: queue the slice RX-1 ahead into it
@@ -1321,15 +1359,20 @@ hipError_t launch_of_roll8(int prec, const SrdArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-void of_roll_kernel_name(int prec, bool cin8, char *buf, int n) { snprintf(buf, n, "dffw::of_roll_kernel<%d, %s>", prec, cin8 ? "true" : "false"); }
+void of_roll_kernel_name(int prec, bool cin8, char *buf, int n, bool sums) {
+    if (sums) snprintf(buf, n, "dffw::of_roll_kernel<%d, %s, true>", prec, cin8 ? "true" : "false");
+    else snprintf(buf, n, "dffw::of_roll_kernel<%d, %s>", prec, cin8 ? "true" : "false");
+}
 
-hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s) {
+hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s, bool sums) {
     const int want = a.wgs > 0 ? a.wgs : (cin8 ? 768 : 512);
     const int per_xcd = (a.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    if (sums && cin8) return hipErrorInvalidValue;
 #define DFFW_OF_LAUNCH(P)                                                                   \
     do {                                                                                    \
-        if (cin8) hipLaunchKernelGGL((of_roll_kernel<P, true>), grid, block, 0, s, a);      \
+        if (sums) hipLaunchKernelGGL((of_roll_kernel<P, false, true>), grid, block, 0, s, a); \
+        else if (cin8) hipLaunchKernelGGL((of_roll_kernel<P, true>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((of_roll_kernel<P, false>), grid, block, 0, s, a);          \
     } while (0)
     switch (prec) {

@@ -174,7 +174,7 @@ def test_hip_e2e_batch_is_per_sample(lib_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_WARP_FILL"])
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_HEAD_SUMS_FUSED", "DFFW_WARP_FILL"])
 def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     """The gather kernel (no LDS tiles), the unsplit alignment heads (reference slice carried in every slice's volume
     instead of entering as a slice-broadcast residual), the unsplit few-tile launches and the heads' last conv + plane mean as
@@ -203,7 +203,7 @@ def _profiled_kernels(model, *inputs):
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
 def test_hip_e2e_warp_fill_first_head_conv(lib_built, monkeypatch, precision):
     """conv_tile's warp-fill variant (first conv of every alpha head samples the FOV-warped features while staging its tiles;
-    End_to_End.py:77-84 without the [cur | flow] volume) against the flow_volume + conv form (DFFW_NO_WARP_FILL) on a batch large
+    End_to_End.py:77-84 without the [cur | flow] volume; opt-in, DFFW_WARP_FILL=1) against the default flow_volume + conv form on a batch large
     enough that all three levels take the fused kernel: same helper, same operation order -> the head outputs agree to rounding
     noise of the two kernels' FMA contraction; the profile proves which kernels ran; default arithmetic also against the oracle."""
     g, sd, FS, fd, fov = load(GOLDEN[0])
@@ -213,6 +213,7 @@ def test_hip_e2e_warp_fill_first_head_conv(lib_built, monkeypatch, precision):
     fd = fd[:1].expand(B, -1, -1, -1).contiguous()
     fov = torch.cat([1.0 + (fov[:1] - 1.0) * k for k in (1.0, 0.5, 1.5, -0.7)], 0).contiguous()   # magnifying and shrinking warps
     tags = ["head3", "head2", "head1", "alpha"]
+    monkeypatch.setenv("DFFW_WARP_FILL", "1")
     m = _model(sd, precision)
     with torch.no_grad():
         outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
@@ -221,7 +222,7 @@ def test_hip_e2e_warp_fill_first_head_conv(lib_built, monkeypatch, precision):
     assert len(fused) == 3 and all(k.endswith("true>") for k in fused), fused
     vols = [k for k, layer in ran if layer.endswith(".volume")]
     assert len(vols) == 3
-    monkeypatch.setenv("DFFW_NO_WARP_FILL", "1")
+    monkeypatch.delenv("DFFW_WARP_FILL")
     m2 = _model(sd, precision)
     with torch.no_grad():
         outs2, taps2 = m2.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
@@ -242,7 +243,7 @@ def test_hip_e2e_warp_fill_first_head_conv(lib_built, monkeypatch, precision):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
-@pytest.mark.parametrize("B,H,W", [(1, 64, 96), (2, 128, 256), (3, 32, 32)])
+@pytest.mark.parametrize("B,H,W", [(1, 64, 96), (2, 128, 256), (3, 32, 32), (1, 256, 256)])
 def test_hip_e2e_head_tail_as_plane_sums(lib_built, monkeypatch, B, H, W, precision):
     """End_to_End.py:44-46: Conv3d(C,3,(1,3,3)) + AdaptiveAvgPool3d((10,1,1)) at the end of every alpha head = bias + weights x
     (plane sums minus border rows / columns plus corners) of the head's last activation volume (plane_sums_kernel +
@@ -271,6 +272,18 @@ def test_hip_e2e_head_tail_as_plane_sums(lib_built, monkeypatch, B, H, W, precis
         err = cpu_ref.rel_l2(t, taps2[tag].cpu().reshape(B, 3, 10))
         assert err <= tol, (tag, err)
     assert not torch.equal(taps["head1"], taps2["head1"])          # equal would mean both runs took the same path
+    if B * (H // 8) * (W // 16) >= 256:
+        # the level-1 head's conv pair then runs as of_roll_kernel<.., SUMS> (its output never stored): against the stored form + plane_sums
+        monkeypatch.delenv("DFFW_NO_HEAD_SUMS")
+        ran = [k for k, layer in _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda()) if layer.endswith("conv3.2.0+.4.0+.6+mean")]
+        assert len(ran) == 1 and ran[0].endswith("true>"), ran
+        monkeypatch.setenv("DFFW_NO_HEAD_SUMS_FUSED", "1")
+        with torch.no_grad():
+            outs3, taps3 = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+        for tag in tags:
+            err = cpu_ref.rel_l2(taps[tag].cpu(), taps3[tag].cpu())
+            assert err <= tol, (tag, err)
+        assert not torch.equal(taps["head1"], taps3["head1"])
     if precision == "bf16x3":
         with torch.no_grad():
             ref = cpu_ref.e2e_forward(cpu_ref.to_torch_state(sd), FS, fd, fov)
