@@ -1058,7 +1058,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(WARP_FILL) X(NO_HEAD_SUMS_FUSED)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(WARP_FILL) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -2270,14 +2270,18 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             // for all N slices of a sample, so it runs once per sample (1/N of the work, no ref channels in the volume) and
             // enters the per-slice conv over [cur | flow] as a slice-broadcast residual in front of the ReLU
             Act refw = r.act(B, 1, fe.H, fe.W, fe.C);
-            // [cur | flow] is not materialised when the per-slice conv has a warp-fill kernel for this shape: it samples the warped
-            // features while staging its tiles (conv_tile's WARP variant)
-            // (opt-in, DFFW_WARP_FILL=1: measured slower than flow_volume + LDS-DMA fill -- 1.64 vs 0.85 + 0.93 ms at level 1 -- the
-            // gathers of a tile are one dependent latency chain per workgroup at two workgroups per CU)
-            const bool fused = r.warp_conv_ok(hp + ".0.0#cur", B, N, fe.H, fe.W) && r.sw.on(SW_WARP_FILL);
+            // [cur | flow] is not materialised when a kernel samples the warped features while staging its tiles: head_warp_kernel
+            // (8-channel level at full resolution, whole 8 x 16 columns) or conv_tile's warp-fill variant (opt-in, DFFW_WARP_FILL=1:
+            // measured slower than flow_volume + LDS-DMA fill -- 1.64 vs 0.85 + 0.93 ms at level 1 -- the gathers of a tile are one
+            // dependent latency chain per workgroup at two workgroups per CU)
+            auto ccur = r.e->convs.find(hp + ".0.0#cur");
+            const bool roll = fe.C == 8 && ccur != r.e->convs.end() && ccur->second.wsrd && ccur->second.def.cin == 10 && ccur->second.def.cout == 16 && fe.H % 8 == 0 &&
+                              fe.W % 16 == 0 && (int64_t)B * (fe.H / 8) * (fe.W / 16) >= 256 && !r.sw.on(SW_NO_HEAD_WARP) && !r.sw.on(SW_NO_TILE);
+            const bool fused = !roll && r.warp_conv_ok(hp + ".0.0#cur", B, N, fe.H, fe.W) && r.sw.on(SW_WARP_FILL);
             Act vol;
             WarpSrc *wsrc = nullptr;
-            if (fused) {
+            if (roll) {
+            } else if (fused) {
                 vol.B = B; vol.N = N; vol.H = fe.H; vol.W = fe.W; vol.C = fe.C + 8;
                 wsrc = (WarpSrc *)r.raw(sizeof(WarpSrc));
             } else {
@@ -2285,9 +2289,10 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             }
             if (r.ok() && !r.dry) {
                 r.prof_begin(kn, std::string("flow") + lv.head + ".volume", 0.0,
-                             ((double)(fused ? 0 : fe.pixels()) * (2.0 * fe.C + 8) + (double)refw.pixels() * 2.0 * fe.C) * r.elem_bytes());
+                             ((double)(fused || roll ? 0 : fe.pixels()) * (2.0 * fe.C + 8) + (double)refw.pixels() * 2.0 * fe.C) * r.elem_bytes());
                 r.check(launch_flow_volume(prec, fe.p, refw.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 2, r.s), "flow_volume ref");
-                if (fused) {
+                if (roll) {
+                } else if (fused) {
                     WarpSrc ws;
                     ws.fe = fe.p; ws.alpha = alpha; ws.fov = fov; ws.C = fe.C; ws.pad = 0;
                     r.check(launch_set_warp(ws, wsrc, r.s), "set_warp");
@@ -2296,7 +2301,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
                 }
                 r.prof_end();
             }
-            if (!fused) r.drop(fe);
+            if (!fused && !roll) r.drop(fe);
             // per-slice conv: the B reference slices are presented as the B slices of ONE sample so that the 5-slice tiles
             // are filled (same memory either way)
             Act refw1 = refw;
@@ -2304,16 +2309,39 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             Act refpart = r.conv(hp + ".0.0#ref", refw1);
             refpart.B = B; refpart.N = 1;
             r.drop(refw);
-            ConvOpt oc = rl;
-            oc.res0 = &refpart;
-            oc.res_bcast = true;
-            oc.warp = wsrc;
-            y0 = r.conv(hp + ".0.0#cur", vol, oc);
-            if (fused) {
+            if (roll) {
+                y0 = r.act(B, N, fe.H, fe.W, 16);
+                if (r.ok() && !r.dry) {
+                    HeadWarpArgs ha;
+                    memset(&ha, 0, sizeof ha);
+                    ha.fe = fe.p; ha.ref = refpart.p; ha.out = y0.p;
+                    ha.w = ccur->second.wsrd; ha.bias = ccur->second.bias;
+                    ha.alpha = alpha; ha.fov = fov;
+                    ha.B = B; ha.N = N; ha.H = fe.H; ha.W = fe.W;
+                    ha.tiles_y = fe.H / 8; ha.tiles_x = fe.W / 16;
+                    ha.total_tiles = B * ha.tiles_y * ha.tiles_x;
+                    ha.wgs = r.sw.srd_wgs;
+                    char knw[64];
+                    head_warp_kernel_name(prec, knw, sizeof knw);
+                    g_last_kernel = knw;
+                    const double px = (double)fe.pixels();
+                    r.prof_begin(knw, hp + ".0.0#cur", 2.0 * px * 9.0 * 10 * 16, px * 24 * r.elem_bytes() + (double)refpart.pixels() * 16 * r.elem_bytes());
+                    r.check(launch_head_warp(prec, ha, r.s), "head_warp");
+                    r.prof_end();
+                }
                 r.drop(fe);
-                r.drop_raw(wsrc);
             } else {
-                r.drop(vol);
+                ConvOpt oc = rl;
+                oc.res0 = &refpart;
+                oc.res_bcast = true;
+                oc.warp = wsrc;
+                y0 = r.conv(hp + ".0.0#cur", vol, oc);
+                if (fused) {
+                    r.drop(fe);
+                    r.drop_raw(wsrc);
+                } else {
+                    r.drop(vol);
+                }
             }
             r.drop(refpart);
         } else {

@@ -1185,6 +1185,205 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- head_warp: the first conv of the level-1 alignment head on the FOV-warped features, without the warped volume ---------------
+// (End_to_End.py:96-101: FE1 = FOV_warp(FE1, alpha); conv3.0 over [ref | cur | flow]; the ref part enters as `ref`, see run_e2e)
+//     y0[b,n] = relu( BN(conv1x3x3([warp(fe)[b,n] (8) | flow_x, flow_y])) + ref[b] )          8 + 2 -> 16 channels, full resolution
+// As two launches flow_volume wrote the 16-channel volume [cur | flow | pad] (1.6 GB at 8 x 10 x 480 x 640) and the conv read it
+// back.  Here a workgroup walks the slices of a column of 8 x 16 output pixels: thread p < 180 owns pixel p of the 10 x 18 footprint,
+// gathers its four bilinear corners (hi and lo piece each) ONE STEP AHEAD into registers -- the loads of slice s+1 travel under the
+// contraction and the stores of slice s -- blends them with the operation order of flow_volume_kernel (warp_octet), splits to the
+// storage format and writes the record [8 channels | flow_x flow_y 0..] into one of two LDS slots; the contraction (wave w = output
+// rows 2w, 2w+1; 5 chunks, K octet g of chunk k = (tap 2k + (g >> 1), channel octet g & 1) = srd_roll16's filter order, resident in
+// LDS) and the epilogue (+ ref, held in registers for all slices of the column, ReLU, split, 16-byte stores) follow after one
+// barrier.  Plain loads only (no LDS-DMA), so hipcc counts every wait itself.
+template <int PREC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void head_warp_kernel(const HeadWarpArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int CF = 8, C = 16, TY = 8, TX = 16, XY = TY + 2, XX = TX + 2, XPIX = XY * XX;
+    constexpr int PIXB = 32, PLANEB = XPIX * PIXB, SLOTB = PARTS * PLANEB;
+    constexpr int NCH = 5, TB = 2;
+    constexpr int W_OFF = 2 * SLOTB, WB = NCH * PARTS * 1024;      // the filter: NCH chunks x parts x 64 lanes x 16 bytes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W_OFF + WB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+    const int rec = PARTS * C, frec = PARTS * CF;
+
+    // ---- gather side: thread t < 180 owns footprint pixel t -------------------------------------------------------
+    const bool gth = tid < XPIX;
+    const int fy = tid / XX, fx = tid - fy * XX;
+    uint4 q[4][PARTS];          // corner k: [hi, lo]
+    float wgt[4], flx = 0.f, fly = 0.f;
+    bool pin = false;
+    auto issue = [&](const Unit &U, int n) {
+        const int iy = U.gy0 - 1 + fy, ix = U.gx0 - 1 + fx;
+        pin = gth && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        if (!pin) return;
+        const int ai = U.b * 3 * a.N + n;
+        const float f = a.alpha[ai] + a.fov[U.b * a.N + n];
+        const WarpPoint wp = warp_point(ix, iy, a.H, a.W, f, a.alpha[ai + a.N], a.alpha[ai + 2 * a.N]);
+        flx = wp.fx;
+        fly = wp.fy;
+        const float x0f = floorf(wp.sx), y0f = floorf(wp.sy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float wx1 = wp.sx - x0f, wy1 = wp.sy - y0f;
+        const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1};
+        const uint16_t *slice = a.fe + ((int64_t)(U.b * a.N + n) * a.H * a.W) * frec;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yc = y0 + (k >> 1), xc = x0 + (k & 1);
+            const bool ok = (unsigned)yc < (unsigned)a.H && (unsigned)xc < (unsigned)a.W;
+            wgt[k] = ok ? wx[k & 1] * wy[k >> 1] : 0.f;
+            const uint16_t *rp = slice + (ok ? (yc * a.W + xc) * frec : 0);
+#pragma unroll
+            for (int i = 0; i < PARTS; ++i) q[k][i] = *reinterpret_cast<const uint4 *>(rp + i * CF);
+        }
+    };
+    auto land = [&](int slot) {     // blend the corners requested by the last issue(), write the pixel's record
+        if (!gth) return;
+        unsigned char *dst = smem + slot * SLOTB + tid * PIXB;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pin) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (wgt[k] == 0.f) continue;      // corner outside the image (or weight exactly 0): skipped, as warp_octet skips it
+                const uint4 h = q[k][0];
+                uint4 l = make_uint4(0, 0, 0, 0);
+                if constexpr (PARTS == 2) l = q[k][1];
+                float x, y;
+                Fmt<PREC>::join2(h.x, l.x, x, y); v[0] += x * wgt[k]; v[1] += y * wgt[k];
+                Fmt<PREC>::join2(h.y, l.y, x, y); v[2] += x * wgt[k]; v[3] += y * wgt[k];
+                Fmt<PREC>::join2(h.z, l.z, x, y); v[4] += x * wgt[k]; v[5] += y * wgt[k];
+                Fmt<PREC>::join2(h.w, l.w, x, y); v[6] += x * wgt[k]; v[7] += y * wgt[k];
+            }
+        }
+        uint4 h, l;
+        Fmt<PREC>::split2(v[0], v[1], h.x, l.x);
+        Fmt<PREC>::split2(v[2], v[3], h.y, l.y);
+        Fmt<PREC>::split2(v[4], v[5], h.z, l.z);
+        Fmt<PREC>::split2(v[6], v[7], h.w, l.w);
+        uint4 fh = make_uint4(0, 0, 0, 0), fl = fh;
+        if (pin) Fmt<PREC>::split2(flx, fly, fh.x, fl.x);
+        *reinterpret_cast<uint4 *>(dst) = h;
+        *reinterpret_cast<uint4 *>(dst + 16) = fh;
+        if constexpr (PARTS == 2) {
+            *reinterpret_cast<uint4 *>(dst + PLANEB) = l;
+            *reinterpret_cast<uint4 *>(dst + PLANEB + 16) = fl;
+        }
+    };
+
+    // ---- contraction side ----------------------------------------------------------------------------------------
+    int pofs[TB], tapo[NCH];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) pofs[j] = ((wave * TB + j) * XX + r) * PIXB + (g & 1) * 16;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int tap = 2 * k + (g >> 1);
+        tapo[k] = tap < 9 ? ((tap / 3) * XX + tap % 3) * PIXB : 0;     // (taps >= 9 carry zero weights)
+    }
+    for (int i = tid; i < WB / 16; i += 256) reinterpret_cast<uint4 *>(smem + W_OFF)[i] = reinterpret_cast<const uint4 *>(a.w)[i];
+    const unsigned char *wl = smem + W_OFF + lane * 16;
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+
+    Unit U = decode(ufirst);
+    issue(U, 0);
+    int slot = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        // the reference part of this column: 4 channels of the lane's two output pixels, added in front of the ReLU of every slice
+        f32x4 rv[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const uint16_t *rp = a.ref + (((int64_t)U.b * a.H + U.gy0 + wave * TB + j) * a.W + U.gx0 + r) * rec + g * 4;
+            const uint2 h = *reinterpret_cast<const uint2 *>(rp);
+            uint2 l = make_uint2(0, 0);
+            if constexpr (PARTS == 2) l = *reinterpret_cast<const uint2 *>(rp + C);
+            float r0, r1, r2, r3;
+            Fmt<PREC>::join2(h.x, l.x, r0, r1);
+            Fmt<PREC>::join2(h.y, l.y, r2, r3);
+            rv[j] = f32x4{r0, r1, r2, r3} + b0;
+        }
+        const Unit Ucur = U;
+        for (int s = 0; s < a.N; ++s) {
+            land(slot);
+            __builtin_amdgcn_sched_barrier(0);
+            // next step's corners: the following slice of this column, or the first slice of the workgroup's next column
+            const bool more = s + 1 < a.N || cu + wgs_per_xcd < uend;
+            if (s + 1 == a.N && more) U = decode(cu + wgs_per_xcd);
+            if (more) issue(U, s + 1 < a.N ? s + 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            const unsigned char *xs = smem + slot * SLOTB;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                f32x4 acc = rv[j];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const short8 xh = *reinterpret_cast<const short8 *>(xs + pofs[j] + tapo[k]);
+                    const short8 wh = *reinterpret_cast<const short8 *>(wl + (k * PARTS) * 1024);
+                    if constexpr (PARTS == 2) {
+                        const short8 xl = *reinterpret_cast<const short8 *>(xs + PLANEB + pofs[j] + tapo[k]);
+                        const short8 wlo = *reinterpret_cast<const short8 *>(wl + (k * PARTS + 1) * 1024);
+                        acc = mma<F16>(wlo, xh, acc);
+                        acc = mma<F16>(wh, xl, acc);
+                    }
+                    acc = mma<F16>(wh, xh, acc);
+                    if (k == 2) __builtin_amdgcn_sched_barrier(0);   // (all ten fragments of both tiles in flight: 194 registers, two workgroups per CU)
+                }
+                uint32_t h01, h23, l01, l23;
+                Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
+                Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
+                const int64_t pix = (((int64_t)Ucur.b * a.N + s) * a.H + Ucur.gy0 + wave * TB + j) * a.W + Ucur.gx0 + r;
+                if constexpr (PARTS == 2) {
+                    swap16(h01, l01);
+                    swap16(h23, l23);
+                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot ^= 1;
+        }
+    }
+}
+
+void head_warp_kernel_name(int prec, char *buf, int n) { snprintf(buf, n, "dffw::head_warp_kernel<%d>", prec); }
+
+hipError_t launch_head_warp(int prec, const HeadWarpArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : 1024;
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    switch (prec) {
+        case P_BF16X3: hipLaunchKernelGGL((head_warp_kernel<P_BF16X3>), grid, block, 0, s, a); break;
+        case P_FP16: hipLaunchKernelGGL((head_warp_kernel<P_FP16>), grid, block, 0, s, a); break;
+        case P_BF16: hipLaunchKernelGGL((head_warp_kernel<P_BF16>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ---- srd_attention_mfma: the attention tail of the 32-channel SRD block (`FM_conv2.1.N_ch_attention`) on the matrix cores ------
 //     out = feat + relu(conv1x1x1(relu(conv3x1x1(feat))))     (DEN.py:322-329; no BatchNorm, no bias)
 // The fused VALU kernel (srd_attention_kernel) stops at 16 channels (C*C*4 FMAs per pixel); at 32 channels the two convs ran as

@@ -174,7 +174,7 @@ def test_hip_e2e_batch_is_per_sample(lib_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_HEAD_SUMS_FUSED", "DFFW_WARP_FILL"])
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_HEAD_SUMS_FUSED", "DFFW_WARP_FILL", "DFFW_NO_HEAD_WARP"])
 def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     """The gather kernel (no LDS tiles), the unsplit alignment heads (reference slice carried in every slice's volume
     instead of entering as a slice-broadcast residual), the unsplit few-tile launches and the heads' last conv + plane mean as
@@ -201,6 +201,44 @@ def _profiled_kernels(model, *inputs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 96, 224)])
+def test_hip_e2e_head_warp_streaming_kernel(lib_built, monkeypatch, B, H, W, precision):
+    """head_warp_kernel (dffw_srd_roll.hip): the level-1 head's first conv over [warp(fe) | flow] with the bilinear gather done one
+    slice ahead while staging (End_to_End.py:96-101 without the warped volume) against flow_volume + conv_tile (DFFW_NO_HEAD_WARP):
+    magnifying, shrinking and out-of-image warps, columns on every image border; the profile proves which kernel ran; default
+    arithmetic also against the oracle."""
+    g, sd, FS, fd, fov = load(GOLDEN[0])
+    from dffinthewild_amd import synth
+    FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=29))
+    fd = fd[:1].expand(B, -1, -1, -1).contiguous()
+    fov = torch.cat([1.0 + (fov[:1] - 1.0) * k for k in (1.0, -2.5, 4.0)][:B], 0).contiguous()
+    tags = ["head3", "head2", "head1", "alpha"]
+    m = _model(sd, precision)
+    with torch.no_grad():
+        outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+    ran = [k for k, layer in _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda()) if layer.endswith(".0.0#cur")]
+    assert len(ran) == 3 and ran[2].startswith("dffw::head_warp_kernel"), ran
+    monkeypatch.setenv("DFFW_NO_HEAD_WARP", "1")
+    m2 = _model(sd, precision)
+    with torch.no_grad():
+        outs2, taps2 = m2.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+    ran2 = [k for k, layer in _profiled_kernels(m2, FS.cuda(), fd.cuda(), fov.cuda()) if layer.endswith(".0.0#cur")]
+    assert all(k.startswith("dffw::conv_tile") for k in ran2), ran2
+    tol = {"bf16x3": 2e-6, "fp16": 1e-3, "bf16": 1e-2}[precision]
+    for tag in tags:
+        err = cpu_ref.rel_l2(taps[tag].cpu(), taps2[tag].cpu())
+        assert err <= tol, (tag, err)
+    for name, a, b in zip(OUT_NAMES, outs, outs2):
+        assert cpu_ref.rel_l2(a.cpu(), b.cpu()) <= 50 * tol, name
+    if precision == "bf16x3":
+        with torch.no_grad():
+            ref = cpu_ref.e2e_forward(cpu_ref.to_torch_state(sd), FS[:1], fd[:1], fov[:1])
+        for name, o, r in zip(OUT_NAMES, outs, ref):
+            assert cpu_ref.rel_l2(o[:1].cpu(), r) <= 1e-3, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
 def test_hip_e2e_warp_fill_first_head_conv(lib_built, monkeypatch, precision):
     """conv_tile's warp-fill variant (first conv of every alpha head samples the FOV-warped features while staging its tiles;
     End_to_End.py:77-84 without the [cur | flow] volume; opt-in, DFFW_WARP_FILL=1) against the default flow_volume + conv form on a batch large
@@ -214,6 +252,7 @@ def test_hip_e2e_warp_fill_first_head_conv(lib_built, monkeypatch, precision):
     fov = torch.cat([1.0 + (fov[:1] - 1.0) * k for k in (1.0, 0.5, 1.5, -0.7)], 0).contiguous()   # magnifying and shrinking warps
     tags = ["head3", "head2", "head1", "alpha"]
     monkeypatch.setenv("DFFW_WARP_FILL", "1")
+    monkeypatch.setenv("DFFW_NO_HEAD_WARP", "1")         # (the level-1 head would otherwise take head_warp_kernel)
     m = _model(sd, precision)
     with torch.no_grad():
         outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
