@@ -802,6 +802,27 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    // ---- head_warp<CF = 16>: the [cur (16) | flow (2)] part of the level-2 alignment head's first conv, 32 output channels: chunk k,
+    // K octet g = o = 4k + g -> (filter tap o / 3, channel octet o % 3) of the 24-channel records the kernel builds in LDS
+    if (geo == G2S1 && L.cin == 18 && cin_pad == 24 && L.cout == 32 && !shortcut_w) {
+        constexpr int NCHW = head_warp_chunks(16);
+        std::vector<uint16_t> wr((size_t)NCHW * 2 * parts * 512, 0);
+        for (int c = 0; c < NCHW; ++c)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nt * 16 + (lane & 15), o = 4 * c + (lane >> 4), tap = o / 3, oct = o % 3;
+                        float val = 0.f;
+                        if (o < 27) val = (float)wval(co, oct * 8 + j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)c * 2 + nt) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        if (parts == 2) wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     // ---- srd_roll16: the per-slice 1x3x3 16 -> 16 convs: chunk k, K octet g = (filter tap 2k + (g >> 1), channel octet g & 1)
     // (packed with a sixth, all-zero chunk: the same buffer then serves as the second conv of of_roll_kernel, whose shortcut chunk
     // it leaves empty, for plain conv -> conv chains such as the alignment heads' .2.0 -> .4.0)
@@ -2271,11 +2292,12 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             // enters the per-slice conv over [cur | flow] as a slice-broadcast residual in front of the ReLU
             Act refw = r.act(B, 1, fe.H, fe.W, fe.C);
             // [cur | flow] is not materialised when a kernel samples the warped features while staging its tiles: head_warp_kernel
-            // (8-channel level at full resolution, whole 8 x 16 columns) or conv_tile's warp-fill variant (opt-in, DFFW_WARP_FILL=1:
+            // (8- and 16-channel levels, whole 8 x 16 columns) or conv_tile's warp-fill variant (opt-in, DFFW_WARP_FILL=1:
             // measured slower than flow_volume + LDS-DMA fill -- 1.64 vs 0.85 + 0.93 ms at level 1 -- the gathers of a tile are one
             // dependent latency chain per workgroup at two workgroups per CU)
             auto ccur = r.e->convs.find(hp + ".0.0#cur");
-            const bool roll = fe.C == 8 && ccur != r.e->convs.end() && ccur->second.wsrd && ccur->second.def.cin == 10 && ccur->second.def.cout == 16 && fe.H % 8 == 0 &&
+            const bool roll = (fe.C == 8 || fe.C == 16) && ccur != r.e->convs.end() && ccur->second.wsrd && ccur->second.def.cin == fe.C + 2 &&
+                              ccur->second.def.cout == 2 * fe.C && fe.H % 8 == 0 &&
                               fe.W % 16 == 0 && (int64_t)B * (fe.H / 8) * (fe.W / 16) >= 256 && !r.sw.on(SW_NO_HEAD_WARP) && !r.sw.on(SW_NO_TILE);
             const bool fused = !roll && r.warp_conv_ok(hp + ".0.0#cur", B, N, fe.H, fe.W) && r.sw.on(SW_WARP_FILL);
             Act vol;
@@ -2310,7 +2332,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             refpart.B = B; refpart.N = 1;
             r.drop(refw);
             if (roll) {
-                y0 = r.act(B, N, fe.H, fe.W, 16);
+                y0 = r.act(B, N, fe.H, fe.W, 2 * fe.C);
                 if (r.ok() && !r.dry) {
                     HeadWarpArgs ha;
                     memset(&ha, 0, sizeof ha);
@@ -2322,11 +2344,11 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
                     ha.total_tiles = B * ha.tiles_y * ha.tiles_x;
                     ha.wgs = r.sw.srd_wgs;
                     char knw[64];
-                    head_warp_kernel_name(prec, knw, sizeof knw);
+                    head_warp_kernel_name(prec, fe.C, knw, sizeof knw);
                     g_last_kernel = knw;
                     const double px = (double)fe.pixels();
-                    r.prof_begin(knw, hp + ".0.0#cur", 2.0 * px * 9.0 * 10 * 16, px * 24 * r.elem_bytes() + (double)refpart.pixels() * 16 * r.elem_bytes());
-                    r.check(launch_head_warp(prec, ha, r.s), "head_warp");
+                    r.prof_begin(knw, hp + ".0.0#cur", 2.0 * px * 9.0 * (fe.C + 2) * 2 * fe.C, (px * 3 + (double)refpart.pixels() * 2) * fe.C * r.elem_bytes());
+                    r.check(launch_head_warp(prec, fe.C, ha, r.s), "head_warp");
                     r.prof_end();
                 }
                 r.drop(fe);

@@ -35,20 +35,24 @@ constexpr int OF_CHUNKS_B = 6;
 // two rows; first / last row; four corners) for head_tail_finish_tiles (dffw_kernels.hip); 16 input channels only
 hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s, bool sums = false);
 void of_roll_kernel_name(int prec, bool cin8, char *buf, int n, bool sums = false);
-// head_warp: first conv of the level-1 alignment head over the FOV-warped 8-channel features (+ flow), warp done while staging
+// head_warp: first conv of the level-1 / level-2 alignment head over the FOV-warped CF-channel features (+ flow), CF = 8 / 16, the warp
+// done while staging
 struct HeadWarpArgs {
-    const uint16_t *fe;       // level features (B,N,H,W,8) in storage format
-    const uint16_t *ref;      // reference part (B,1,H,W,16): conv#ref of the warped reference slice (BatchNorm scale, no shift)
-    uint16_t *out;            // (B,N,H,W,16)
-    const uint16_t *w;        // the [cur (8) | flow (2)] filter in srd_roll16's order (5 chunks [part][64 lanes][8], pack_conv)
-    const float *bias;        // BatchNorm shift (16 floats)
+    const uint16_t *fe;       // level features (B,N,H,W,CF) in storage format
+    const uint16_t *ref;      // reference part (B,1,H,W,2 CF): conv#ref of the warped reference slice (BatchNorm scale, no shift)
+    uint16_t *out;            // (B,N,H,W,2 CF)
+    const uint16_t *w;        // the [cur (CF) | flow (2)] filter as head_warp_chunks(CF) chunks [output tile][part][64 lanes][8]: K octet g of
+                              // chunk k = o = 4k + g -> (tap o / OCT, channel octet o % OCT), OCT = CF / 8 + 1 (pack_conv; for CF = 8 this
+                              // is srd_roll16's order)
+    const float *bias;        // BatchNorm shift (2 CF floats)
     const float *alpha, *fov; // warp parameters so far (B,3,N), fields of view (B,N)
     int B, N, H, W;
     int tiles_y, tiles_x, total_tiles;   // 8 x 16 columns
-    int wgs;                  // workgroups to launch (0: four per CU)
+    int wgs;                  // workgroups to launch (0: default)
 };
-hipError_t launch_head_warp(int prec, const HeadWarpArgs &a, hipStream_t s);
-void head_warp_kernel_name(int prec, char *buf, int n);
+constexpr int head_warp_chunks(int cf) { return (9 * (cf / 8 + 1) + 3) / 4; }
+hipError_t launch_head_warp(int prec, int cf, const HeadWarpArgs &a, hipStream_t s);
+void head_warp_kernel_name(int prec, int cf, char *buf, int n);
 // ... and the 8 -> 8 channel blocks (pixel-pair form): a.w0 = conv.0 as 3 pair-form chunks, a.w2 = conv.2 as 3 chunks + 1 shortcut chunk
 hipError_t launch_of_roll8(int prec, const SrdArgs &a, hipStream_t s);
 void of_roll8_kernel_name(int prec, char *buf, int n);

@@ -1185,25 +1185,29 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---- head_warp: the first conv of the level-1 alignment head on the FOV-warped features, without the warped volume ---------------
-// (End_to_End.py:96-101: FE1 = FOV_warp(FE1, alpha); conv3.0 over [ref | cur | flow]; the ref part enters as `ref`, see run_e2e)
-//     y0[b,n] = relu( BN(conv1x3x3([warp(fe)[b,n] (8) | flow_x, flow_y])) + ref[b] )          8 + 2 -> 16 channels, full resolution
-// As two launches flow_volume wrote the 16-channel volume [cur | flow | pad] (1.6 GB at 8 x 10 x 480 x 640) and the conv read it
-// back.  Here a workgroup walks the slices of a column of 8 x 16 output pixels: thread p < 180 owns pixel p of the 10 x 18 footprint,
-// gathers its four bilinear corners (hi and lo piece each) ONE STEP AHEAD into registers -- the loads of slice s+1 travel under the
-// contraction and the stores of slice s -- blends them with the operation order of flow_volume_kernel (warp_octet), splits to the
-// storage format and writes the record [8 channels | flow_x flow_y 0..] into one of two LDS slots; the contraction (wave w = output
-// rows 2w, 2w+1; 5 chunks, K octet g of chunk k = (tap 2k + (g >> 1), channel octet g & 1) = srd_roll16's filter order, resident in
-// LDS) and the epilogue (+ ref, held in registers for all slices of the column, ReLU, split, 16-byte stores) follow after one
-// barrier.  Plain loads only (no LDS-DMA), so hipcc counts every wait itself.
-template <int PREC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void head_warp_kernel(const HeadWarpArgs a) {
+// ---- head_warp: the first conv of an alignment head on the FOV-warped features, without the warped volume -------------------------
+// (End_to_End.py:88-101: FE = FOV_warp(FE, alpha); conv over [ref | cur | flow]; the ref part enters as `ref`, see run_e2e)
+//     y0[b,n] = relu( BN(conv1x3x3([warp(fe)[b,n] (CF) | flow_x, flow_y])) + ref[b] )       CF + 2 -> 2 CF channels
+// CF = 8: level 1 (full resolution), CF = 16: level 2 (half resolution).  As two launches flow_volume wrote the volume
+// [cur | flow | pad] (1.6 GB at 8 x 10 x 480 x 640 for level 1) and the conv read it back.  Here a workgroup walks the slices of a
+// column of 8 x 16 output pixels: every channel octet of every pixel of the 10 x 18 footprint has its thread, which gathers the four
+// bilinear corners (hi and lo piece each) ONE STEP AHEAD into registers -- the loads of slice s+1 travel under the contraction and
+// the stores of slice s -- blends them with the operation order of flow_volume_kernel (warp_octet), splits to the storage format and
+// writes its octet of the record [CF channels | flow_x flow_y 0..] into one of two LDS slots; the contraction (CF = 8: 4 waves, wave
+// w = output rows 2w, 2w+1; CF = 16: 8 waves, wave w = row w, two 16-channel output tiles; K octet g of chunk k = o = 4k + g ->
+// (tap o / OCT, channel octet o % OCT), OCT = CF / 8 + 1; filter resident in LDS) and the epilogue (+ ref, held in registers for all
+// slices of the column, ReLU, split, 16-byte stores) follow after one barrier.  Plain loads only (no LDS-DMA): hipcc counts every wait.
+template <int PREC, int CF>
+__global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_per_eu(4))) void head_warp_kernel(const HeadWarpArgs a) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
-    constexpr int CF = 8, C = 16, TY = 8, TX = 16, XY = TY + 2, XX = TX + 2, XPIX = XY * XX;
-    constexpr int PIXB = 32, PLANEB = XPIX * PIXB, SLOTB = PARTS * PLANEB;
-    constexpr int NCH = 5, TB = 2;
-    constexpr int W_OFF = 2 * SLOTB, WB = NCH * PARTS * 1024;      // the filter: NCH chunks x parts x 64 lanes x 16 bytes
+    constexpr int GO = CF / 8, OCT = GO + 1, NT = CF / 8, C = 16 * NT;
+    constexpr int NWAVES = CF == 8 ? 4 : 8, NTHR = NWAVES * 64;
+    constexpr int TY = 8, TX = 16, XY = TY + 2, XX = TX + 2, XPIX = XY * XX;
+    constexpr int PIXB = OCT * 16, PLANEB = XPIX * PIXB, SLOTB = PARTS * PLANEB;
+    constexpr int NCH = (9 * OCT + 3) / 4, TB = TY / NWAVES;
+    constexpr int W_OFF = 2 * SLOTB, WB = NCH * NT * PARTS * 1024;   // the filter: [chunk][output tile][part][64 lanes][16 bytes]
+    static_assert(XPIX * GO <= NTHR, "one gather item per thread");
     __shared__ __attribute__((aligned(16))) unsigned char smem[W_OFF + WB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1230,10 +1234,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void h
         return c;
     };
     const int rec = PARTS * C, frec = PARTS * CF;
+    for (int i = tid; i < WB / 16; i += NTHR) reinterpret_cast<uint4 *>(smem + W_OFF)[i] = reinterpret_cast<const uint4 *>(a.w)[i];
 
-    // ---- gather side: thread t < 180 owns footprint pixel t -------------------------------------------------------
-    const bool gth = tid < XPIX;
-    const int fy = tid / XX, fx = tid - fy * XX;
+    // ---- gather side: thread t < 180 * GO owns channel octet t / 180 of footprint pixel t % 180 ---------------------
+    const bool gth = tid < XPIX * GO;
+    const int goct = GO == 1 ? 0 : tid / XPIX, gp = tid - goct * XPIX;
+    const int fy = gp / XX, fx = gp - fy * XX;
     uint4 q[4][PARTS];          // corner k: [hi, lo]
     float wgt[4], flx = 0.f, fly = 0.f;
     bool pin = false;
@@ -1250,7 +1256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void h
         const int x0 = (int)x0f, y0 = (int)y0f;
         const float wx1 = wp.sx - x0f, wy1 = wp.sy - y0f;
         const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1};
-        const uint16_t *slice = a.fe + ((int64_t)(U.b * a.N + n) * a.H * a.W) * frec;
+        const uint16_t *slice = a.fe + ((int64_t)(U.b * a.N + n) * a.H * a.W) * frec + goct * 8;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int yc = y0 + (k >> 1), xc = x0 + (k & 1);
@@ -1261,9 +1267,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void h
             for (int i = 0; i < PARTS; ++i) q[k][i] = *reinterpret_cast<const uint4 *>(rp + i * CF);
         }
     };
-    auto land = [&](int slot) {     // blend the corners requested by the last issue(), write the pixel's record
+    auto land = [&](int slot) {     // blend the corners requested by the last issue(), write the octet (octet-0 threads: also the flow record)
         if (!gth) return;
-        unsigned char *dst = smem + slot * SLOTB + tid * PIXB;
+        unsigned char *dst = smem + slot * SLOTB + gp * PIXB;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (pin) {
 #pragma unroll
@@ -1284,46 +1290,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void h
         Fmt<PREC>::split2(v[2], v[3], h.y, l.y);
         Fmt<PREC>::split2(v[4], v[5], h.z, l.z);
         Fmt<PREC>::split2(v[6], v[7], h.w, l.w);
-        uint4 fh = make_uint4(0, 0, 0, 0), fl = fh;
-        if (pin) Fmt<PREC>::split2(flx, fly, fh.x, fl.x);
-        *reinterpret_cast<uint4 *>(dst) = h;
-        *reinterpret_cast<uint4 *>(dst + 16) = fh;
-        if constexpr (PARTS == 2) {
-            *reinterpret_cast<uint4 *>(dst + PLANEB) = l;
-            *reinterpret_cast<uint4 *>(dst + PLANEB + 16) = fl;
+        *reinterpret_cast<uint4 *>(dst + goct * 16) = h;
+        if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(dst + PLANEB + goct * 16) = l;
+        if (goct == 0) {
+            uint4 fh = make_uint4(0, 0, 0, 0), fl = fh;
+            if (pin) Fmt<PREC>::split2(flx, fly, fh.x, fl.x);
+            *reinterpret_cast<uint4 *>(dst + GO * 16) = fh;
+            if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(dst + PLANEB + GO * 16) = fl;
         }
     };
 
     // ---- contraction side ----------------------------------------------------------------------------------------
     int pofs[TB], tapo[NCH];
 #pragma unroll
-    for (int j = 0; j < TB; ++j) pofs[j] = ((wave * TB + j) * XX + r) * PIXB + (g & 1) * 16;
+    for (int j = 0; j < TB; ++j) pofs[j] = ((wave * TB + j) * XX + r) * PIXB;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        const int tap = 2 * k + (g >> 1);
-        tapo[k] = tap < 9 ? ((tap / 3) * XX + tap % 3) * PIXB : 0;     // (taps >= 9 carry zero weights)
+        const int o = 4 * k + g, tap = o < 9 * OCT ? o / OCT : 0, oct = o < 9 * OCT ? o % OCT : 0;   // (octets >= 9 OCT carry zero weights)
+        tapo[k] = ((tap / 3) * XX + tap % 3) * PIXB + oct * 16;
     }
-    for (int i = tid; i < WB / 16; i += 256) reinterpret_cast<uint4 *>(smem + W_OFF)[i] = reinterpret_cast<const uint4 *>(a.w)[i];
     const unsigned char *wl = smem + W_OFF + lane * 16;
-    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+    f32x4 b0[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b0[nt] = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
 
     Unit U = decode(ufirst);
     issue(U, 0);
     int slot = 0;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
-        // the reference part of this column: 4 channels of the lane's two output pixels, added in front of the ReLU of every slice
-        f32x4 rv[TB];
+        // the reference part of this column: 4 channels per output tile of the lane's output pixels, added in front of the ReLU of every slice
+        f32x4 rv[TB][NT];
 #pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const uint16_t *rp = a.ref + (((int64_t)U.b * a.H + U.gy0 + wave * TB + j) * a.W + U.gx0 + r) * rec + g * 4;
-            const uint2 h = *reinterpret_cast<const uint2 *>(rp);
-            uint2 l = make_uint2(0, 0);
-            if constexpr (PARTS == 2) l = *reinterpret_cast<const uint2 *>(rp + C);
-            float r0, r1, r2, r3;
-            Fmt<PREC>::join2(h.x, l.x, r0, r1);
-            Fmt<PREC>::join2(h.y, l.y, r2, r3);
-            rv[j] = f32x4{r0, r1, r2, r3} + b0;
-        }
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint16_t *rp = a.ref + (((int64_t)U.b * a.H + U.gy0 + wave * TB + j) * a.W + U.gx0 + r) * rec + nt * 16 + g * 4;
+                const uint2 h = *reinterpret_cast<const uint2 *>(rp);
+                uint2 l = make_uint2(0, 0);
+                if constexpr (PARTS == 2) l = *reinterpret_cast<const uint2 *>(rp + C);
+                float r0, r1, r2, r3;
+                Fmt<PREC>::join2(h.x, l.x, r0, r1);
+                Fmt<PREC>::join2(h.y, l.y, r2, r3);
+                rv[j][nt] = f32x4{r0, r1, r2, r3} + b0[nt];
+            }
         const Unit Ucur = U;
         for (int s = 0; s < a.N; ++s) {
             land(slot);
@@ -1337,30 +1346,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void h
             const unsigned char *xs = smem + slot * SLOTB;
 #pragma unroll
             for (int j = 0; j < TB; ++j) {
-                f32x4 acc = rv[j];
+                f32x4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = rv[j][nt];
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
                     const short8 xh = *reinterpret_cast<const short8 *>(xs + pofs[j] + tapo[k]);
-                    const short8 wh = *reinterpret_cast<const short8 *>(wl + (k * PARTS) * 1024);
-                    if constexpr (PARTS == 2) {
-                        const short8 xl = *reinterpret_cast<const short8 *>(xs + PLANEB + pofs[j] + tapo[k]);
-                        const short8 wlo = *reinterpret_cast<const short8 *>(wl + (k * PARTS + 1) * 1024);
-                        acc = mma<F16>(wlo, xh, acc);
-                        acc = mma<F16>(wh, xl, acc);
+                    short8 xl = xh;
+                    if constexpr (PARTS == 2) xl = *reinterpret_cast<const short8 *>(xs + PLANEB + pofs[j] + tapo[k]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const short8 wh = *reinterpret_cast<const short8 *>(wl + ((k * NT + nt) * PARTS) * 1024);
+                        if constexpr (PARTS == 2) {
+                            const short8 wlo = *reinterpret_cast<const short8 *>(wl + ((k * NT + nt) * PARTS + 1) * 1024);
+                            acc[nt] = mma<F16>(wlo, xh, acc[nt]);
+                            acc[nt] = mma<F16>(wh, xl, acc[nt]);
+                        }
+                        acc[nt] = mma<F16>(wh, xh, acc[nt]);
                     }
-                    acc = mma<F16>(wh, xh, acc);
-                    if (k == 2) __builtin_amdgcn_sched_barrier(0);   // (all ten fragments of both tiles in flight: 194 registers, two workgroups per CU)
+                    if (CF == 8 ? k == 2 : ((k & 1) == 0 && k > 0)) __builtin_amdgcn_sched_barrier(0);   // (every fragment of the row in flight at once: +40 registers)
                 }
-                uint32_t h01, h23, l01, l23;
-                Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
-                Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
                 const int64_t pix = (((int64_t)Ucur.b * a.N + s) * a.H + Ucur.gy0 + wave * TB + j) * a.W + Ucur.gx0 + r;
-                if constexpr (PARTS == 2) {
-                    swap16(h01, l01);
-                    swap16(h23, l23);
-                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
-                } else {
-                    *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    uint32_t h01, h23, l01, l23;
+                    Fmt<PREC>::split2(relu_bits(acc[nt][0]), relu_bits(acc[nt][1]), h01, l01);
+                    Fmt<PREC>::split2(relu_bits(acc[nt][2]), relu_bits(acc[nt][3]), h23, l23);
+                    if constexpr (PARTS == 2) {
+                        swap16(h01, l01);
+                        swap16(h23, l23);
+                        *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + nt * 16 + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                    } else {
+                        *reinterpret_cast<uint2 *>(a.out + pix * rec + nt * 16 + g * 4) = make_uint2(h01, h23);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1369,18 +1387,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void h
     }
 }
 
-void head_warp_kernel_name(int prec, char *buf, int n) { snprintf(buf, n, "dffw::head_warp_kernel<%d>", prec); }
+void head_warp_kernel_name(int prec, int cf, char *buf, int n) { snprintf(buf, n, "dffw::head_warp_kernel<%d, %d>", prec, cf); }
 
-hipError_t launch_head_warp(int prec, const HeadWarpArgs &a, hipStream_t s) {
-    const int want = a.wgs > 0 ? a.wgs : 1024;
+hipError_t launch_head_warp(int prec, int cf, const HeadWarpArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : (cf == 8 ? 1024 : 512);
     const int per_xcd = (a.total_tiles + 7) / 8;
-    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8))));
+#define DFFW_HW_LAUNCH(P)                                                                             \
+    do {                                                                                              \
+        if (cf == 8) hipLaunchKernelGGL((head_warp_kernel<P, 8>), grid, dim3(256), 0, s, a);          \
+        else if (cf == 16) hipLaunchKernelGGL((head_warp_kernel<P, 16>), grid, dim3(512), 0, s, a);   \
+        else return hipErrorInvalidValue;                                                             \
+    } while (0)
     switch (prec) {
-        case P_BF16X3: hipLaunchKernelGGL((head_warp_kernel<P_BF16X3>), grid, block, 0, s, a); break;
-        case P_FP16: hipLaunchKernelGGL((head_warp_kernel<P_FP16>), grid, block, 0, s, a); break;
-        case P_BF16: hipLaunchKernelGGL((head_warp_kernel<P_BF16>), grid, block, 0, s, a); break;
+        case P_BF16X3: DFFW_HW_LAUNCH(P_BF16X3); break;
+        case P_FP16: DFFW_HW_LAUNCH(P_FP16); break;
+        case P_BF16: DFFW_HW_LAUNCH(P_BF16); break;
         default: return hipErrorInvalidValue;
     }
+#undef DFFW_HW_LAUNCH
     return hipGetLastError();
 }
 

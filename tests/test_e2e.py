@@ -189,6 +189,9 @@ def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
         assert cpu_ref.rel_l2(a.cpu(), g[name]) <= 1e-3, name
 
 
+PREC_ID = {"bf16x3": 0, "fp16": 1, "bf16": 2}
+
+
 def _profiled_kernels(model, *inputs):
     eng = model._engine_on(inputs[0].device)
     eng.profile(True)
@@ -201,23 +204,26 @@ def _profiled_kernels(model, *inputs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
-@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 96, 224)])
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 96, 224), (4, 256, 256)])
 def test_hip_e2e_head_warp_streaming_kernel(lib_built, monkeypatch, B, H, W, precision):
-    """head_warp_kernel (dffw_srd_roll.hip): the level-1 head's first conv over [warp(fe) | flow] with the bilinear gather done one
-    slice ahead while staging (End_to_End.py:96-101 without the warped volume) against flow_volume + conv_tile (DFFW_NO_HEAD_WARP):
+    """head_warp_kernel (dffw_srd_roll.hip): the level-1 (8-channel, full resolution) and, on large enough batches, level-2 (16-channel,
+    half resolution) heads' first conv over [warp(fe) | flow] with the bilinear gather done one slice ahead while staging
+    (End_to_End.py:88-101 without the warped volume) against flow_volume + conv_tile (DFFW_NO_HEAD_WARP):
     magnifying, shrinking and out-of-image warps, columns on every image border; the profile proves which kernel ran; default
     arithmetic also against the oracle."""
     g, sd, FS, fd, fov = load(GOLDEN[0])
     from dffinthewild_amd import synth
     FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=29))
     fd = fd[:1].expand(B, -1, -1, -1).contiguous()
-    fov = torch.cat([1.0 + (fov[:1] - 1.0) * k for k in (1.0, -2.5, 4.0)][:B], 0).contiguous()
+    fov = torch.cat([1.0 + (fov[:1] - 1.0) * k for k in (1.0, -2.5, 4.0, 0.3)][:B], 0).contiguous()
     tags = ["head3", "head2", "head1", "alpha"]
     m = _model(sd, precision)
     with torch.no_grad():
         outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
     ran = [k for k, layer in _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda()) if layer.endswith(".0.0#cur")]
-    assert len(ran) == 3 and ran[2].startswith("dffw::head_warp_kernel"), ran
+    assert len(ran) == 3 and ran[2].startswith("dffw::head_warp_kernel<%d, 8>" % PREC_ID[precision]), ran
+    level2 = B * (H // 16) * (W // 32) >= 256 and (H // 2) % 8 == 0 and (W // 2) % 16 == 0
+    assert ran[1].startswith("dffw::head_warp_kernel<%d, 16>" % PREC_ID[precision]) == level2, ran
     monkeypatch.setenv("DFFW_NO_HEAD_WARP", "1")
     m2 = _model(sd, precision)
     with torch.no_grad():
