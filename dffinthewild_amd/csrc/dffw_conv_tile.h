@@ -70,7 +70,7 @@ const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide = false);
 // configuration with the same geometry, channel group and TILE SHAPE as `base` but `nt` output tiles (for splits)
 const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt);
 bool tile_cfg_has_splitk(const TileCfg *c);   // a split-K instantiation of this configuration exists
-bool tile_cfg_has_warp(const TileCfg *c);     // a warp-fill instantiation (DFFW_ARGS_WARP, WarpSrc through ConvArgs::fs32) exists
+bool tile_cfg_has_sums(const TileCfg *c);     // a row-sums instantiation (DFFW_ARGS_SUMS: per-row sums through ConvArgs::outf, nothing stored) exists
 int tile_cfg_count();
 const TileCfg *tile_cfg_at(int i);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);

@@ -42,9 +42,10 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     constexpr int MTW = T::MT / NWAVES;  // operand tiles (16 grid points) per wave
     constexpr bool STEM = (GEO == G2D || GEO == G2P);   // the stem, per pixel or (STEMP) per pixel pair
     constexpr bool STEMP = (GEO == G2P);
-    // the per-slice 1x3x3 geometry never splits K: its "SPLITK" instantiations are the warp-fill variant (first conv of an alignment
-    // head, End_to_End.py:77-84: the footprint is the FOV-warped feature volume, sampled while staging instead of read from HBM)
-    constexpr bool WARP = (GEO == G2S1) && SPLITK;
+    // the per-slice 1x3x3 geometry never splits K: its "SPLITK" instantiations are the row-sums variant (third conv of an alignment
+    // head, End_to_End.py:41-46, whose result only feeds the head's last conv + plane mean = plane sums, dffw_kernels.hip "alpha head
+    // tail"): nothing is stored but, per output row segment of 16 pixels, its sum and its first and last pixel (a.outf)
+    constexpr bool SUMS = (GEO == G2S1) && SPLITK;
     constexpr int CG8 = CG / 8;
 
     // LDS image: PARTS planes (hi, lo) of [footprint pixel][CG channels], 16-bit.  With CG = 8 a pixel is
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     const Coord cur = decode(tile);
     // split-K (few-tile layers with a deep contraction, see Run::conv): blockIdx.z owns a contiguous range of the
     // channel-group stages and writes raw fp32 partial sums; splitk_finish adds them up and runs the epilogue
-    const bool splitk = SPLITK && !STEM && !WARP && t.ksplit > 1;
+    const bool splitk = SPLITK && !STEM && !SUMS && t.ksplit > 1;
     const int st_lo = splitk ? (int)blockIdx.z * t.nstage / t.ksplit : 0;
     const int st_hi = splitk ? ((int)blockIdx.z + 1) * t.nstage / t.ksplit : t.nstage;
     // pass split (transposed conv, few tiles): the 4 sub-pixel passes write disjoint output phases, so they can be
@@ -296,51 +297,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(smem + PLANEB + p * PIXB) = l;
         }
     };
-    // ---- warp fill: channel octet g8 of the virtual input [warp(fe)[slice n] (ws.C) | flow_x, flow_y, 6 zeros | zero padding] for every
-    // footprint pixel, computed as flow_volume_kernel computes it (same helper, same operation order), split and written to the two
-    // LDS planes.  One item = (footprint pixel, octet of the stage); a thread's items are independent, so the 4 x PARTS corner loads
-    // of all of them are in flight together.  The head's input volume (2.4 GB written and read back at level 1) never exists. ----
-    auto fill_warp = [&](const Coord &c, int st) {
-        const WarpSrc ws = *reinterpret_cast<const WarpSrc *>(a.fs32);   // wave-uniform: scalar loads
-        constexpr int NITEM = T::FPIX * CG8;
-        constexpr int NITW = (NITEM + NWAVES * 64 - 1) / (NWAVES * 64);
-        const int iy0 = c.gy0 + G::MINY, ix0 = c.gx0 + G::MINX;
-        const int fc8 = ws.C >> 3;                                       // octet index of the flow record
-#pragma unroll 2   // two items' corner loads in flight per thread (all of them: +80 VGPRs, a resident workgroup lost)
-        for (int it = 0; it < NITW; ++it) {
-            const int item = tid + it * NWAVES * 64;
-            if (item >= NITEM) break;
-            const int p = item / CG8, c8 = item - p * CG8;
-            const int fz = p / (T::FY * T::FXL), q = p - fz * (T::FY * T::FXL);
-            const int fy = q / T::FXL, fx = q - fy * T::FXL;
-            const int n = c.gz0 + fz, iy = iy0 + fy, ix = ix0 + fx;
-            const int g8 = st * CG8 + c8;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (n < a.Ni && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi && g8 <= fc8) {
-                const int ai = c.b * 3 * a.Ni + n;
-                const float f = ws.alpha[ai] + ws.fov[c.b * a.Ni + n];
-                const WarpPoint wp = warp_point(ix, iy, a.Hi, a.Wi, f, ws.alpha[ai + a.Ni], ws.alpha[ai + 2 * a.Ni]);
-                if (g8 == fc8) {
-                    v[0] = wp.fx;
-                    v[1] = wp.fy;
-                } else {
-                    warp_octet<PREC>(ws.fe + ((int64_t)(c.b * a.Ni + n) * a.Hi * a.Wi) * (PARTS * ws.C) + g8 * 8, ws.C, a.Hi, a.Wi, wp, v);
-                }
-            }
-            uint4 h, l;
-            Fmt<PREC>::split2(v[0], v[1], h.x, l.x);
-            Fmt<PREC>::split2(v[2], v[3], h.y, l.y);
-            Fmt<PREC>::split2(v[4], v[5], h.z, l.z);
-            Fmt<PREC>::split2(v[6], v[7], h.w, l.w);
-            *reinterpret_cast<uint4 *>(smem + p * PIXB + c8 * 16) = h;
-            if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(smem + PLANEB + p * PIXB + c8 * 16) = l;
-        }
-    };
     bool from_stack = false;
     if constexpr (STEM) from_stack = STEMP || a.fs32 != nullptr;
-    if constexpr (WARP) {
-        fill_warp(cur, st_lo);
-    } else if (from_stack) {
+    if (from_stack) {
         if constexpr (STEM) fill_from_stack(cur);
     } else if (!(a.dbg & 1)) {
         issue_fill(cur, st_lo);
@@ -380,8 +339,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                 if ((pass == pass_lo || st_hi - st_lo > 1) && !resident && !(a.dbg & 1)) {
                     if (!prefilled) {
                         __syncthreads();  // everyone is done reading the previous image
-                        if constexpr (WARP) fill_warp(cur, st);
-                        else issue_fill(cur, st);
+                        issue_fill(cur, st);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
@@ -610,6 +568,40 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                     epilogue_cls(a, cls, g, opix, pv);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            } else if constexpr (SUMS) {
+                // an operand tile is one row segment of 16 pixels (TX == 16): lane (g, r) holds channels 4g..4g+3 of pixel r.  Row sums
+                // over the 16 lanes by DPP (quad xor 1, xor 2, half-row mirror, row mirror); lanes r = 0 / r = 15 are the segment's
+                // first / last pixel.  rows[((plane * Ho + y) * tiles_x + tile column) * 3 + {sum, first, last}][Cout] fp32.
+                static_assert(!SUMS || TX == 16, "row-sums variant: one operand tile = one row segment");
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    int64_t opix;
+                    const bool pv = where(j, opix);
+                    const int c = tcrd[j];
+                    const int64_t row = ((int64_t)cur.b * a.No + cur.gz0 + (c >> 16)) * a.Ho + cur.gy0 + ((c >> 8) & 255);
+                    float *rp = a.outf + ((row * t.tiles_x + cur.gx0 / TX) * 3) * a.Cout + g * 4;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 v, rs;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = pv ? relu_bits(acc[nt][j][i]) : 0.f;
+                            float q = v[i];
+                            q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                            q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                            q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                            q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x140, 0xF, 0xF, true));   // row_mirror
+                            rs[i] = q;
+                        }
+                        // (a row of an edge tile past the volume: its lane r = 0 is past it too, nothing is written)
+                        if (pv && r == 0) {
+                            *reinterpret_cast<f32x4 *>(rp + (ntb + nt) * 16) = rs;
+                            *reinterpret_cast<f32x4 *>(rp + a.Cout + (ntb + nt) * 16) = v;
+                        }
+                        if (pv && r == 15) *reinterpret_cast<f32x4 *>(rp + 2 * a.Cout + (ntb + nt) * 16) = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < MTW; ++j) {
@@ -703,7 +695,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(17, G3S2, 2, 4, 4, 8, 8, 1)
 
 #if DFFW_TILE_PREC == 0   // configuration table and look-ups live in one of the three per-precision objects
-bool tile_cfg_has_warp(const TileCfg *c) { return c && c->geo == G2S1 && (c->id == 29 || c->id == 18 || c->id == 20); }
+bool tile_cfg_has_sums(const TileCfg *c) { return c && c->geo == G2S1 && c->nw == 4 && (c->id == 34 || c->id == 19); }
 bool tile_cfg_has_splitk(const TileCfg *c) {
     switch (c->id) {
 #define X_HAS(ID, GEO, NT, TZ, TY, TX, CG, PIPE) case ID:
@@ -750,7 +742,7 @@ void conv_tile_kernel_name(int prec, const TileCfg *c, bool splitk, char *buf, i
 
 template <int PREC>
 static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
-    switch (t.ksplit > 1 ? 1000 + cfg->id : ((a.dbg & DFFW_ARGS_WARP) ? 3000 + cfg->id : ((a.dbg & DFFW_ARGS_RAW) ? 2000 + cfg->id : cfg->id))) {
+    switch (t.ksplit > 1 ? 1000 + cfg->id : ((a.dbg & DFFW_ARGS_SUMS) ? 3000 + cfg->id : ((a.dbg & DFFW_ARGS_RAW) ? 2000 + cfg->id : cfg->id))) {
 #define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
     case ID:                                                                                                        \
         hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.ksplit > 1 ? t.ksplit : (t.pass_split ? 4 : 1))), dim3(256), 0, s, a, t); \
@@ -769,15 +761,12 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
         break;
         DFFW_TILE_CONFIGS_SPLITK(X_LAUNCHK)
 #undef X_LAUNCHK
-        // the warp-fill variant of the per-slice 1x3x3 configurations the alignment heads' first conv runs on
-        case 3000 + 29:
-            hipLaunchKernelGGL((conv_tile<PREC, G2S1, 1, 5, 8, 16, 16, 0, 8, true>), dim3((unsigned)t.grid, 1, 1), dim3(512), 0, s, a, t);
+        // the row-sums variant of the per-slice 1x3x3 configurations the alignment heads' third conv runs on
+        case 3000 + 34:
+            hipLaunchKernelGGL((conv_tile<PREC, G2S1, 2, 5, 4, 16, 32, 1, 4, true>), dim3((unsigned)t.grid, 1, 1), dim3(256), 0, s, a, t);
             break;
-        case 3000 + 18:
-            hipLaunchKernelGGL((conv_tile<PREC, G2S1, 2, 5, 4, 16, 8, 1, 4, true>), dim3((unsigned)t.grid, 1, 1), dim3(256), 0, s, a, t);
-            break;
-        case 3000 + 20:
-            hipLaunchKernelGGL((conv_tile<PREC, G2S1, 4, 5, 4, 16, 8, 1, 4, true>), dim3((unsigned)t.grid, 1, 1), dim3(256), 0, s, a, t);
+        case 3000 + 19:
+            hipLaunchKernelGGL((conv_tile<PREC, G2S1, 4, 5, 4, 16, 16, 1, 4, true>), dim3((unsigned)t.grid, 1, 1), dim3(256), 0, s, a, t);
             break;
         // the stem reading a raw (uint8 / 0..255) stack: its "SPLITK" instantiations
         case 2000 + 15:

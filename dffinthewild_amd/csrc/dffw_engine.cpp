@@ -1079,7 +1079,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(WARP_FILL) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1126,8 +1126,9 @@ struct ConvOpt {
     int outf_ch = 1;
     const float *fs32 = nullptr;  // stem: read the fp32 focal stack directly (in0 then only carries the geometry)
     bool raw = false;   // stem: fs32 is a device-side RawStack descriptor (raw uint8 / 0..255 stack, normalised and padded on the fly)
-    const WarpSrc *warp = nullptr;   // per-slice 1x3x3 conv over the FOV-warped volume described by this device-side descriptor (in0 then
-                                     // only carries the geometry): conv_tile's warp-fill variant; Run::warp_conv_ok() says when it exists
+    float *sums = nullptr;      // per-slice 1x3x3 conv + ReLU whose result only feeds plane sums: nothing is stored, `sums` receives per output
+                                // row segment of 16 pixels [sum | first pixel | last pixel][Cout] fp32 (conv_tile's row-sums variant;
+                                // Run::sums_conv_ok() says when it exists; out is not allocated)
     const char *cls = nullptr;  // name of a 1x1x1 C->1 layer to apply to the final value inside the epilogue
     float *cls_out = nullptr;   // its fp32 score volume
     bool discard = false;       // the activation output itself is not needed (only cls_out / out_pre)
@@ -1251,13 +1252,13 @@ struct Run {
         return c && !sw.on(SW_NO_TILE) && gW * 2 >= c->tx && gH * 2 >= c->ty;
     }
 
-    // conv_tile's warp-fill variant serves per-slice layer `name` on a (B,N,H,W) volume: tiled, an instantiation exists, and enough
-    // tiles that conv() will not split the output channels over the grid
-    bool warp_conv_ok(const std::string &name, int B, int N, int H, int W) const {
+    // conv_tile's row-sums variant serves per-slice layer `name` on a (B,N,H,W) volume: tiled, an instantiation exists, whole row
+    // segments of 16 pixels, and enough tiles that conv() will not split the output channels over the grid
+    bool sums_conv_ok(const std::string &name, int B, int N, int H, int W) const {
         if (!tiled(name, H, W)) return false;
         const TileCfg *c = e->convs.find(name)->second.tile.cfg;
-        if (!tile_cfg_has_warp(c)) return false;
-        const int64_t tiles = (int64_t)B * ((N + c->tz - 1) / c->tz) * ((H + c->ty - 1) / c->ty) * ((W + c->tx - 1) / c->tx);
+        if (!tile_cfg_has_sums(c) || W % c->tx) return false;
+        const int64_t tiles = (int64_t)B * ((N + c->tz - 1) / c->tz) * ((H + c->ty - 1) / c->ty) * (W / c->tx);
         return tiles >= 256 && sw.small_max_units == 0;
     }
 
@@ -1287,7 +1288,7 @@ struct Run {
             Wo = (win + 2 * L.pw - L.dw * (L.kw - 1) - 1) / L.sw + 1;
         }
         const int No = in0.N + 2 * L.pd - (L.kd - 1);
-        if (o.outf == nullptr && !o.discard) out = act(in0.B, No, Ho, Wo, L.cout);
+        if (o.outf == nullptr && !o.discard && !o.sums) out = act(in0.B, No, Ho, Wo, L.cout);
         else { out.B = in0.B; out.N = No; out.H = Ho; out.W = Wo; out.C = L.cout; }
         const float *cls_w = nullptr;
         if (o.cls) {
@@ -1332,13 +1333,13 @@ struct Run {
         a.zero = e->zero_page;
         a.dbg = sw.debug_flags & (7 | 48 | 64);
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
-        if (o.warp) {
-            if (!warp_conv_ok(name, in0.B, in0.N, in0.H, in0.W)) {
-                err = fail(DFFW_EINVAL, "layer %s has no warp-fill kernel for this shape", name.c_str());
+        if (o.sums) {
+            if (!sums_conv_ok(name, in0.B, in0.N, in0.H, in0.W) || o.relu != 1 || o.res0 || o.res1 || o.cls || o.out_pre || o.in1) {
+                err = fail(DFFW_EINVAL, "layer %s has no row-sums kernel for this shape / epilogue", name.c_str());
                 return out;
             }
-            a.fs32 = reinterpret_cast<const float *>(o.warp);
-            a.dbg |= DFFW_ARGS_WARP;
+            a.outf = o.sums;
+            a.dbg |= DFFW_ARGS_SUMS;
         }
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
@@ -1653,7 +1654,7 @@ struct Run {
 #ifdef DFFW_WITH_PP
                 if (use_pp) return conv_pp_kernel_name(e->prec, cfg, kn, n);
 #endif
-                conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_WARP)), kn, n);
+                conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)), kn, n);
             };
             {
                 char kn[96];
@@ -2291,39 +2292,24 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             // for all N slices of a sample, so it runs once per sample (1/N of the work, no ref channels in the volume) and
             // enters the per-slice conv over [cur | flow] as a slice-broadcast residual in front of the ReLU
             Act refw = r.act(B, 1, fe.H, fe.W, fe.C);
-            // [cur | flow] is not materialised when a kernel samples the warped features while staging its tiles: head_warp_kernel
-            // (8- and 16-channel levels, whole 8 x 16 columns) or conv_tile's warp-fill variant (opt-in, DFFW_WARP_FILL=1:
-            // measured slower than flow_volume + LDS-DMA fill -- 1.64 vs 0.85 + 0.93 ms at level 1 -- the gathers of a tile are one
-            // dependent latency chain per workgroup at two workgroups per CU)
+            // [cur | flow] is not materialised when head_warp_kernel serves the level (8- and 16-channel levels, whole 8 x 16 columns): it
+            // samples the warped features while staging its tiles.  (The same inside conv_tile's fill was measured slower than
+            // flow_volume + LDS-DMA fill -- 1.64 vs 0.85 + 0.93 ms at level 1: a tile's gathers are one dependent latency chain per
+            // workgroup there -- and removed again.)
             auto ccur = r.e->convs.find(hp + ".0.0#cur");
             const bool roll = (fe.C == 8 || fe.C == 16) && ccur != r.e->convs.end() && ccur->second.wsrd && ccur->second.def.cin == fe.C + 2 &&
                               ccur->second.def.cout == 2 * fe.C && fe.H % 8 == 0 &&
                               fe.W % 16 == 0 && (int64_t)B * (fe.H / 8) * (fe.W / 16) >= 256 && !r.sw.on(SW_NO_HEAD_WARP) && !r.sw.on(SW_NO_TILE);
-            const bool fused = !roll && r.warp_conv_ok(hp + ".0.0#cur", B, N, fe.H, fe.W) && r.sw.on(SW_WARP_FILL);
             Act vol;
-            WarpSrc *wsrc = nullptr;
-            if (roll) {
-            } else if (fused) {
-                vol.B = B; vol.N = N; vol.H = fe.H; vol.W = fe.W; vol.C = fe.C + 8;
-                wsrc = (WarpSrc *)r.raw(sizeof(WarpSrc));
-            } else {
-                vol = r.act(B, N, fe.H, fe.W, fe.C + 8);
-            }
+            if (!roll) vol = r.act(B, N, fe.H, fe.W, fe.C + 8);
             if (r.ok() && !r.dry) {
                 r.prof_begin(kn, std::string("flow") + lv.head + ".volume", 0.0,
-                             ((double)(fused || roll ? 0 : fe.pixels()) * (2.0 * fe.C + 8) + (double)refw.pixels() * 2.0 * fe.C) * r.elem_bytes());
+                             ((double)(roll ? 0 : fe.pixels()) * (2.0 * fe.C + 8) + (double)refw.pixels() * 2.0 * fe.C) * r.elem_bytes());
                 r.check(launch_flow_volume(prec, fe.p, refw.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 2, r.s), "flow_volume ref");
-                if (roll) {
-                } else if (fused) {
-                    WarpSrc ws;
-                    ws.fe = fe.p; ws.alpha = alpha; ws.fov = fov; ws.C = fe.C; ws.pad = 0;
-                    r.check(launch_set_warp(ws, wsrc, r.s), "set_warp");
-                } else {
-                    r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 1, r.s), "flow_volume cur");
-                }
+                if (!roll) r.check(launch_flow_volume(prec, fe.p, vol.p, alpha, fov, B, N, fe.H, fe.W, fe.C, 1, r.s), "flow_volume cur");
                 r.prof_end();
             }
-            if (!fused && !roll) r.drop(fe);
+            if (!roll) r.drop(fe);
             // per-slice conv: the B reference slices are presented as the B slices of ONE sample so that the 5-slice tiles
             // are filled (same memory either way)
             Act refw1 = refw;
@@ -2356,14 +2342,8 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
                 ConvOpt oc = rl;
                 oc.res0 = &refpart;
                 oc.res_bcast = true;
-                oc.warp = wsrc;
                 y0 = r.conv(hp + ".0.0#cur", vol, oc);
-                if (fused) {
-                    r.drop(fe);
-                    r.drop_raw(wsrc);
-                } else {
-                    r.drop(vol);
-                }
+                r.drop(vol);
             }
             r.drop(refpart);
         } else {
@@ -2435,7 +2415,26 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             } else {
                 Act y1 = r.conv(hp + ".2.0", y0, rl);
                 r.drop(y0);
-                y2 = r.conv(hp + ".4.0", y1, rl);
+                // the head's tail as plane sums and a row-sums kernel for the third conv: its output is not stored either
+                if (tail_sums && c6->second.def.cin == y1.C && c4 != end && c4->second.def.cout == y1.C && !r.sw.on(SW_NO_HEAD_SUMS_FUSED) &&
+                    r.sums_conv_ok(hp + ".4.0", y1.B, y1.N, y1.H, y1.W)) {
+                    const int tiles_x = y1.W / c4->second.tile.cfg->tx;
+                    float *rows = (float *)r.raw((int64_t)B * N * y1.H * tiles_x * 3 * y1.C * sizeof(float));
+                    double *seg = (double *)r.raw(head_tail_tiles_scratch_bytes(B, N, y1.C));
+                    ConvOpt os = rl;
+                    os.sums = rows;
+                    r.conv(hp + ".4.0", y1, os);
+                    if (r.ok() && !r.dry) {
+                        r.prof_begin("dffw::head_tail_rows_reduce_kernel", hp + ".6+mean (finish)", 0.0, (double)B * N * y1.H * tiles_x * 3 * y1.C * 4.0);
+                        r.check(launch_head_tail_rows(rows, seg, tiles_x, c6->second.whead, alpha, rawh, B, N, y1.H, y1.W, y1.C, r.s), "head_tail_rows");
+                        r.prof_end();
+                    }
+                    r.drop_raw(seg);
+                    r.drop_raw(rows);
+                    tail_done = true;
+                } else {
+                    y2 = r.conv(hp + ".4.0", y1, rl);
+                }
                 r.drop(y1);
             }
         }

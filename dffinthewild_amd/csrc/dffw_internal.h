@@ -42,16 +42,7 @@ struct RawStack {
 
 #define DFFW_RAW_NORM_F64_BIT 16   // == DFFW_RAW_NORM_F64 of include/dffw.h (device code does not include that header)
 #define DFFW_ARGS_RAW 8
-#define DFFW_ARGS_WARP 128
-// Source of conv_tile's warp-fill variant (first conv of an alignment head): the level's feature volume and the warp parameters
-// found so far; lives in device memory, ConvArgs::fs32 points to it.
-struct WarpSrc {
-    const uint16_t *fe;             // (B,N,H,W,C) channels-last, the conv's own B, Ni, Hi, Wi
-    const float *alpha;             // (B,3,N): scale offset, x shift, y shift per slice
-    const float *fov;               // (B,N)
-    int C;                          // channels of fe; the virtual conv input is [warp(fe) (C) | flow_x, flow_y, 6 zeros]
-    int pad;
-};
+#define DFFW_ARGS_SUMS 128
 // (ConvArgs must not grow: the register allocation of the lean transposed-conv kernels is sensitive to its size, a
 // 56-byte larger argument block cost them 38 %)
 struct ConvArgs {
@@ -91,7 +82,6 @@ hipError_t launch_conv(int prec, const ConvArgs &a, hipStream_t s);
 void conv_kernel_name(int prec, int cout, char *buf, int n);  // name of the instantiation launch_conv picks
 void conv_kernel_name_for(int prec, const ConvArgs &a, char *buf, int n);   // name of the kernel launch_conv picks for `a` (conv_small for small grids)
 hipError_t launch_set_raw(const RawStack &rs, RawStack *dst, hipStream_t s);   // writes the descriptor into device memory (enqueue-only)
-hipError_t launch_set_warp(const WarpSrc &ws, WarpSrc *dst, hipStream_t s);
 hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int N, int H, int W, hipStream_t s);
 hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C, int N, int H, int W, hipStream_t s);
@@ -112,6 +102,9 @@ hipError_t launch_alpha_mean(const float *head, float *alpha, float *raw, int B,
 // B*N*(head_tail_chunks()+4)*C doubles; w: PackedConv::whead
 int head_tail_chunks(int B, int N, int64_t hw);
 // ... from the per-tile vectors of of_roll_kernel<.., SUMS> (tsum: B*N*tiles_y*tiles_x*18*C floats)
+// ... from the per-row-segment vectors of conv_tile's row-sums variant (rows: B*N*H*tiles_x*3*C floats)
+hipError_t launch_head_tail_rows(const float *rows, double *seg, int tiles_x, const float *w, float *alpha, float *raw, int B, int N, int H, int W,
+                                 int C, hipStream_t s);
 // seg: device scratch of head_tail_tiles_scratch_bytes()
 int64_t head_tail_tiles_scratch_bytes(int B, int N, int C);
 hipError_t launch_head_tail_tiles(const float *tsum, double *seg, int tiles_y, int tiles_x, const float *w, float *alpha, float *raw, int B,

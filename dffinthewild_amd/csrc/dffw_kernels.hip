@@ -981,12 +981,57 @@ __global__ __launch_bounds__(64) void head_tail_tiles_finish_kernel(const double
     if (tid < 3) head_tail_apply(sums, w, alpha, raw, b, n, N, (int64_t)H * W, C, tid);
 }
 
+// ... and for conv_tile's row-sums variant: rows[((plane * H + y) * tiles_x + tx) * 3 * C + k * C + c], k = 0 sum over the row segment of 16
+// pixels, 1 / 2 its first / last pixel.  Same two steps (segments = contiguous ranges of rows).
+__global__ __launch_bounds__(256) void head_tail_rows_reduce_kernel(const float *__restrict__ rows, double *__restrict__ seg, int H, int tiles_x, int C) {
+    __shared__ double red[9][256];
+    const int plane = blockIdx.y;
+    const int tid = threadIdx.x, c = tid % C, j0 = tid / C, nj = 256 / C;
+    const int per = (H + HT_SEG - 1) / HT_SEG, y0 = blockIdx.x * per, y1 = y0 + per < H ? y0 + per : H;
+    const int n0 = y0 * tiles_x, n1 = y1 * tiles_x;
+    const float *tp = rows + (int64_t)plane * H * tiles_x * 3 * C + c;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = n0 + j0; t < n1; t += nj) {
+        const int y = t / tiles_x, tx = t - y * tiles_x;
+        const float *q = tp + (int64_t)t * 3 * C;
+        const bool top = y == 0, bot = y == H - 1, lef = tx == 0, rig = tx == tiles_x - 1;
+        const double rs = (double)q[0];
+        acc[0] += rs;
+        if (top) acc[1] += rs;
+        if (bot) acc[2] += rs;
+        if (lef) acc[3] += (double)q[C];
+        if (rig) acc[4] += (double)q[2 * C];
+        if (top && lef) acc[5] += (double)q[C];
+        if (top && rig) acc[6] += (double)q[2 * C];
+        if (bot && lef) acc[7] += (double)q[C];
+        if (bot && rig) acc[8] += (double)q[2 * C];
+    }
+    for (int k = 0; k < 9; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    if (tid < C)
+        for (int k = 0; k < 9; ++k) {
+            double a = 0.0;
+            for (int j = 0; j < nj; ++j) a += red[k][j * C + tid];
+            seg[(((int64_t)plane * HT_SEG + blockIdx.x) * 9 + k) * C + tid] = a;
+        }
+}
+
 int64_t head_tail_tiles_scratch_bytes(int B, int N, int C) { return (int64_t)B * N * HT_SEG * 9 * C * (int64_t)sizeof(double); }
 
 hipError_t launch_head_tail_tiles(const float *tsum, double *seg, int tiles_y, int tiles_x, const float *w, float *alpha, float *raw, int B,
                                   int N, int H, int W, int C, hipStream_t s) {
     if (C < 8 || C > 64 || 256 % C) return hipErrorInvalidValue;
     hipLaunchKernelGGL(head_tail_tiles_reduce_kernel, dim3(HT_SEG, B * N), dim3(256), 0, s, tsum, seg, tiles_y, tiles_x, C);
+    hipError_t h = hipGetLastError();
+    if (h != hipSuccess) return h;
+    hipLaunchKernelGGL(head_tail_tiles_finish_kernel, dim3(B * N), dim3(64), 0, s, seg, w, alpha, raw, N, H, W, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_head_tail_rows(const float *rows, double *seg, int tiles_x, const float *w, float *alpha, float *raw, int B, int N, int H, int W,
+                                 int C, hipStream_t s) {
+    if (C < 8 || C > 64 || 256 % C) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_tail_rows_reduce_kernel, dim3(HT_SEG, B * N), dim3(256), 0, s, rows, seg, H, tiles_x, C);
     hipError_t h = hipGetLastError();
     if (h != hipSuccess) return h;
     hipLaunchKernelGGL(head_tail_tiles_finish_kernel, dim3(B * N), dim3(64), 0, s, seg, w, alpha, raw, N, H, W, C);
@@ -1111,12 +1156,6 @@ hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H,
 __global__ void set_raw_kernel(RawStack rs, RawStack *dst) { *dst = rs; }
 hipError_t launch_set_raw(const RawStack &rs, RawStack *dst, hipStream_t s) {
     hipLaunchKernelGGL(set_raw_kernel, dim3(1), dim3(1), 0, s, rs, dst);
-    return hipGetLastError();
-}
-
-__global__ void set_warp_kernel(WarpSrc ws, WarpSrc *dst) { *dst = ws; }
-hipError_t launch_set_warp(const WarpSrc &ws, WarpSrc *dst, hipStream_t s) {
-    hipLaunchKernelGGL(set_warp_kernel, dim3(1), dim3(1), 0, s, ws, dst);
     return hipGetLastError();
 }
 
