@@ -643,15 +643,12 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
                                                        const float *__restrict__ fov, float *__restrict__ out,
                                                        float *__restrict__ flow, int B, int C, int N, int H, int W,
                                                        int alpha_from_sample0) {
+    // grid = (pixel blocks of a slice, B * N): 32-bit index arithmetic (as one flat 64-bit index the four divisions per pixel were the
+    // kernel's longest dependency chain)
     const int64_t plane = (int64_t)H * W;
-    const int64_t total = (int64_t)B * N * plane;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(i % W);
-        int64_t t = i / W;
-        const int yy = (int)(t % H);
-        t /= H;
-        const int n = (int)(t % N);
-        const int b = (int)(t / N);
+    const int n = blockIdx.y % N, b = blockIdx.y / N;
+    for (unsigned ip = blockIdx.x * 256u + threadIdx.x; ip < (unsigned)plane; ip += gridDim.x * 256u) {
+        const int yy = (int)(ip / (unsigned)W), xx = (int)(ip - (unsigned)yy * (unsigned)W);
         // the reference's batch>1 quirk (End_to_End.py:112): `alpha[:,0,:,:] + FOVs` broadcasts to (B,B,N,1,1) and `[:,0]` keeps
         // alpha[0,n] + FOVs[b,n] -- sample 0's scale offset, but every sample's OWN field of view
         const int ab = alpha_from_sample0 ? 0 : b;
@@ -683,6 +680,22 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
             coff[k] = cok[k] ? (int64_t)zz * plane + (int64_t)yc * W + xc : 0;
             cw[k] = wx[dx] * wy[dy] * wz[dz];
         }
+        // the slice coordinate is the slice index itself for most slices (exactly: for N = 10 all but slices 1 and 2, where it falls
+        // one ulp short): when no lane of the wave blends two slices only the four in-plane corners are requested
+        if (__builtin_amdgcn_ballot_w64(wz1 != 0.f) == 0) {
+            for (int c = 0; c < C; ++c) {
+                const float *src = x + ((int64_t)b * C + c) * N * plane;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = src[coff[k]];
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (cok[k]) acc += v[k] * cw[k];
+                out[(((int64_t)b * C + c) * N + n) * plane + (int64_t)yy * W + xx] = acc;
+            }
+            continue;
+        }
         for (int c = 0; c < C; ++c) {
             const float *src = x + ((int64_t)b * C + c) * N * plane;
             float v[8];
@@ -699,9 +712,10 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
 
 hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,
                            int H, int W, int alpha_from_sample0, hipStream_t s) {
-    const int64_t total = (int64_t)B * N * H * W;
-    hipLaunchKernelGGL(fov_warp_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, alpha, fov, out, flow, B, C, N, H, W,
-                       alpha_from_sample0);
+    const int64_t plane = (int64_t)H * W;
+    if (plane >= (1ll << 31) || (int64_t)B * N > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fov_warp_kernel, dim3((unsigned)std::min<int64_t>((plane + 255) / 256, 65535), B * N), dim3(256), 0, s, x, alpha, fov, out, flow,
+                       B, C, N, H, W, alpha_from_sample0);
     return hipGetLastError();
 }
 
