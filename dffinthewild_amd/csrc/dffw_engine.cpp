@@ -823,6 +823,37 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    // ---- of_s2 (down-sampling block 8 -> 16 of the alignment network): conv.0 = 1x3x3 stride (1,2,2), 8 -> 16: chunk k, K octet g = filter
+    // tap 4k + g; its 1x1x1 stride-2 shortcut (no BatchNorm, no bias): one chunk, K octet 0 = the 8 input channels
+    if (geo == G2S2 && cin_pad == 8 && L.cout == 16 && !shortcut_w) {
+        std::vector<uint16_t> wr((size_t)3 * parts * 512, 0);
+        for (int c = 0; c < 3; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = lane & 15, tap = 4 * c + (lane >> 4);
+                    float val = 0.f;
+                    if (tap < 9) val = (float)wval(co, j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                    uint16_t hi, lo;
+                    host_split(prec, val, hi, lo);
+                    const size_t base = ((size_t)c * parts) * 512 + (size_t)lane * 8 + j;
+                    wr[base] = hi;
+                    if (parts == 2) wr[base + 512] = lo;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    if (!L.transposed && L.kd == 1 && L.kh == 1 && L.kw == 1 && L.sh == 2 && cin_pad == 8 && L.cout == 16 && !bn && !conv_bias && !shortcut_w) {
+        std::vector<uint16_t> wr((size_t)parts * 512, 0);
+        for (int lane = 0; lane < 16; ++lane)        // K octet 0 only
+            for (int j = 0; j < 8; ++j) {
+                uint16_t hi, lo;
+                host_split(prec, (float)wval(lane, j, Tap{0, 0, 0, 0, 0, 0}), hi, lo);
+                wr[(size_t)lane * 8 + j] = hi;
+                if (parts == 2) wr[512 + (size_t)lane * 8 + j] = lo;
+            }
+        HIPCHK(hipMalloc((void **)&pc.wsrd, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wsrd, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     // ---- srd_roll16: the per-slice 1x3x3 16 -> 16 convs: chunk k, K octet g = (filter tap 2k + (g >> 1), channel octet g & 1)
     // (packed with a sixth, all-zero chunk: the same buffer then serves as the second conv of of_roll_kernel, whose shortcut chunk
     // it leaves empty, for plain conv -> conv chains such as the alignment heads' .2.0 -> .4.0)
@@ -2227,6 +2258,35 @@ static Act of_block(Run &r, const std::string &p, const Act &x) {
                 const LayerDef &L0 = c0->second.def;
                 r.prof_begin(kn, p, 2.0 * px * (9.0 * L0.cin * co + 9.0 * co * co + (double)L0.cin * co), px * (x.C + co) * r.elem_bytes());
                 r.check(co == 8 ? launch_of_roll8(r.e->prec, a, r.s) : launch_of_roll(r.e->prec, x.C == 8, a, r.s), "of_roll");
+                r.prof_end();
+            }
+            return out;
+        }
+    }
+    {
+        // the 8 -> 16 down-sampling block on whole 8 x 16 output columns: one streaming kernel (of_s2_kernel, dffw_srd_roll.hip)
+        auto c0 = r.e->convs.find(p + ".conv.0.0"), c2 = r.e->convs.find(p + ".conv.2.0"), cf = r.e->convs.find(p + ".feature");
+        const auto end = r.e->convs.end();
+        if (c0 != end && c2 != end && cf != end && x.C == 8 && c0->second.wsrd && c2->second.wsrd && cf->second.wsrd && c0->second.def.sh == 2 &&
+            c0->second.def.cout == 16 && c2->second.def.cout == 16 && c2->second.cin_all == 16 && cf->second.def.sh == 2 && cf->second.def.cout == 16 &&
+            x.H % 16 == 0 && x.W % 32 == 0 && (int64_t)x.B * (x.H / 16) * (x.W / 32) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
+            Act out = r.act(x.B, x.N, x.H / 2, x.W / 2, 16);
+            if (r.ok() && !r.dry) {
+                SrdArgs a;
+                memset(&a, 0, sizeof a);
+                a.x = x.p; a.out = out.p;
+                a.w0 = c0->second.wsrd; a.w2 = c2->second.wsrd; a.w3f = cf->second.wsrd;
+                a.b0 = c0->second.bias; a.b2 = c2->second.bias;
+                a.B = x.B; a.N = x.N; a.H = out.H; a.W = out.W;
+                a.tiles_y = out.H / 8; a.tiles_x = out.W / 16;
+                a.total_tiles = x.B * a.tiles_y * a.tiles_x;
+                a.wgs = r.sw.srd_wgs;
+                char kn[64];
+                of_s2_kernel_name(r.e->prec, kn, sizeof kn);
+                g_last_kernel = kn;
+                const double px = (double)out.pixels();
+                r.prof_begin(kn, p, 2.0 * px * (9.0 * 8 * 16 + 9.0 * 16 * 16 + 8.0 * 16), (4.0 * px * 8 + px * 16) * r.elem_bytes());
+                r.check(launch_of_s2(r.e->prec, a, r.s), "of_s2");
                 r.prof_end();
             }
             return out;

@@ -1409,6 +1409,226 @@ hipError_t launch_head_warp(int prec, int cf, const HeadWarpArgs &a, hipStream_t
     return hipGetLastError();
 }
 
+// ---- of_s2: the down-sampling residual block of the alignment network at 8 -> 16 channels (End_to_End.py:135-145 with stride 2,
+// `OF_feature1.0`) as ONE streaming kernel ---------------------------------------------------------------------------------------
+//     out = relu( conv1x1x1_s2(x) + BN(conv1x3x3(relu(BN(conv1x3x3_s2(x))))) )
+// As three launches (strided conv on conv_tile, the 1x1x1 shortcut on the gather kernel, the second conv with the shortcut as a
+// residual) the full-resolution input was read twice and the two half-resolution intermediates went through HBM.  Here a workgroup
+// walks the slices of a column of 8 x 16 OUTPUT pixels: the 21 x 37 input footprint of a slice (two 3x3 halos, the inner one at stride
+// 2) is fetched one step ahead into registers (plain 16-byte loads, one (pixel, part) piece per thread and pass) and written into one
+// of two LDS slots with the even columns of a row first, so that the stride-2 operand reads of 16 neighbouring pixels stay
+// contiguous; stage A computes t = relu(BN(conv.0)) on the 10 x 18 region conv.2 needs (3 chunks, K octet g of chunk k = tap 4k + g)
+// into LDS records, zero outside the image; stage B contracts t (5 chunks, srd_roll16's order) plus one chunk for the shortcut (the
+// input pixel under the output pixel, already in LDS) and stores the block's output.  No LDS-DMA: hipcc counts every wait itself.
+template <int PREC>
+__global__ __launch_bounds__(256) void of_s2_kernel(const SrdArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int CI = 8, C = 16, TY = 8, TX = 16, NWAVES = 4;
+    constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;               // t region
+    constexpr int XY = 2 * TYT + 1, XX = 2 * TXT + 1, XPIX = XY * XX, XEV = TXT + 1;   // input footprint; XEV even columns per row
+    constexpr int XPIXB = CI * 2, PIXB = C * 2;
+    constexpr int XPLANEB = XPIX * XPIXB, XSLOTB = PARTS * XPLANEB, TPLANEB = TPIX * PIXB;
+    constexpr int T_OFF = 2 * XSLOTB;
+    constexpr int NITEM = XPIX * PARTS, NPASS = (NITEM + 255) / 256;
+    constexpr int NCHA = 3, NCHB = 5, TA = 3, TB = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[T_OFF + PARTS * TPLANEB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {      // columns of the OUTPUT grid (a.H x a.W = output size; the input is 2 a.H x 2 a.W)
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+    const int Hi = 2 * a.H, Wi = 2 * a.W;
+    const int rec = PARTS * C, xrec = PARTS * CI;
+
+    // ---- fill side: item = (footprint pixel, part); thread t takes items t, t + 256, ... -------------------------------
+    uint4 q[NPASS];
+    int ldst[NPASS];      // LDS byte offset inside a slot of the item's piece (even columns of a row first)
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        const int item = tid + k * 256, part = item / XPIX, pix = item - part * XPIX;
+        const int fy = pix / XX, fx = pix - fy * XX;
+        ldst[k] = part * XPLANEB + (fy * XX + ((fx & 1) ? XEV + (fx >> 1) : (fx >> 1))) * XPIXB;
+    }
+    auto issue = [&](const Unit &U, int n) {
+        const uint16_t *slice = a.x + ((int64_t)(U.b * a.N + n) * Hi * Wi) * xrec;
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int item = tid + k * 256, part = item / XPIX, pix = item - part * XPIX;
+            const int fy = pix / XX, fx = pix - fy * XX;
+            const int iy = 2 * U.gy0 - 3 + fy, ix = 2 * U.gx0 - 3 + fx;
+            const bool ok = item < NITEM && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+            q[k] = make_uint4(0, 0, 0, 0);
+            if (ok) q[k] = *reinterpret_cast<const uint4 *>(slice + (iy * Wi + ix) * xrec + part * CI);
+        }
+    };
+    auto land = [&](int slot) {
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k)
+            if (tid + k * 256 < NITEM) *reinterpret_cast<uint4 *>(smem + slot * XSLOTB + ldst[k]) = q[k];
+    };
+
+    // ---- stage A: the 10 x 18 t pixels are 12 operand tiles (the last one partly idle), three per wave ----------------
+    int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
+    bool ta_ok[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        int p = (wave * TA + j) * 16 + r;
+        ta_ok[j] = p < TPIX;
+        if (p >= TPIX) p = TPIX - 1;
+        ta_y[j] = p / TXT;
+        ta_x[j] = p - ta_y[j] * TXT;
+        pa[j] = (2 * ta_y[j] * XX + ta_x[j]) * XPIXB;             // footprint pixel (2 ty, 2 tx): even column tx of row 2 ty
+        ta_st[j] = T_OFF + p * PIXB + g * 8;
+    }
+    int tapA[NCHA], tapB[NCHB];
+#pragma unroll
+    for (int k = 0; k < NCHA; ++k) {
+        const int tap = 4 * k + g;                                 // taps >= 9 carry zero weights
+        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
+        tapA[k] = (dy * XX + (dx == 1 ? XEV : (dx == 2 ? 1 : 0))) * XPIXB;
+    }
+#pragma unroll
+    for (int k = 0; k < NCHB; ++k) {
+        const int tap = 2 * k + (g >> 1);
+        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
+        tapB[k] = (dy * TXT + dx) * PIXB + (g & 1) * 16;
+    }
+    // ---- stage B: wave w = output rows 2w, 2w+1 ---------------------------------------------------------------------
+    int pbo[TB], pbx[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int oy = wave * TB + j;
+        pbo[j] = (oy * TXT + r) * PIXB;
+        pbx[j] = ((2 * oy + 3) * XX + XEV + r + 1) * XPIXB;       // input pixel (2 oy + 3, 2 r + 3): odd column r + 1
+    }
+    short8 w0[NCHA][PARTS], w2[NCHB][PARTS], wsc[PARTS];
+#pragma unroll
+    for (int k = 0; k < NCHA; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < NCHB; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) wsc[pt] = reinterpret_cast<const short8 *>(a.w3f)[pt * 64 + lane];
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
+
+    Unit U = decode(ufirst);
+    issue(U, 0);
+    int slot = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit Ucur = U;
+        for (int s = 0; s < a.N; ++s) {
+            land(slot);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = s + 1 < a.N || cu + wgs_per_xcd < uend;
+            if (s + 1 == a.N && more) U = decode(cu + wgs_per_xcd);
+            if (more) issue(U, s + 1 < a.N ? s + 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();          // the slice is in LDS; stage B of the previous step has read t
+            const unsigned char *xs = smem + slot * XSLOTB;
+            // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image (conv.2's padding) ----------
+#pragma unroll
+            for (int j = 0; j < TA; ++j) {
+                f32x4 acc = b0;
+#pragma unroll
+                for (int k = 0; k < NCHA; ++k) {
+                    const short8 xh = *reinterpret_cast<const short8 *>(xs + pa[j] + tapA[k]);
+                    if constexpr (PARTS == 2) {
+                        const short8 xl = *reinterpret_cast<const short8 *>(xs + XPLANEB + pa[j] + tapA[k]);
+                        acc = mma<F16>(w0[k][1], xh, acc);
+                        acc = mma<F16>(w0[k][0], xl, acc);
+                    }
+                    acc = mma<F16>(w0[k][0], xh, acc);
+                }
+                const int iy = Ucur.gy0 - 1 + ta_y[j], ix = Ucur.gx0 - 1 + ta_x[j];
+                const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                if (ta_ok[j]) {
+                    uint32_t h01, h23, l01, l23;
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    *reinterpret_cast<uint2 *>(smem + ta_st[j]) = make_uint2(h01, h23);
+                    if constexpr (PARTS == 2) *reinterpret_cast<uint2 *>(smem + ta_st[j] + TPLANEB) = make_uint2(l01, l23);
+                }
+            }
+            __syncthreads();
+            // ---- stage B: out = relu(conv.2(t) + shift + shortcut(x)) ------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                f32x4 acc = b2;
+#pragma unroll
+                for (int k = 0; k < NCHB; ++k) {
+                    const short8 th = *reinterpret_cast<const short8 *>(smem + T_OFF + pbo[j] + tapB[k]);
+                    if constexpr (PARTS == 2) {
+                        const short8 tl = *reinterpret_cast<const short8 *>(smem + T_OFF + TPLANEB + pbo[j] + tapB[k]);
+                        acc = mma<F16>(w2[k][1], th, acc);
+                        acc = mma<F16>(w2[k][0], tl, acc);
+                    }
+                    acc = mma<F16>(w2[k][0], th, acc);
+                }
+                {   // the shortcut chunk: K octet 0 = the 8 channels of the input pixel under the output pixel (octets 1..3: zero weights)
+                    const short8 sh = *reinterpret_cast<const short8 *>(xs + pbx[j]);
+                    if constexpr (PARTS == 2) {
+                        const short8 sl = *reinterpret_cast<const short8 *>(xs + XPLANEB + pbx[j]);
+                        acc = mma<F16>(wsc[1], sh, acc);
+                        acc = mma<F16>(wsc[0], sl, acc);
+                    }
+                    acc = mma<F16>(wsc[0], sh, acc);
+                }
+                uint32_t h01, h23, l01, l23;
+                Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
+                Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
+                const int64_t pix = (((int64_t)Ucur.b * a.N + s) * a.H + Ucur.gy0 + wave * TB + j) * a.W + Ucur.gx0 + r;
+                if constexpr (PARTS == 2) {
+                    swap16(h01, l01);
+                    swap16(h23, l23);
+                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+                }
+            }
+            slot ^= 1;
+        }
+    }
+}
+
+void of_s2_kernel_name(int prec, char *buf, int n) { snprintf(buf, n, "dffw::of_s2_kernel<%d>", prec); }
+
+hipError_t launch_of_s2(int prec, const SrdArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : 512;
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    switch (prec) {
+        case P_BF16X3: hipLaunchKernelGGL((of_s2_kernel<P_BF16X3>), grid, block, 0, s, a); break;
+        case P_FP16: hipLaunchKernelGGL((of_s2_kernel<P_FP16>), grid, block, 0, s, a); break;
+        case P_BF16: hipLaunchKernelGGL((of_s2_kernel<P_BF16>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ---- srd_attention_mfma: the attention tail of the 32-channel SRD block (`FM_conv2.1.N_ch_attention`) on the matrix cores ------
 //     out = feat + relu(conv1x1x1(relu(conv3x1x1(feat))))     (DEN.py:322-329; no BatchNorm, no bias)
 // The fused VALU kernel (srd_attention_kernel) stops at 16 channels (C*C*4 FMAs per pixel); at 32 channels the two convs ran as

@@ -302,7 +302,7 @@ def test_hip_e2e_head_tail_as_plane_sums(lib_built, monkeypatch, B, H, W, precis
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
-@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (2, 128, 256)])
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (2, 128, 256), (4, 256, 256), (9, 96, 160)])
 def test_hip_e2e_fused_alignment_blocks_match_two_launch_form(lib_built, monkeypatch, B, H, W, precision):
     """of_roll8 / of_roll (dffw_srd_roll.hip): the stride-1 residual blocks of the alignment network (End_to_End.py:135-145:
     OF_feature.0, OF_feature.1 at full resolution, OF_feature1.1 at half) as one streaming kernel each (conv.0 -> t in LDS ->
@@ -313,7 +313,11 @@ def test_hip_e2e_fused_alignment_blocks_match_two_launch_form(lib_built, monkeyp
     fd = fd[:1].expand(B, -1, -1, -1).contiguous()
     fov = fov[:1].expand(B, -1, -1, -1, -1).contiguous()
     with torch.no_grad():
-        outs, taps = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
+        m = _model(sd, precision)
+        outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
+        # the 8 -> 16 down-sampling block (OF_feature1.0) runs as of_s2_kernel when the batch gives it >= 256 columns of 8 x 16 outputs
+        ran = [k for k, layer in _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda()) if layer.endswith("OF_feature1.0")]
+        assert (len(ran) == 1 and ran[0].startswith("dffw::of_s2_kernel")) == (B * (H // 16) * (W // 32) >= 256 and H % 16 == 0 and W % 32 == 0), ran
         monkeypatch.setenv("DFFW_NO_FUSED_OF", "1")
         outs2, taps2 = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
     tol = {"bf16x3": 1e-4, "fp16": 2e-2, "bf16": 1e-1}[precision]
