@@ -1,7 +1,5 @@
 mkdir -p gpurun_out/s4
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for u in 0 128 256 512 1024 2048 4096; do
-DFFW_SMALL_MAX_UNITS=$u python bench.py --batch 1 --steps 100 --warmup 20 --no-cpu-baseline --no-roofline > gpurun_out/s4/b1_$u.json 2>/dev/null
-DFFW_SMALL_MAX_UNITS=$u python bench.py --batch 1 --slices 5 --size 224 --steps 100 --warmup 20 --no-cpu-baseline --no-roofline > gpurun_out/s4/b1s_$u.json 2>/dev/null
-done
-DFFW_SMALL_MAX_UNITS=1024 python bench.py --batch 1 --steps 20 --warmup 5 --no-cpu-baseline --dump-layers gpurun_out/s4/layers_b1_1024.tsv > /dev/null 2>&1
+python -m pytest tests/test_gpu_forward.py -x -q -m gpu -k test_oracle_parity_fresh 2>&1 | tail -30 > gpurun_out/s4/ta.txt
+DFFW_SMALL_MAX_UNITS=0 python -m pytest tests/test_gpu_forward.py -x -q -m gpu -k test_oracle_parity_fresh 2>&1 | tail -5 > gpurun_out/s4/tb.txt
+DFFW_SMALL_MAX_UNITS=0 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -8 > gpurun_out/s4/tall.txt
