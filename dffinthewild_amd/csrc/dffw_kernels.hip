@@ -1113,11 +1113,22 @@ __global__ __launch_bounds__(256) void regress_kernel(const float *__restrict__ 
                                                       int64_t fsh, int64_t fsw, float *__restrict__ depth) {
     const int64_t total = (int64_t)B * H * W;
     const float sch = (float)h / (float)H, scw = (float)w / (float)W;
+    const bool small = total < (1ll << 31);      // 32-bit index arithmetic whenever it fits (two 64-bit divisions per pixel otherwise)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int X = (int)(i % W);
-        const int64_t t = i / W;
-        const int Y = (int)(t % H);
-        const int64_t b = t / H;
+        int X, Y;
+        int64_t b;
+        if (small) {
+            const unsigned u = (unsigned)i, t = u / (unsigned)W;
+            X = (int)(u - t * (unsigned)W);
+            const unsigned bb = t / (unsigned)H;
+            Y = (int)(t - bb * (unsigned)H);
+            b = bb;
+        } else {
+            X = (int)(i % W);
+            const int64_t t = i / W;
+            Y = (int)(t % H);
+            b = t / H;
+        }
         float sy = ((float)Y + 0.5f) * sch - 0.5f;
         float sx = ((float)X + 0.5f) * scw - 0.5f;
         sy = sy < 0.f ? 0.f : sy;
