@@ -217,6 +217,8 @@ def test_hip_e2e_head_warp_streaming_kernel(lib_built, monkeypatch, B, H, W, pre
     fd = fd[:1].expand(B, -1, -1, -1).contiguous()
     fov = torch.cat([1.0 + (fov[:1] - 1.0) * k for k in (1.0, -2.5, 4.0, 0.3)][:B], 0).contiguous()
     tags = ["head3", "head2", "head1", "alpha"]
+    if B == 3:
+        monkeypatch.setenv("DFFW_SRD_WGS", "16")         # two workgroups per XCD: every workgroup walks a long stream of columns
     m = _model(sd, precision)
     with torch.no_grad():
         outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
@@ -312,6 +314,8 @@ def test_hip_e2e_fused_alignment_blocks_match_two_launch_form(lib_built, monkeyp
     FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=91))
     fd = fd[:1].expand(B, -1, -1, -1).contiguous()
     fov = fov[:1].expand(B, -1, -1, -1, -1).contiguous()
+    if B == 9:
+        monkeypatch.setenv("DFFW_SRD_WGS", "8")          # one workgroup per XCD walks all of its columns
     with torch.no_grad():
         m = _model(sd, precision)
         outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
