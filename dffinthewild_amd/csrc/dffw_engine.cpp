@@ -1110,7 +1110,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP)
+    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -2315,17 +2315,51 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
     const std::string P = "optical_flow_aggregation";
     const int prec = r.e->prec;
     ConvOpt rl; rl.relu = 1;
-    Act in = r.act(B, N, H, W, 8);
-    if (r.ok() && !r.dry) {
-        char kn[56];
-        snprintf(kn, sizeof kn, "dffw::from_ncdhw_pad_kernel<%d>", prec);
-        r.prof_begin(kn, "flow.stack_in", 0.0, (double)B * N * H * W * (3 * 4.0 + 8 * r.elem_bytes()));
-        r.check(launch_from_ncdhw_pad(prec, FS, in.p, B, 3, 8, N, H, W, r.s), "from_ncdhw_pad");
-        r.prof_end();
-    }
     // three feature levels: full, 1/2, 1/4 resolution                               End_to_End.py:72-74
-    Act a0 = of_block(r, P + ".OF_feature.0", in);
-    r.drop(in);
+    Act a0;
+    {
+        // the first block reads the fp32 stack itself when its streaming kernel applies (of_first_kernel = of_roll8 with the record
+        // conversion inside its fill): the 8-channel record volume of the stack is neither written nor read
+        const std::string p0 = P + ".OF_feature.0";
+        auto c0 = r.e->convs.find(p0 + ".conv.0.0"), c2 = r.e->convs.find(p0 + ".conv.2.0");
+        const auto end = r.e->convs.end();
+        const bool first = c0 != end && c2 != end && r.e->convs.find(p0 + ".feature") == end && c0->second.wsrd && c2->second.wsrd &&
+                           c0->second.def.cin == 3 && c0->second.def.cout == 8 && c2->second.def.cout == 8 && c2->second.cin_all == 16 && H % 8 == 0 &&
+                           W % 16 == 0 && (int64_t)B * (H / 8) * (W / 16) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_OF_FIRST) &&
+                           !r.sw.on(SW_NO_TILE);
+        if (first) {
+            a0 = r.act(B, N, H, W, 8);
+            if (r.ok() && !r.dry) {
+                SrdArgs a;
+                memset(&a, 0, sizeof a);
+                a.w3 = FS; a.out = a0.p;
+                a.w0 = c0->second.wsrd; a.w2 = c2->second.wsrd;
+                a.b0 = c0->second.bias; a.b2 = c2->second.bias;
+                a.B = B; a.N = N; a.H = H; a.W = W;
+                a.tiles_y = H / 8; a.tiles_x = W / 16;
+                a.total_tiles = B * a.tiles_y * a.tiles_x;
+                a.wgs = r.sw.srd_wgs;
+                char kn[64];
+                of_first_kernel_name(prec, kn, sizeof kn);
+                g_last_kernel = kn;
+                const double px = (double)B * N * H * W;
+                r.prof_begin(kn, p0, 2.0 * px * (9.0 * 3 * 8 + 9.0 * 8 * 8 + 3.0 * 8), px * (3 * 4.0 + 8 * r.elem_bytes()));
+                r.check(launch_of_first(prec, a, r.s), "of_first");
+                r.prof_end();
+            }
+        } else {
+            Act in = r.act(B, N, H, W, 8);
+            if (r.ok() && !r.dry) {
+                char kn[56];
+                snprintf(kn, sizeof kn, "dffw::from_ncdhw_pad_kernel<%d>", prec);
+                r.prof_begin(kn, "flow.stack_in", 0.0, (double)B * N * H * W * (3 * 4.0 + 8 * r.elem_bytes()));
+                r.check(launch_from_ncdhw_pad(prec, FS, in.p, B, 3, 8, N, H, W, r.s), "from_ncdhw_pad");
+                r.prof_end();
+            }
+            a0 = of_block(r, p0, in);
+            r.drop(in);
+        }
+    }
     Act fe1 = of_block(r, P + ".OF_feature.1", a0);
     r.drop(a0);
     Act a1 = of_block(r, P + ".OF_feature1.0", fe1);

@@ -35,6 +35,9 @@ constexpr int OF_CHUNKS_B = 6;
 // two rows; first / last row; four corners) for head_tail_finish_tiles (dffw_kernels.hip); 16 input channels only
 hipError_t launch_of_roll(int prec, bool cin8, const SrdArgs &a, hipStream_t s, bool sums = false);
 void of_roll_kernel_name(int prec, bool cin8, char *buf, int n, bool sums = false);
+// of_first: of_roll8's block with its input taken from the planar fp32 focal stack (B,3,N,H,W) = a.w3 (a.x unused); filters as for of_roll8
+hipError_t launch_of_first(int prec, const SrdArgs &a, hipStream_t s);
+void of_first_kernel_name(int prec, char *buf, int n);
 // of_s2: the down-sampling residual block 8 -> 16 channels of the alignment network as one kernel: a.x = block input (B,N,2H,2W,8),
 // a.out (B,N,H,W,16) (a.H, a.W = OUTPUT size, columns of 8 x 16 output pixels); a.w0 = conv.0 (1x3x3 stride 2, 8 -> 16) as 3 chunks
 // (K octet g of chunk k = tap 4k + g), a.w2 = conv.2 (16 -> 16) in srd_roll16's order, a.w3f = the 1x1x1 shortcut as one chunk (K octet

@@ -584,6 +584,194 @@ __global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
 }
 
+// ---- of_first: the first residual block of the alignment network (`OF_feature.0`, 3 -> 8 channels) straight from the fp32 stack ---
+// of_roll8's arithmetic (pixel-pair form, same filter packing, same operation order: bit-identical results) with the block input
+// taken from the planar fp32 focal stack (B,3,N,H,W) instead of the 8-channel record volume: thread p < 240 owns pixel p of the
+// 12 x 20 footprint, requests its three colour values for slice s+1 before the contraction of slice s, splits them afterwards into the
+// record [c0 c1 c2 0 0 0 0 0] (what from_ncdhw_pad wrote) and stores it into one of two LDS slots, even columns of a row first.  Saves
+// the record volume's write and read (32 B per pixel each; the stack is 12 B per pixel).  Plain loads only: hipcc counts every wait.
+template <int PREC>
+__global__ __launch_bounds__(256) void of_first_kernel(const SrdArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int C = 8, TY = 8, TX = 16;
+    constexpr int XY = TY + 4, XX = TX + 4, XPIX = XY * XX;        // x footprint
+    constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;    // region of t that conv.2 needs
+    constexpr int PIXB = C * 2;
+    constexpr int PLANEB = XPIX * PIXB, SLOTB = PARTS * PLANEB;
+    constexpr int TPLANEB = (TPIX * PIXB + 15) / 16 * 16;
+    constexpr int T_OFF = 2 * SLOTB;
+    static_assert(XPIX <= 256, "one footprint pixel per thread");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[T_OFF + PARTS * TPLANEB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+    const int rec = PARTS * C;
+    const float *FS = a.w3;                                         // the fp32 focal stack (B,3,N,H,W)
+    const int64_t plane = (int64_t)a.H * a.W, cplane = (int64_t)a.N * plane;
+
+    // ---- fill side ---------------------------------------------------------------------------------------------------
+    const bool gth = tid < XPIX;
+    const int fy = tid / XX, fx = tid - fy * XX;
+    const int lpos = (fy * XX + ((fx & 1) ? XX / 2 + (fx >> 1) : (fx >> 1))) * PIXB;   // even columns of a row first
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    auto issue = [&](const Unit &U, int n) {
+        const int iy = U.gy0 - 2 + fy, ix = U.gx0 - 2 + fx;
+        c0 = c1 = c2 = 0.f;
+        if (gth && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+            const float *sp = FS + (int64_t)U.b * 3 * cplane + (int64_t)n * plane + (int64_t)iy * a.W + ix;
+            c0 = sp[0];
+            c1 = sp[cplane];
+            c2 = sp[2 * cplane];
+        }
+    };
+    auto land = [&](int slot) {
+        if (!gth) return;
+        uint4 h = make_uint4(0, 0, 0, 0), l = h;
+        Fmt<PREC>::split2(c0, c1, h.x, l.x);
+        Fmt<PREC>::split2(c2, 0.f, h.y, l.y);
+        *reinterpret_cast<uint4 *>(smem + slot * SLOTB + lpos) = h;
+        if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(smem + slot * SLOTB + PLANEB + lpos) = l;
+    };
+
+    // ---- per-lane constants (of_roll8's) --------------------------------------------------------------------------------
+    constexpr int TA = 2;
+    const int nA = wave < 2 ? 2 : 1;
+    constexpr int APAIRS = TYT * (TXT / 2);
+    int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
+    bool ta_ok[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        const int tile = j == 0 ? wave : 4 + wave;
+        int pi = tile * 16 + r;
+        ta_ok[j] = pi < APAIRS;
+        if (pi >= APAIRS) pi = APAIRS - 1;
+        const int row = pi / (TXT / 2), pc = pi - row * (TXT / 2);
+        ta_y[j] = row;
+        ta_x[j] = 2 * pc + (g >> 1);
+        pa[j] = (row * XX + ((g & 1) ? XX / 2 : 0) + pc + (g >> 1)) * PIXB;
+        ta_st[j] = T_OFF + (row * TXT + ((g >> 1) ? TXT / 2 : 0) + pc) * PIXB + (g & 1) * 8;
+    }
+    const int pb_pi = wave * 16 + r, pb_y = pb_pi / (TX / 2), pb_pc = pb_pi % (TX / 2), pb_x = 2 * pb_pc + (g >> 1);
+    const int pbo = (pb_y * TXT + ((g & 1) ? TXT / 2 : 0) + pb_pc + (g >> 1)) * PIXB;
+    const int pb_sc = ((pb_y + 2) * XX + ((g & 1) ? XX / 2 : 0) + pb_pc + 1) * PIXB;
+    short8 w0[3][PARTS], w2[3][PARTS], wsc[PARTS];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) {
+            w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
+            w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
+        }
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) wsc[pt] = reinterpret_cast<const short8 *>(a.w2)[(3 * PARTS + pt) * 64 + lane];
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + (g & 1) * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + (g & 1) * 4);
+    auto tile_mma = [&](const unsigned char *base, int rowB, int loB, const short8 (&wf)[3][PARTS], f32x4 acc) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const short8 xh = *reinterpret_cast<const short8 *>(base + k * rowB);
+            if constexpr (PARTS == 2) {
+                const short8 xl = *reinterpret_cast<const short8 *>(base + k * rowB + loB);
+                acc = mma<F16>(wf[k][1], xh, acc);
+                acc = mma<F16>(wf[k][0], xl, acc);
+            }
+            acc = mma<F16>(wf[k][0], xh, acc);
+        }
+        return acc;
+    };
+
+    Unit U = decode(ufirst);
+    issue(U, 0);
+    int slot = 0;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit Ucur = U;
+        for (int s = 0; s < a.N; ++s) {
+            land(slot);
+            const bool more = s + 1 < a.N || cu + wgs_per_xcd < uend;
+            if (s + 1 == a.N && more) U = decode(cu + wgs_per_xcd);
+            if (more) issue(U, s + 1 < a.N ? s + 1 : 0);
+            __syncthreads();
+            const unsigned char *xs = smem + slot * SLOTB;
+            // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ----------------------------
+#pragma unroll
+            for (int j = 0; j < TA; ++j) {
+                if (j >= nA) break;
+                const f32x4 acc = tile_mma(xs + pa[j], XX * PIXB, PLANEB, w0, b0);
+                const int iy = Ucur.gy0 - 1 + ta_y[j], ix = Ucur.gx0 - 1 + ta_x[j];
+                const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                if (ta_ok[j]) {
+                    uint32_t h01, h23, l01, l23;
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    *reinterpret_cast<uint2 *>(smem + ta_st[j]) = make_uint2(h01, h23);
+                    if constexpr (PARTS == 2) *reinterpret_cast<uint2 *>(smem + ta_st[j] + TPLANEB) = make_uint2(l01, l23);
+                }
+            }
+            __syncthreads();
+            // ---- stage B: out = relu(conv.2(t) + shift + shortcut(x)) -------------------------------------------------------------
+            {
+                f32x4 acc = tile_mma(smem + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
+                const short8 sh = *reinterpret_cast<const short8 *>(xs + pb_sc);
+                if constexpr (PARTS == 2) {
+                    const short8 sl = *reinterpret_cast<const short8 *>(xs + PLANEB + pb_sc);
+                    acc = mma<F16>(wsc[1], sh, acc);
+                    acc = mma<F16>(wsc[0], sl, acc);
+                }
+                acc = mma<F16>(wsc[0], sh, acc);
+                uint32_t h01, h23, l01, l23;
+                Fmt<PREC>::split2(relu_bits(acc[0]), relu_bits(acc[1]), h01, l01);
+                Fmt<PREC>::split2(relu_bits(acc[2]), relu_bits(acc[3]), h23, l23);
+                const int64_t pix = (((int64_t)Ucur.b * a.N + s) * a.H + Ucur.gy0 + pb_y) * a.W + Ucur.gx0 + pb_x;
+                if constexpr (PARTS == 2) {
+                    swap16(h01, l01);
+                    swap16(h23, l23);
+                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C) = make_uint4(h01, h23, l01, l23);
+                } else {
+                    *reinterpret_cast<uint2 *>(a.out + pix * rec + (g & 1) * 4) = make_uint2(h01, h23);
+                }
+            }
+            slot ^= 1;
+        }
+    }
+}
+
+void of_first_kernel_name(int prec, char *buf, int n) { snprintf(buf, n, "dffw::of_first_kernel<%d>", prec); }
+
+hipError_t launch_of_first(int prec, const SrdArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : 1024;
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    switch (prec) {
+        case P_BF16X3: hipLaunchKernelGGL((of_first_kernel<P_BF16X3>), grid, block, 0, s, a); break;
+        case P_FP16: hipLaunchKernelGGL((of_first_kernel<P_FP16>), grid, block, 0, s, a); break;
+        case P_BF16: hipLaunchKernelGGL((of_first_kernel<P_BF16>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ---- srd_roll16: the same block for the 16-channel half-resolution stage (`FM_conv1.1`) -----------------------------------
 // 16 output channels fill the MFMA result rows, so no pixel pairs: a GEMM column is one pixel, the 1x3x3 convs contract over
 // 5 chunks of (2 taps x 16 channels) (tap 9 = zeros), records are 32 bytes per plane (natural column order).  Columns are

@@ -322,6 +322,19 @@ def test_hip_e2e_fused_alignment_blocks_match_two_launch_form(lib_built, monkeyp
         # the 8 -> 16 down-sampling block (OF_feature1.0) runs as of_s2_kernel when the batch gives it >= 256 columns of 8 x 16 outputs
         ran = [k for k, layer in _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda()) if layer.endswith("OF_feature1.0")]
         assert (len(ran) == 1 and ran[0].startswith("dffw::of_s2_kernel")) == (B * (H // 16) * (W // 32) >= 256 and H % 16 == 0 and W % 32 == 0), ran
+        # ... and the first block reads the fp32 stack itself (of_first_kernel): bit-identical to stack_in + of_roll8
+        prof = _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda())
+        first = [k for k, layer in prof if layer.endswith("OF_feature.0")]
+        assert len(first) == 1 and first[0].startswith("dffw::of_first_kernel") and not any(layer == "flow.stack_in" for _, layer in prof), first
+        monkeypatch.setenv("DFFW_NO_OF_FIRST", "1")
+        m1 = _model(sd, precision)
+        outs1, taps1 = m1.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
+        assert any(layer == "flow.stack_in" for _, layer in _profiled_kernels(m1, FS.cuda(), fd.cuda(), fov.cuda()))
+        for tag in ("head3", "head2", "head1", "alpha"):
+            assert torch.equal(taps[tag], taps1[tag]), tag
+        for a_, b_ in zip(outs, outs1):
+            assert torch.equal(a_, b_)
+        monkeypatch.delenv("DFFW_NO_OF_FIRST")
         monkeypatch.setenv("DFFW_NO_FUSED_OF", "1")
         outs2, taps2 = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), ["head3", "head2", "head1", "alpha"])
     tol = {"bf16x3": 1e-4, "fp16": 2e-2, "bf16": 1e-1}[precision]
@@ -393,6 +406,33 @@ def test_real_scenes_driver_sequence(lib_built):
     assert np.array_equal(slices.cpu().numpy(), pipeline_ref.unpack_stack(warped.cpu().numpy(), size=crop[2:]))
     rgb = pipeline.colorize(depth, size=crop[2:])                                                    # TRS.py:40,48-52
     assert np.array_equal(rgb.cpu().numpy()[0], pipeline_ref.colorize(depth[0].cpu().numpy(), size=crop[2:]))
+
+
+@pytest.mark.gpu
+def test_hip_e2e_real_scene_size(lib_built):
+    """One stack at the size the reference's real-scene loader produces for its 1280 x 720 JPEGs (1/12 border crop -> 600 x 1068,
+    padded to 608 x 1088; End_to_End/Test_dataloader.py:20-23, 56-75): every streaming kernel of the alignment network takes its
+    fast path at batch 1 there (76 x 68 columns of 8 x 16 pixels) -- checked in the profile -- and the five outputs match the oracle."""
+    from dffinthewild_amd import pipeline
+    from tests.test_pipeline import BALLS_FOCUS, BALLS_FOCAL
+    g, sd, _, _, _ = load(SMOOTH[0])
+    H, W = 608, 1088
+    FS = torch.from_numpy(synth.focal_stack(1, 10, H, W, seed=404))
+    FS[:, :, :, 600:, :] = -1.0                                   # the loader's padding value
+    FS[:, :, :, :, 1068:] = -1.0
+    fd, fov = pipeline.real_scene_inputs(BALLS_FOCUS, BALLS_FOCAL)
+    m = _model(sd)
+    with torch.no_grad():
+        outs = m(FS.cuda(), fd, fov)
+    prof = _profiled_kernels(m, FS.cuda(), fd, fov)
+    names = [k for k, _ in prof]
+    for want in ("dffw::of_roll8_kernel<0>", "dffw::of_s2_kernel<0>", "dffw::head_warp_kernel<0, 8>", "dffw::head_warp_kernel<0, 16>",
+                 "dffw::of_roll_kernel<0, false, true>", "dffw::head_tail_rows_reduce_kernel"):
+        assert want in names, (want, sorted(set(names)))
+    with torch.no_grad():
+        ref = cpu_ref.e2e_forward(cpu_ref.to_torch_state(sd), FS, fd.cpu(), fov.cpu())
+    for name, o, r in zip(OUT_NAMES, outs, ref):
+        assert cpu_ref.rel_l2(o.cpu(), r) <= 1e-3, name
 
 
 @pytest.mark.gpu
