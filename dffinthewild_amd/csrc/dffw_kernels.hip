@@ -455,11 +455,16 @@ hipError_t launch_splitk_finish(int prec, const float *partial, int ksplit, int6
 template <int PREC>
 __global__ __launch_bounds__(256) void pool_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ out, int B, int N,
                                                    int H, int W, int C, int k, int mode) {
+    // k adjacent lanes per (output pixel, channel octet): lane dy takes row dy of the k x k window (its k loads are independent
+    // and requested together), the rows are combined by a xor-shuffle tree -- the same order at every batch size, and a
+    // 64-load serial chain per thread (27 us for the (1,8,8) pool of one stack) becomes 8 loads + 3 shuffles.  k = 2, 4, 8.
     constexpr int PARTS = Fmt<PREC>::PARTS;
     const int Ho = H / k, Wo = W / k, C8 = C / 8;
-    const int64_t total = (int64_t)B * N * Ho * Wo * C8;
+    const int64_t total = (int64_t)B * N * Ho * Wo * C8 * k;
     const float inv = 1.0f / (float)(k * k);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int dy = (int)(i0 & (k - 1));
+        const int64_t i = i0 / k;
         const int c8 = (int)(i % C8);
         int64_t t = i / C8;
         const int ox = (int)(t % Wo);
@@ -469,19 +474,26 @@ __global__ __launch_bounds__(256) void pool_kernel(const uint16_t *__restrict__ 
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = mode == 0 ? -INFINITY : 0.f;
-        for (int dy = 0; dy < k; ++dy)
-            for (int dx = 0; dx < k; ++dx) {
-                const int64_t pix = (bn * H + (oy * k + dy)) * W + (ox * k + dx);
-                const uint16_t *p = x + pix * (PARTS * C) + c8 * 8;
-                const short8 h = *reinterpret_cast<const short8 *>(p);
-                short8 l = short8{0, 0, 0, 0, 0, 0, 0, 0};
-                if constexpr (PARTS == 2) l = *reinterpret_cast<const short8 *>(p + C);
+        const uint16_t *row = x + ((bn * H + (oy * k + dy)) * W + ox * k) * (int64_t)(PARTS * C) + c8 * 8;
+        for (int dx = 0; dx < k; ++dx) {
+            const uint16_t *p = row + dx * (PARTS * C);
+            const short8 h = *reinterpret_cast<const short8 *>(p);
+            short8 l = short8{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (PARTS == 2) l = *reinterpret_cast<const short8 *>(p + C);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float f = Fmt<PREC>::join((uint16_t)h[j], (uint16_t)l[j]);
-                    v[j] = mode == 0 ? fmaxf(v[j], f) : v[j] + f;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float f = Fmt<PREC>::join((uint16_t)h[j], (uint16_t)l[j]);
+                v[j] = mode == 0 ? fmaxf(v[j], f) : v[j] + f;
             }
+        }
+        for (int off = 1; off < k; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float o = __shfl_xor(v[j], off);
+                v[j] = mode == 0 ? fmaxf(v[j], o) : v[j] + o;
+            }
+        }
+        if (dy != 0) continue;
         short8 h, l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -498,8 +510,8 @@ __global__ __launch_bounds__(256) void pool_kernel(const uint16_t *__restrict__ 
 
 hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *out, int B, int N, int H, int W, int C,
                        hipStream_t s) {
-    if (C % 8 || H % k || W % k) return hipErrorInvalidValue;
-    const int64_t total = (int64_t)B * N * (H / k) * (W / k) * (C / 8);
+    if (C % 8 || H % k || W % k || (k != 2 && k != 4 && k != 8)) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * N * (H / k) * (W / k) * (C / 8) * k;
     DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((pool_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, x, out, B, N, H, W, C, k, mode));
     return hipGetLastError();
 }
