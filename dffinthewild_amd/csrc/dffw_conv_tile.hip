@@ -670,6 +670,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(25, G3T, 4, 5, 4, 16, 32, 1)   \
     X(34, G2S1, 2, 5, 4, 16, 32, 1)  \
     X(37, G3S2, 4, 4, 4, 8, 16, 1)   \
+    X(38, G3S2, 2, 4, 4, 8, 16, 1)   \
+    X(39, G3S2, 1, 4, 4, 8, 16, 1)   \
     X(32, G2P, 1, 1, 16, 32, 8, 0)
 // 8-wave "wide" variants: 640-point tiles, same work per wave.  Measured +8..17 % on the bandwidth-bound
 // single-stage layers with <= 16 output channels (one more resident wave per SIMD for the same LDS, 17 % less
@@ -692,7 +694,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(16, G3S1, 2, 4, 4, 8, 16, 1)   \
     X(5, G3S2, 1, 5, 4, 16, 8, 1)    \
     X(6, G3S2, 2, 5, 4, 16, 8, 1)    \
-    X(17, G3S2, 2, 4, 4, 8, 8, 1)
+    X(17, G3S2, 2, 4, 4, 8, 8, 1)    \
+    X(38, G3S2, 2, 4, 4, 8, 16, 1)   \
+    X(39, G3S2, 1, 4, 4, 8, 16, 1)
 
 #if DFFW_TILE_PREC == 0   // configuration table and look-ups live in one of the three per-precision objects
 bool tile_cfg_has_sums(const TileCfg *c) { return c && c->geo == G2S1 && c->nw == 4 && (c->id == 34 || c->id == 19); }
