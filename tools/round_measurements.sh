@@ -17,6 +17,7 @@ python bench.py --workload e2e --batch 1 --steps 30 --warmup 5 --no-cpu-baseline
 # share the chip and each one's duration says nothing about the kernel)
 export DFFW_NO_CONCURRENT=1 DFFW_NO_PROBE=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/rocprof_bench.json 2> $out/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_e2e -o stats -- python3 bench.py --workload e2e --steps 5 --warmup 2 --no-cpu-baseline > $out/rocprof_bench_e2e.json 2> $out/rocprof_e2e.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 # wave-state / matrix-pipe / LDS counters of the conv kernels (two passes: 8 SQ slots each), batch 32
