@@ -472,7 +472,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) ---------------------------
             if (pass == G::NPASS - 1) stamp(3);
             const int ooy = t.ooy[pass], oox = t.oox[pass];
-            const bool last_pass = pass == G::NPASS - 1;
             // output location of operand tile j = tile base (wave-uniform) + the lane's precomputed offset; the
             // bounds test is only evaluated for tiles that stick out of the volume
             const int64_t obase = (((int64_t)cur.b * a.No + cur.gz0) * a.Ho + (cur.gy0 * G::OS + ooy)) * a.Wo + (cur.gx0 * G::OS + oox);

@@ -1005,7 +1005,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
 // (B,N,H,W), so a dry run of the same code computes the exact peak (dffw_workspace_bytes).
 class Arena {
   public:
-    explicit Arena(int64_t cap = INT64_MAX) : cap_(cap) { free_.push_back({0, cap}); }
+    explicit Arena(int64_t cap = INT64_MAX) { free_.push_back({0, cap}); }
     int64_t alloc(int64_t bytes) {
         bytes = (bytes + 255) & ~(int64_t)255;
         for (size_t i = 0; i < free_.size(); ++i) {
@@ -1041,7 +1041,7 @@ class Arena {
     int64_t peak() const { return peak_; }
 
   private:
-    int64_t cap_, peak_ = 0;
+    int64_t peak_ = 0;
     std::vector<std::pair<int64_t, int64_t>> free_;
     std::map<int64_t, int64_t> live_;
 };
@@ -1676,7 +1676,6 @@ struct Run {
             if (use_stream) t.grid = 256;   // 8 XCDs x 32 CUs, one resident workgroup each
 #else
             const TileCfg *scfg = nullptr;
-            const bool use_stream = false;
 #endif
             auto kernel_name = [&](char *kn, int n) {
 #ifdef DFFW_WITH_STREAM

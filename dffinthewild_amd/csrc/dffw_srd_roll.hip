@@ -387,7 +387,6 @@ __global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
         const u32x2 d = {v0, v1};
         asm volatile("ds_write_b64 %0, %1" ::"v"(lds0 + byte_off), "v"(d) : "memory");
     };
-    auto lds_store16 = [&](unsigned byte_off, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + byte_off), "v"(v) : "memory"); };
 
     // ---- columns of this workgroup: as conv_roll (XCD-contiguous ranges, round-robin inside the XCD) ----------------
     const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
@@ -1130,7 +1129,6 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
         const u32x2 d = {v0, v1};
         asm volatile("ds_write_b64 %0, %1" ::"v"(lds0 + byte_off), "v"(d) : "memory");
     };
-    auto lds_store16 = [&](unsigned byte_off, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + byte_off), "v"(v) : "memory"); };
 
     const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     int ufirst, uend;
@@ -1612,7 +1610,7 @@ template <int PREC>
 __global__ __launch_bounds__(256) void of_s2_kernel(const SrdArgs a) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
-    constexpr int CI = 8, C = 16, TY = 8, TX = 16, NWAVES = 4;
+    constexpr int CI = 8, C = 16, TY = 8, TX = 16;
     constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;               // t region
     constexpr int XY = 2 * TYT + 1, XX = 2 * TXT + 1, XPIX = XY * XX, XEV = TXT + 1;   // input footprint; XEV even columns per row
     constexpr int XPIXB = CI * 2, PIXB = C * 2;
