@@ -1,10 +1,14 @@
 /* Minimal C host of libdffw.so: no PyTorch, no C++ — HIP runtime + the C ABI of include/dffw.h only.
  *
- *   c_host <weights.bin> <input.bin> <output.bin>
+ *   c_host <weights.bin> <input.bin> <output.bin> [e2e]
  *
  * weights.bin : int32 n, then n x { int32 name_len, name bytes, int64 numel, numel x float32 }
- * input.bin   : int32 B, N, H, W, then FS (B,3,N,H,W) float32, then focus_dists (B,N) float32 (broadcast over H,W)
- * output.bin  : 4 x (B,H,W) float32 = mid_out, pred1, pred2, pred3
+ * input.bin   : int32 B, N, H, W, then FS (B,3,N,H,W) float32, then focus_dists (B,N) float32 (broadcast over H,W);
+ *               with `e2e`: then the relative fields of view (B,N) float32
+ * output.bin  : 4 x (B,H,W) float32 = mid_out, pred1, pred2, pred3; with `e2e`: then the aligned stack (B,3,N,H,W)
+ *
+ * `e2e` = the End_to_End variant: a DFFW_NET_E2E engine (522-entry state dict) and dffw_forward_e2e in place of
+ * `mid, p1, p2, p3, aligned = model(FS, focus_dists, FOVs)` (End_to_End/TRS.py:44).
  *
  * Build (tests/test_c_host.py does this):
  *   gcc -std=c11 -D__HIP_PLATFORM_AMD__ examples/c_host.c -I/opt/rocm/include -Iinclude -Ldffinthewild_amd -ldffw \
@@ -25,7 +29,8 @@
 static int read_all(FILE *f, void *dst, size_t bytes) { return fread(dst, 1, bytes, f) == bytes ? 0 : -1; }
 
 int main(int argc, char **argv) {
-    if (argc != 4) { fprintf(stderr, "usage: %s weights.bin input.bin output.bin\n", argv[0]); return 1; }
+    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: %s weights.bin input.bin output.bin [e2e]\n", argv[0]); return 1; }
+    const int e2e = argc == 5;
     FILE *fw = fopen(argv[1], "rb");
     if (!fw) { perror(argv[1]); return 1; }
     int32_t n = 0;
@@ -52,16 +57,18 @@ int main(int argc, char **argv) {
     const int B = dims[0], N = dims[1], H = dims[2], W = dims[3];
     const size_t fs_elems = (size_t)B * 3 * N * H * W, fd_elems = (size_t)B * N, map_elems = (size_t)B * H * W;
     float *h_fs = (float *)malloc(fs_elems * sizeof(float)), *h_fd = (float *)malloc(fd_elems * sizeof(float));
+    float *h_fov = (float *)malloc(fd_elems * sizeof(float));
     if (read_all(fi, h_fs, fs_elems * sizeof(float)) || read_all(fi, h_fd, fd_elems * sizeof(float))) return 1;
+    if (e2e && read_all(fi, h_fov, fd_elems * sizeof(float))) return 1;
     fclose(fi);
 
     dffw_engine *eng = NULL;
     CHECK_HIP(hipSetDevice(0));
-    CHECK_DFFW(dffw_engine_create(0, DFFW_NET_DEPTH, tensors, n, DFFW_PREC_BF16X3, &eng));
+    CHECK_DFFW(dffw_engine_create(0, e2e ? DFFW_NET_E2E : DFFW_NET_DEPTH, tensors, n, DFFW_PREC_BF16X3, &eng));
     const int64_t ws_bytes = dffw_workspace_bytes(eng, B, N, H, W);
     if (ws_bytes < 0) { fprintf(stderr, "workspace: %s\n", dffw_last_error()); return 3; }
 
-    float *d_fs = NULL, *d_fd = NULL, *d_out[4] = {NULL, NULL, NULL, NULL};
+    float *d_fs = NULL, *d_fd = NULL, *d_fov = NULL, *d_aligned = NULL, *d_out[4] = {NULL, NULL, NULL, NULL};
     void *d_ws = NULL;
     hipStream_t stream;
     CHECK_HIP(hipStreamCreate(&stream));
@@ -73,7 +80,14 @@ int main(int argc, char **argv) {
     CHECK_HIP(hipMemcpyAsync(d_fd, h_fd, fd_elems * sizeof(float), hipMemcpyHostToDevice, stream));
 
     const int64_t fd_strides[4] = {N, 1, 0, 0}; /* (B,N) values broadcast over rows and columns */
-    CHECK_DFFW(dffw_forward(eng, d_fs, d_fd, fd_strides, B, N, H, W, d_out, d_ws, ws_bytes, stream));
+    if (e2e) {
+        CHECK_HIP(hipMalloc((void **)&d_fov, fd_elems * sizeof(float)));
+        CHECK_HIP(hipMalloc((void **)&d_aligned, fs_elems * sizeof(float)));
+        CHECK_HIP(hipMemcpyAsync(d_fov, h_fov, fd_elems * sizeof(float), hipMemcpyHostToDevice, stream));
+        CHECK_DFFW(dffw_forward_e2e(eng, d_fs, d_fd, fd_strides, d_fov, B, N, H, W, d_out, d_aligned, d_ws, ws_bytes, stream, NULL, 0));
+    } else {
+        CHECK_DFFW(dffw_forward(eng, d_fs, d_fd, fd_strides, B, N, H, W, d_out, d_ws, ws_bytes, stream));
+    }
     CHECK_HIP(hipStreamSynchronize(stream));
 
     FILE *fo = fopen(argv[3], "wb");
@@ -83,8 +97,14 @@ int main(int argc, char **argv) {
         CHECK_HIP(hipMemcpy(h_map, d_out[k], map_elems * sizeof(float), hipMemcpyDeviceToHost));
         fwrite(h_map, sizeof(float), map_elems, fo);
     }
+    if (e2e) {
+        float *h_al = (float *)malloc(fs_elems * sizeof(float));
+        CHECK_HIP(hipMemcpy(h_al, d_aligned, fs_elems * sizeof(float), hipMemcpyDeviceToHost));
+        fwrite(h_al, sizeof(float), fs_elems, fo);
+    }
     fclose(fo);
     dffw_engine_destroy(eng);
-    printf("%s: %d stacks of %dx%dx%d -> 4 depth maps, workspace %lld bytes\n", dffw_version(), B, N, H, W, (long long)ws_bytes);
+    printf("%s: %d stacks of %dx%dx%d -> 4 depth maps%s, workspace %lld bytes\n", dffw_version(), B, N, H, W, e2e ? " + aligned stack" : "",
+           (long long)ws_bytes);
     return 0;
 }

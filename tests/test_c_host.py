@@ -52,3 +52,45 @@ def test_c_host_forward_matches_reference_golden(lib_built, tmp_path):
         ref = g[name].astype(np.float64)
         err = np.linalg.norm(out[i].astype(np.float64).ravel() - ref.ravel()) / np.linalg.norm(ref.ravel())
         assert err <= 1e-3, (name, err)
+
+
+@pytest.mark.gpu
+def test_c_host_e2e_forward_matches_reference_golden(lib_built, tmp_path):
+    """The End_to_End variant from the same C host (`c_host ... e2e`): DFFW_NET_E2E engine from the 522-entry state dict,
+    dffw_forward_e2e, against the golden the reference's End_to_End.Network produced (BASELINE config 5's call path without torch)."""
+    import glob
+    from oracle.make_goldens_e2e import net_inputs
+    path = [p for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "e2e_net_*.npz"))) if "smooth_64x96" in p][0]
+    g = np.load(path)
+    sd = synth.state_dict_numpy(list(graph.param_entries(graph.e2e_convs())), seed=int(g["wseed"]), profile=str(g["profile"]))
+    FS, fd, fov = net_inputs(int(g["H"]), int(g["W"]), int(g["iseed"]))
+    FS, fd, fov = (np.asarray(t, dtype=np.float32) for t in (FS, fd, fov))
+    B, _, N, H, W = FS.shape
+    with open(tmp_path / "weights.bin", "wb") as f:
+        floats = [(k, np.asarray(v)) for k, v in sd.items() if np.asarray(v).dtype == np.float32]
+        f.write(struct.pack("<i", len(floats)))
+        for k, v in floats:
+            name = k.encode()
+            f.write(struct.pack("<i", len(name)) + name + struct.pack("<q", v.size) + np.ascontiguousarray(v).tobytes())
+    with open(tmp_path / "input.bin", "wb") as f:
+        f.write(struct.pack("<4i", B, N, H, W) + np.ascontiguousarray(FS).tobytes() +
+                np.ascontiguousarray(fd.reshape(B, N)).tobytes() + np.ascontiguousarray(fov.reshape(B, N)).tobytes())
+    exe = build(tmp_path)
+    run = subprocess.run([exe, str(tmp_path / "weights.bin"), str(tmp_path / "input.bin"), str(tmp_path / "out.bin"), "e2e"],
+                         capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    out = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    maps, aligned = out[:4 * B * H * W].reshape(4, B, H, W), out[4 * B * H * W:].reshape(B, 3, N, H, W)
+
+    def rel(a, b):
+        a, b = a.astype(np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+        return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+    checked = 0
+    for i, name in enumerate(("mid_out", "pred1", "pred2", "pred3")):
+        if name in g.files:
+            assert rel(maps[i], g[name]) <= 1e-3, name
+            checked += 1
+    assert checked >= 1
+    if "aligned" in g.files:
+        assert rel(aligned, g["aligned"]) <= 1e-3
