@@ -1119,7 +1119,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1139,6 +1139,8 @@ struct Switches {
         s.small_max_units = geti("DFFW_SMALL_MAX_UNITS", 0, 0);   // (256 measured 6 % faster on one 5x224x224 stack, level on 10x256x256 -- but a
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
+        s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
+                                                                  // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
         { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
         { const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS"); s.concurrent_max_pixels = z ? atoll(z) : -1; }
@@ -1375,7 +1377,7 @@ struct Run {
         }
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
-            (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= 256 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_T32)) {
+            (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= sw.roll_min_units && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_T32)) {
             if (dry) return out;
             a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
             a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
@@ -1417,7 +1419,7 @@ struct Run {
             int sty, stx;
             s2_roll_tile(ntk, &sty, &stx);
             if ((L.cout / 16) % ntk == 0 && Ho % sty == 0 && Wo % stx == 0 && in0.H == 2 * Ho && in0.W == 2 * Wo &&
-                (int64_t)in0.B * (Ho / sty) * (Wo / stx) >= 256) {
+                (int64_t)in0.B * (Ho / sty) * (Wo / stx) >= sw.roll_min_units) {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
@@ -1452,7 +1454,7 @@ struct Run {
             int ety, etx;
             efd_roll_tile(&ety, &etx);
             if (pc.wroll8 && !L.transposed && L.sh == 2 && in0.C == 8 && !o.in1 && !o.res0 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre &&
-                !o.cls && Ho % ety == 0 && Wo % etx == 0 && (int64_t)in0.B * (Ho / ety) * (Wo / etx) >= 256 && !sw.on(SW_NO_ROLL) &&
+                !o.cls && Ho % ety == 0 && Wo % etx == 0 && (int64_t)in0.B * (Ho / ety) * (Wo / etx) >= sw.roll_min_units && !sw.on(SW_NO_ROLL) &&
                 !sw.on(SW_NO_ROLL_S2)) {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
@@ -1485,7 +1487,7 @@ struct Run {
             roll_tile(&rty, &rtx);
             const int cols = (in0.H / rty) * (in0.W / rtx);
             if (pc.wroll_t && in0.H % rty == 0 && in0.W % rtx == 0 && in0.C == 16 && !o.in1 && !o.res_bcast && !o.res1 && !o.outf &&
-                (int64_t)in0.B * cols >= 256 && !sw.on(SW_NO_ROLL)) {
+                (int64_t)in0.B * cols >= sw.roll_min_units && !sw.on(SW_NO_ROLL)) {
                 if (dry) return out;
                 a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
                 a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
@@ -1528,7 +1530,7 @@ struct Run {
             roll_tile(&rty, &rtx);
             const int cols = (Ho / rty) * (Wo / rtx);
             if (pc.wroll && Ho % rty == 0 && Wo % rtx == 0 && in0.C % 8 == 0 && (!o.in1 || o.in1->C == in0.C) && !o.res_bcast && !o.res1 &&
-                (int64_t)in0.B * cols >= 256 && !sw.on(SW_NO_ROLL)) {
+                (int64_t)in0.B * cols >= sw.roll_min_units && !sw.on(SW_NO_ROLL)) {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
@@ -1858,7 +1860,7 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
         if ((x.C == 8 || (x.C == 16 && !r.sw.on(SW_NO_FUSED_SRD16))) && c0 != end && c2 != end && a3 != end && a1 != end &&
             c0->second.wsrd && c2->second.wsrd && a3->second.w32 &&
             a1->second.w32 && a3->second.watt && a1->second.watt && a3->second.def.kd == 3 && a1->second.def.kd == 1 &&
-            x.H % sty == 0 && x.W % stx == 0 && x.H % 2 == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= 256 &&
+            x.H % sty == 0 && x.W % stx == 0 && x.H % 2 == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= r.sw.roll_min_units &&
             !r.sw.on(SW_NO_FUSED_SRD) && !r.sw.on(SW_NO_FUSED_ATTENTION) && !r.sw.on(SW_NO_TILE)) {
             Act out = r.act(x.B, x.N, x.H, x.W, x.C);
             const bool with_pool = pooled && !r.sw.on(SW_NO_FUSED_POOL);
@@ -1947,7 +1949,7 @@ static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr
         const int Ho = x.H / 2, Wo = x.W / 2;
         const auto end = r.e->convs.end();
         if (x.C == 8 && pooled && pooled->p && ca != end && cb != end && ca->second.wroll8 && cb->second.wroll8 && x.H % 2 == 0 && x.W % 2 == 0 &&
-            Ho % ty == 0 && Wo % tx == 0 && (int64_t)x.B * (Ho / ty) * (Wo / tx) >= 256 && !r.sw.on(SW_NO_ROLL) &&
+            Ho % ty == 0 && Wo % tx == 0 && (int64_t)x.B * (Ho / ty) * (Wo / tx) >= r.sw.roll_min_units && !r.sw.on(SW_NO_ROLL) &&
             !r.sw.on(SW_NO_FUSED_EFD) && !r.sw.on(SW_NO_TILE)) {
             Act out = r.act(x.B, x.N, Ho, Wo, 16);
             if (r.ok() && !r.dry) {
@@ -2236,7 +2238,7 @@ static Act of_block(Run &r, const std::string &p, const Act &x) {
         const int co = (c0 != end) ? c0->second.def.cout : 0;
         if (r.e->convs.find(p + ".feature") == end && c0 != end && c2 != end && c0->second.wsrd && c2->second.wsrd && (x.C == 8 || x.C == 16) &&
             (co == 16 || (co == 8 && x.C == 8)) && c2->second.def.cout == co && c2->second.cin_all == co + x.C && x.H % 8 == 0 && x.W % 16 == 0 &&
-            (int64_t)x.B * (x.H / 8) * (x.W / 16) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
+            (int64_t)x.B * (x.H / 8) * (x.W / 16) >= r.sw.roll_min_units && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
             Act out = r.act(x.B, x.N, x.H, x.W, co);
             if (r.ok() && !r.dry) {
                 if (r.e->ensure_zero_page() != DFFW_OK) { r.err = DFFW_EHIP; return out; }
@@ -2269,7 +2271,7 @@ static Act of_block(Run &r, const std::string &p, const Act &x) {
         const auto end = r.e->convs.end();
         if (c0 != end && c2 != end && cf != end && x.C == 8 && c0->second.wsrd && c2->second.wsrd && cf->second.wsrd && c0->second.def.sh == 2 &&
             c0->second.def.cout == 16 && c2->second.def.cout == 16 && c2->second.cin_all == 16 && cf->second.def.sh == 2 && cf->second.def.cout == 16 &&
-            x.H % 16 == 0 && x.W % 32 == 0 && (int64_t)x.B * (x.H / 16) * (x.W / 32) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
+            x.H % 16 == 0 && x.W % 32 == 0 && (int64_t)x.B * (x.H / 16) * (x.W / 32) >= r.sw.roll_min_units && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
             Act out = r.act(x.B, x.N, x.H / 2, x.W / 2, 16);
             if (r.ok() && !r.dry) {
                 SrdArgs a;
@@ -2324,7 +2326,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
         const auto end = r.e->convs.end();
         const bool first = c0 != end && c2 != end && r.e->convs.find(p0 + ".feature") == end && c0->second.wsrd && c2->second.wsrd &&
                            c0->second.def.cin == 3 && c0->second.def.cout == 8 && c2->second.def.cout == 8 && c2->second.cin_all == 16 && H % 8 == 0 &&
-                           W % 16 == 0 && (int64_t)B * (H / 8) * (W / 16) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_OF_FIRST) &&
+                           W % 16 == 0 && (int64_t)B * (H / 8) * (W / 16) >= r.sw.roll_min_units && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_OF_FIRST) &&
                            !r.sw.on(SW_NO_TILE);
         if (first) {
             a0 = r.act(B, N, H, W, 8);
@@ -2393,7 +2395,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             auto ccur = r.e->convs.find(hp + ".0.0#cur");
             const bool roll = (fe.C == 8 || fe.C == 16) && ccur != r.e->convs.end() && ccur->second.wsrd && ccur->second.def.cin == fe.C + 2 &&
                               ccur->second.def.cout == 2 * fe.C && fe.H % 8 == 0 &&
-                              fe.W % 16 == 0 && (int64_t)B * (fe.H / 8) * (fe.W / 16) >= 256 && !r.sw.on(SW_NO_HEAD_WARP) && !r.sw.on(SW_NO_TILE);
+                              fe.W % 16 == 0 && (int64_t)B * (fe.H / 8) * (fe.W / 16) >= r.sw.roll_min_units && !r.sw.on(SW_NO_HEAD_WARP) && !r.sw.on(SW_NO_TILE);
             Act vol;
             if (!roll) vol = r.act(B, N, fe.H, fe.W, fe.C + 8);
             if (r.ok() && !r.dry) {
@@ -2462,7 +2464,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             const auto end = r.e->convs.end();
             if (y0.C == 16 && c2 != end && c4 != end && c2->second.wsrd && c4->second.wsrd && c2->second.def.cout == 16 && c4->second.def.cout == 16 &&
                 c2->second.cin_all == 16 && c4->second.cin_all == 16 && y0.H % 8 == 0 && y0.W % 16 == 0 &&
-                (int64_t)y0.B * (y0.H / 8) * (y0.W / 16) >= 256 && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
+                (int64_t)y0.B * (y0.H / 8) * (y0.W / 16) >= r.sw.roll_min_units && !r.sw.on(SW_NO_FUSED_OF) && !r.sw.on(SW_NO_TILE)) {
                 // ... and when the head's tail runs as plane sums, the pair's output is not stored either: the kernel leaves nine
                 // 16-channel vectors per (slice, column) and head_tail_finish_tiles does the rest
                 const bool sums = tail_sums && c6->second.def.cin == 16 && !r.sw.on(SW_NO_HEAD_SUMS_FUSED);
