@@ -1119,7 +1119,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1139,6 +1139,7 @@ struct Switches {
         s.small_max_units = geti("DFFW_SMALL_MAX_UNITS", 0, 0);   // (256 measured 6 % faster on one 5x224x224 stack, level on 10x256x256 -- but a
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
+        s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
@@ -1656,7 +1657,9 @@ struct Run {
 #endif
             if (!use_pp && !t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
                 !sw.on(SW_NO_SPLITK)) {
-                const int want = 256 / (t.total_tiles * t.nsplit);
+                // enough splits for ~two workgroups per CU (measured 256 ... 768 at batch 1 / 4 and on one End_to_End stack: 512 is 3-4 %
+                // faster than the earlier floor(256 / n), which left 129 ... 192-workgroup launches unsplit)
+                const int want = (sw.ksplit_target + t.total_tiles * t.nsplit - 1) / (t.total_tiles * t.nsplit);
                 t.ksplit = std::max(1, std::min(std::min(tp.nstage, want), 8));
                 if (t.ksplit > 1) {
                     t.partial_stride = M_out * (int64_t)pc.nt * 16;
