@@ -276,34 +276,69 @@ def launch_ranks(n):
     through; the exit code is the worst child's."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's stdout goes to a file, not a pipe: nobody has to drain it while the children are polled
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # poll: the first rank that fails (or an overall timeout) takes its siblings down instead of leaving them -- and this
+        # parent -- parked in the rendezvous or in a collective for good
+        deadline = time.time() + float(os.environ.get("DFFW_BENCH_TIMEOUT_S", "1500"))
+        codes = [None] * n
+        failed = None
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+                    if codes[i] not in (None, 0) and failed is None:
+                        failed = i
+            if failed is not None or time.time() > deadline:
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        p.terminate()
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        try:
+                            codes[i] = p.wait(timeout=10)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            codes[i] = p.wait()
+                if failed is None:
+                    sys.stderr.write("bench.py: ranks did not finish in time, terminated\n")
+                    codes = [c if c else 124 for c in codes]
+                else:
+                    sys.stderr.write(f"bench.py: rank {failed} exited with {codes[failed]}, the other ranks were terminated\n")
+                break
+            time.sleep(0.05)
+        out0.seek(0)
+        out = out0.read()
     # rank 0's stdout also carries the communication library's banner lines: pass on the JSON line only (the rest to stderr)
-    for line in out.decode().splitlines():
+    for line in out.decode(errors="replace").splitlines():
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
+    if failed is not None:
+        return abs(codes[failed]) or 1
     return max(abs(c) for c in codes)
 
 
 def measure_allgather(local, world, iters=20):
     """The step's one collective on its own: RCCL all-gather of this rank's pred3 maps, timed over `iters` calls between
     device synchronisations (max over ranks).  bus GB/s = bytes every rank receives from the others / time."""
+    total = world * local.shape[0]          # equal shards: exactly one all_gather_into_tensor per call, as in the timed step
     for _ in range(3):
-        ddist.all_gather_depth(local)
+        ddist.all_gather_depth(local, total=total)
     torch.cuda.synchronize()
     torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(iters):
-        ddist.all_gather_depth(local)
+        ddist.all_gather_depth(local, total=total)
     torch.cuda.synchronize()
     t = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=local.device)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -379,7 +414,9 @@ def main():
     def step():
         with torch.no_grad():
             outs = model.forward_raw(raw_u8, fd, "NHWC") if raw_u8 is not None else model(*inputs)
-            gathered = ddist.all_gather_depth(outs[3]) if world > 1 else outs[3]
+            # every rank runs B stacks: the total is known, so the step's only collective is ONE all_gather_into_tensor (no size
+            # negotiation, no host sync)
+            gathered = ddist.all_gather_depth(outs[3], total=world * B) if world > 1 else outs[3]
         return outs, gathered
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):

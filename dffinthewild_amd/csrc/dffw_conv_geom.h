@@ -1,4 +1,4 @@
-// Device-side geometry/tile templates shared by conv_tile and conv_stream.
+// Device-side geometry/tile templates of conv_tile.
 #pragma once
 #include "dffw_conv_tile.h"
 #include "dffw_device.h"

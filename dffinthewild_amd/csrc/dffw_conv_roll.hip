@@ -174,6 +174,10 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
         voff[0] = (prow * a.Wo + pcol) * (PARTS * 8) + ((PARTS == 2) ? (g & 1) * 8 : (g & 1) * 4);
     }
     const bool packed = !PAIR && (a.Cout == 8 && !a.outf && MTW % 2 == 0);   // two 8-channel result tiles share one epilogue
+    // the common epilogue "out = [relu](acc [+ residual])" takes the straight-line routine (dffw_device.h: epilogue_lean)
+    const bool lean = PARTS == 2 && a.out && !a.out_pre && !a.cls_w && !a.outf && !a.res1 && !a.res_bcast && a.relu != 2 && (RES || !a.res0) &&
+                      (PAIR || packed || a.Cout == 16);
+    const bool lean_relu = a.relu == 1;
 
     // Ring protocol.  Window n of the stream reads slices n, n+1, n+2 (ring slots n, n+1, n+2 mod RING).  The prologue
     // queues slices 0 .. RING-2; iteration n queues slice n+RING-1 into the slot of slice n-1 (every wave left it
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     int sidx = 0;   // ring slot of the window's first slice
+    StepTrace trc(a.trace, wave, lane, NWAVES);
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         const int64_t obase0 = (((int64_t)U.b * a.No + U.zbeg) * a.Ho + U.gy0) * a.Wo + U.gx0;
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
             const bool live = st < U.nz;   // windows starting on the unit's last two slices straddle two units: no output
             const int64_t obase = obase0 + (int64_t)st * a.Ho * a.Wo;
             const int64_t ubase = obase * (PARTS * a.Cout);
+            trc.stamp(0);
             // residual pieces of this step's outputs: requested BEFORE this iteration's slice so that the counted wait
             // below covers them (an ordinary load would make hipcc drain the whole DMA queue at its first use)
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
                 }
             }
             if (!(a.dbg & 1)) issue_next();
+            trc.stamp(1);
 
             f32x4 acc[MTW];
 #pragma unroll
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
                 }
             }
 
+            trc.stamp(2);
             // slice n+3 has landed for this wave's pieces (and this step's residual pieces, which are older); after the
             // barrier for everyone's, and everyone is done reading slice n (its slot is the next DMA target).  The stores
             // below get a whole iteration to drain.
@@ -317,10 +325,41 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
                 for (int j = 0; j < MTW; ++j) asm volatile("" : "+v"(rq[j]));
             }
             sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
-            if (!live) continue;
+            trc.stamp(3);
+            if (!live) {
+                trc.next();
+                continue;
+            }
             if ((a.dbg & 4) && acc[0][0] != 12345.f) continue;
 
             // ---- epilogue of output slice zbeg + st (shared with conv_tile / conv_igemm) ----------------------------
+            if constexpr (PARTS == 2) {
+                if (lean) {
+                    uint16_t *ob = a.out + ubase;
+                    if constexpr (PAIR) {
+                        epilogue_lean<PREC, RES>(ob, voff[0], acc[0], RES ? make_uint4(rq[0][0], rq[0][1], rq[0][2], rq[0][3]) : uint4{}, lean_relu);
+                    } else if (packed) {
+#pragma unroll
+                        for (int j = 0; j + 1 < MTW; j += 2) {
+                            f32x4 q;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][i]), __float_as_uint(acc[j + 1][i]), false, false);
+                                q[i] = __uint_as_float(sw[0]);
+                            }
+                            const int vo = (lane >= 32) ? voff[j + 1] - 8 : voff[j];
+                            epilogue_lean<PREC, RES>(ob, vo, q, RES ? make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]) : uint4{}, lean_relu);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j)
+                            epilogue_lean<PREC, RES>(ob, voff[j], acc[j], RES ? make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]) : uint4{}, lean_relu);
+                    }
+                    trc.stamp(4);
+                    trc.next();
+                    continue;
+                }
+            }
             if constexpr (PAIR) {
                 // lane rows 0-1 hold the even pixel's 8 channels, rows 2-3 the odd pixel's: both are "rows g & 1" of their
                 // own pixel record, exactly the packed form of the 8-channel epilogue (no register shuffling needed)
@@ -358,6 +397,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
                     epilogue_cls(a, cls, g, opix, true);
                 }
             }
+            trc.stamp(4);
+            trc.next();
         }
     }
     // the slices queued past the end of the stream are still in flight: a wave must not retire before its LDS-DMA has

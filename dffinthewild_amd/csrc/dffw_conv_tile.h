@@ -76,10 +76,4 @@ const TileCfg *tile_cfg_at(int i);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
 void conv_tile_kernel_name(int prec, const TileCfg *cfg, bool splitk, char *buf, int n);
 
-// persistent warp-specialised variant (dffw_conv_stream.hip); a config matches conv_tile's packing when it
-// has the same (geo, nt, cg) AND the same tile dims (tap offsets depend on the footprint shape)
-const TileCfg *stream_cfg_find(int geo, int nt, int cg);
-hipError_t launch_conv_stream(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
-void conv_stream_kernel_name(int prec, const TileCfg *cfg, char *buf, int n);
-
 }  // namespace dffw

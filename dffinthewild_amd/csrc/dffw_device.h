@@ -99,6 +99,39 @@ __device__ __forceinline__ f32x4 mma(short8 a, short8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- step timeline of the persistent streaming kernels (make TRACE=1; DFFW_TRACE_LAYER / DFFW_TRACE_OUT, tools/trace_steps.py) ----
+// Lane 0 of every wave stamps s_memtime at up to 7 points of DFFW_TRACE_STEPS consecutive steps (after skipping the first
+// DFFW_TRACE_SKIP, i.e. the cold ring of the workgroup's first column); slot 7 of step 0 = XCC_ID << 32 | HW_ID.
+// Buffer: [workgroup][wave][step][8] u64.  Compiled out of production builds.
+#define DFFW_TRACE_STEPS 32
+#define DFFW_TRACE_SKIP 14
+struct StepTrace {
+#ifdef DFFW_TRACE_BUILD
+    unsigned long long *p;
+    int n;
+    __device__ __forceinline__ StepTrace(unsigned long long *base, int wave, int lane, int nwaves) {
+        p = (base && lane == 0) ? base + ((int64_t)blockIdx.x * nwaves + wave) * (DFFW_TRACE_STEPS * 8) : nullptr;
+        n = -DFFW_TRACE_SKIP;
+    }
+    __device__ __forceinline__ void stamp(int k) {
+        if (p && n >= 0 && n < DFFW_TRACE_STEPS) p[n * 8 + k] = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void next() {
+        if (p && n == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p[7] = ((unsigned long long)xcc << 32) | hwid;
+        }
+        ++n;
+    }
+#else
+    __device__ __forceinline__ StepTrace(unsigned long long *, int, int, int) {}
+    __device__ __forceinline__ void stamp(int) {}
+    __device__ __forceinline__ void next() {}
+#endif
+};
+
 // ---- conv epilogue shared by conv_igemm and conv_tile ---------------------------------------------------
 // One call handles, for every lane of the wave, the 4 output channels c0 = nt*16 + g*4 .. +3 of the
 // lane's grid point (the v_mfma_f32_16x16x32 result layout): BatchNorm shift, optional copy of the
@@ -270,6 +303,41 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
         }
         if (a.out) store4(a.out);
     }
+}
+
+// Lean epilogue of the streaming kernels for the common case "out = relu(acc [+ residual])" in split-bf16 storage: the same
+// arithmetic and the same instructions as epilogue_quad<PREC, PRE, FAST> takes for that case (bit-identical results), but
+// straight-line: the generic routine tests nine ConvArgs fields per call and its ~25 taken branches, SGPR spills and AGPR round
+// trips cost ~1100 cycles per operand tile in the rolling kernels (step timeline, profiles/r03_step_timeline_*.txt), a third
+// of a step.  `out` = wave-uniform pointer of the step's first output element, `voff` = the lane's element offset (16-byte piece).
+// MUST be called by all 64 lanes (v_permlane16_swap).
+template <int PREC, bool RES>
+__device__ __forceinline__ void epilogue_lean(uint16_t *__restrict__ out, int voff, const f32x4 &acc, uint4 rq, bool relu) {
+    static_assert(Fmt<PREC>::PARTS == 2, "split-bf16 storage only");
+    float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
+    if constexpr (RES) {
+        swap16(rq.x, rq.z);
+        swap16(rq.y, rq.w);
+        float r0, r1, r2, r3;
+        Fmt<PREC>::join2(rq.x, rq.z, r0, r1);
+        Fmt<PREC>::join2(rq.y, rq.w, r2, r3);
+        v0 += r0;
+        v1 += r1;
+        v2 += r2;
+        v3 += r3;
+    }
+    if (relu) {
+        v0 = relu_bits(v0);
+        v1 = relu_bits(v1);
+        v2 = relu_bits(v2);
+        v3 = relu_bits(v3);
+    }
+    uint32_t h01, h23, l01, l23;
+    Fmt<PREC>::split2(v0, v1, h01, l01);
+    Fmt<PREC>::split2(v2, v3, h23, l23);
+    swap16(h01, l01);
+    swap16(h23, l23);
+    *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(out) + (uint32_t)(voff * 2)) = make_uint4(h01, h23, l01, l23);
 }
 
 // finish the fused 1x1x1 classifier: sum the partial dots of the 4 lane rows, row 0 writes the score

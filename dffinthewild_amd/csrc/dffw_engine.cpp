@@ -19,9 +19,6 @@
 #include "dffw_conv_roll.h"
 #include "dffw_srd_roll.h"
 #include "dffw_conv_tile.h"
-#ifdef DFFW_WITH_PP
-#include "dffw_conv_pp.h"
-#endif
 #include "dffw_internal.h"
 
 namespace dffw {
@@ -1110,7 +1107,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(STREAM) X(PP) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST)
+    X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1119,7 +1116,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, pp_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1135,7 +1132,6 @@ struct Switches {
         };
         s.roll_wgs = geti("DFFW_ROLL_WGS", 8, 0);
         s.srd_wgs = geti("DFFW_SRD_WGS", 8, 0);
-        s.pp_wgs = geti("DFFW_PP_WGS", 8, 0);
         s.small_max_units = geti("DFFW_SMALL_MAX_UNITS", 0, 0);   // (256 measured 6 % faster on one 5x224x224 stack, level on 10x256x256 -- but a
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
@@ -1279,6 +1275,32 @@ struct Run {
     }
     double elem_bytes() const { return 2.0 * prec_parts(e->prec); }
 
+    // step timeline of a persistent streaming kernel (library built with `make TRACE=1`; DFFW_TRACE_LAYER=<layer> DFFW_TRACE_OUT=<file>):
+    // [workgroup][wave][32 steps][8] u64 of s_memtime stamps (StepTrace, dffw_device.h; tools/trace_steps.py)
+    unsigned long long *trace_dev = nullptr;
+    size_t trace_n = 0;
+    unsigned long long *trace_begin(const std::string &layer, int wgs, int waves) {
+        if (dry || !ok() || !sw.trace_layer || !sw.trace_out || layer != sw.trace_layer) return nullptr;
+        trace_n = (size_t)wgs * waves * 32 * 8;
+        check(hipMalloc((void **)&trace_dev, trace_n * 8), "trace alloc");
+        if (ok()) check(hipMemsetAsync(trace_dev, 0, trace_n * 8, s), "trace memset");
+        return ok() ? trace_dev : nullptr;
+    }
+    void trace_end() {
+        if (!trace_dev) return;
+        if (ok()) {
+            std::vector<unsigned long long> host(trace_n);
+            check(hipStreamSynchronize(s), "trace sync");
+            check(hipMemcpy(host.data(), trace_dev, trace_n * 8, hipMemcpyDeviceToHost), "trace copy");
+            if (FILE *f = fopen(sw.trace_out, "wb")) {
+                fwrite(host.data(), 8, host.size(), f);
+                fclose(f);
+            }
+        }
+        (void)hipFree(trace_dev);
+        trace_dev = nullptr;
+    }
+
     // does the LDS-tiled kernel serve layer `name` for an output grid of gH x gW (same test as in conv())?
     bool tiled(const std::string &name, int gH, int gW) const {
         auto it = e->convs.find(name);
@@ -1366,7 +1388,7 @@ struct Run {
         a.relu = o.relu;
         if (!dry && e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
-        a.dbg = sw.debug_flags & (7 | 48 | 64);
+        a.dbg = sw.debug_flags & 7;   // ablation switches only (1 no fill, 2 no MFMA loop, 4 no stores); bit 5 below is DFFW_NO_SMALL's own
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
         if (o.sums) {
             if (!sums_conv_ok(name, in0.B, in0.N, in0.H, in0.W) || o.relu != 1 || o.res0 || o.res1 || o.cls || o.out_pre || o.in1) {
@@ -1561,8 +1583,10 @@ struct Run {
                                          + 27.0 * L.cin * L.cout * elem_bytes();
                     prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout, bytes);
                 }
+                a.trace = trace_begin(name, 1024, 4);
                 check(launch_conv_roll(e->prec, a, t, s), name.c_str());
                 prof_end();
+                trace_end();
                 return out;
             }
         }
@@ -1611,29 +1635,6 @@ struct Run {
                     if (t.nsplit >= want) break;
                 }
             }
-            // ping-pong kernel (dffw_conv_pp.hip; rejected experiment, built only with `make PP=1` and selected with DFFW_PP=1:
-            // measured 8 % SLOWER than conv_tile on dres2.conv0): persistent workgroups whose wave groups
-            // alternate contraction and fill / epilogue
-            bool use_pp = false;
-#ifdef DFFW_WITH_PP
-            if (sw.on(SW_PP) && tp.cfg->nw == 4 && !o.outf && !o.cls && !o.res_bcast && !a.fs32 && tp.npass == 1) {
-                // the widest output-channel slab that has an instantiation and leaves at least two units per CU
-                const TileCfg *pcfg = nullptr;
-                int ns = 0;
-                for (int nts = tp.cfg->nt; nts >= 1; nts /= 2) {
-                    const TileCfg *c2 = nts == tp.cfg->nt ? tp.cfg : tile_cfg_find_like(tp.cfg, nts);
-                    if (!c2 || !conv_pp_has(c2)) continue;
-                    pcfg = c2;
-                    ns = tp.cfg->nt / nts;
-                    if (t.total_tiles * ns >= 512) break;
-                }
-                if (pcfg && t.total_tiles * ns >= 256) {
-                    use_pp = true;
-                    cfg = pcfg;
-                    t.nsplit = ns;
-                }
-            }
-#endif
             t.grid = 8 * ((t.total_tiles + 7) / 8);   // one tile per workgroup, grid a multiple of the 8 XCDs
             // split-K: when even the channel split leaves most CUs idle and the contraction is several channel-group
             // stages deep, the stages are dealt to grid.z workgroups (fp32 partials, summed in fixed order by
@@ -1644,18 +1645,7 @@ struct Run {
             // transposed conv on few tiles: its 4 sub-pixel passes as 4 workgroups (no reduction, any epilogue)
             const int thr = sw.split_wg;
             t.pass_split = (L.transposed && t.total_tiles * t.nsplit <= thr && !sw.on(SW_NO_SPLITK)) ? 1 : 0;
-#ifdef DFFW_WITH_PP
-            if (use_pp) {
-                t.pass_split = 0;
-                { const char *z = getenv("DFFW_PP_PACE"); t.ksplit = z ? atoi(z) : 1; }     // experiment knobs (not switches)
-                { const char *z = getenv("DFFW_PP_PRIO"); t.pass_split = z ? atoi(z) : 0; }
-                const int ng = conv_pp_groups(cfg);
-                const int sets = (t.total_tiles * t.nsplit + ng - 1) / ng;
-                t.grid = std::min(256, 8 * ((sets + 7) / 8));   // persistent: at most one workgroup (ng wave groups) per CU
-                if (sw.pp_wgs) t.grid = std::min(t.grid, sw.pp_wgs / 8 * 8);   // test knob: longer unit streams per workgroup
-            }
-#endif
-            if (!use_pp && !t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
+            if (!t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
                 !sw.on(SW_NO_SPLITK)) {
                 // enough splits for ~two workgroups per CU (measured 256 ... 768 at batch 1 / 4 and on one End_to_End stack: 512 is 3-4 %
                 // faster than the earlier floor(256 / n), which left 129 ... 192-workgroup launches unsplit)
@@ -1672,24 +1662,7 @@ struct Run {
                 drop_raw(partial);
                 return out;
             }
-            // persistent warp-specialised kernel when the layer has enough tiles to keep one workgroup per CU busy
-            // (rejected experiment, built only with `make STREAM=1`: persistent warp-specialised kernel)
-#ifdef DFFW_WITH_STREAM
-            const TileCfg *scfg = stream_cfg_find(cfg->geo, cfg->nt, cfg->cg);
-            const bool use_stream = scfg && scfg->tz == cfg->tz && scfg->ty == cfg->ty && scfg->tx == cfg->tx &&
-                                    t.total_tiles >= 1024 && sw.on(SW_STREAM);
-            if (use_stream) t.grid = 256;   // 8 XCDs x 32 CUs, one resident workgroup each
-#else
-            const TileCfg *scfg = nullptr;
-#endif
             auto kernel_name = [&](char *kn, int n) {
-#ifdef DFFW_WITH_STREAM
-                if (use_stream) return conv_stream_kernel_name(e->prec, scfg, kn, n);
-#endif
-                (void)scfg;
-#ifdef DFFW_WITH_PP
-                if (use_pp) return conv_pp_kernel_name(e->prec, cfg, kn, n);
-#endif
                 conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)), kn, n);
             };
             {
@@ -1707,39 +1680,6 @@ struct Run {
                                      + (double)L.kd * L.kh * L.kw * L.cin * L.cout * elem_bytes();
                 prof_begin(kn, name, flops, bytes);
             }
-#ifdef DFFW_WITH_STREAM
-            if (use_stream) {
-                check(launch_conv_stream(e->prec, scfg, a, t, s), name.c_str());
-                prof_end();
-                return out;
-            }
-#endif
-#ifdef DFFW_WITH_PP
-            if (use_pp) {
-                // debug timeline of one layer (make TRACE=1): DFFW_TRACE_LAYER=<layer name> DFFW_TRACE_OUT=<file>; per workgroup
-                // 512 slots x 2 groups x 4 x u64 (tools/trace_pp.py)
-                unsigned long long *trace = nullptr;
-                const size_t tbytes = (size_t)t.grid * 512 * 4 * 4 * 8;
-                if (sw.trace_layer && sw.trace_out && name == sw.trace_layer) {
-                    check(hipMalloc((void **)&trace, tbytes), "trace alloc");
-                    if (ok()) check(hipMemsetAsync(trace, 0, tbytes, s), "trace memset");
-                    a.trace = trace;
-                }
-                check(launch_conv_pp(e->prec, cfg, a, t, s), name.c_str());
-                prof_end();
-                if (trace && ok()) {
-                    std::vector<unsigned long long> host(tbytes / 8);
-                    check(hipStreamSynchronize(s), "trace sync");
-                    check(hipMemcpy(host.data(), trace, tbytes, hipMemcpyDeviceToHost), "trace copy");
-                    if (FILE *f = fopen(sw.trace_out, "wb")) {
-                        fwrite(host.data(), 8, host.size(), f);
-                        fclose(f);
-                    }
-                    (void)hipFree(trace);
-                }
-                return out;
-            }
-#endif
             // debug timeline of one layer: DFFW_TRACE_LAYER=<layer name> DFFW_TRACE_OUT=<file>; per tile 8 x u64
             // (s_memtime at start / fill issued / fill landed / contraction done / stores acknowledged, HW_ID)
             unsigned long long *trace = nullptr;
@@ -1889,8 +1829,10 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
                 const double px = (double)x.pixels();
                 // algorithmic: two 1x3x3 C -> C convs + the 3x1x1 and 1x1x1 attention convs; x read once, out (+ pooled) written once
                 r.prof_begin(kn, p, 2.0 * px * (2 * 9 + 4) * x.C * x.C, (with_pool ? 2.25 : 2.0) * px * x.C * r.elem_bytes());
+                a.trace = r.trace_begin(p, 1024, 4);
                 r.check(x.C == 16 ? launch_srd_roll16(r.e->prec, a, r.s) : launch_srd_roll(r.e->prec, a, r.s), "srd_roll");
                 r.prof_end();
+                r.trace_end();
             }
             if (drop_x) r.drop(x);
             return out;

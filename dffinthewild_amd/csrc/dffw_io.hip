@@ -415,40 +415,51 @@ extern "C" int dffw_probe_peaks(int device, float *mfma_tflops, float *hbm_gbs, 
     if (!mfma_tflops || !hbm_gbs) return dffw_fail(DFFW_EINVAL, "null argument");
     IO_HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)hip_stream;
-    hipEvent_t e0, e1;
-    IO_HIPCHK(hipEventCreate(&e0));
-    IO_HIPCHK(hipEventCreate(&e1));
+    // everything acquired here is released on every exit path
+    struct Guard {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        char *buf = nullptr;
+        ~Guard() {
+            if (buf) (void)hipFree(buf);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } gd;
+    IO_HIPCHK(hipEventCreate(&gd.e0));
+    IO_HIPCHK(hipEventCreate(&gd.e1));
     const int64_t bytes = (int64_t)1 << 30;
-    char *buf = nullptr;
-    IO_HIPCHK(hipMalloc((void **)&buf, 2 * bytes));
+    IO_HIPCHK(hipMalloc((void **)&gd.buf, 2 * bytes));
+    char *buf = gd.buf;
     IO_HIPCHK(hipMemsetAsync(buf, 1, 2 * bytes, s));
     float best_m = 1e30f, best_c = 1e30f, best_r = 1e30f, ms = 0.f;
     const int iters = 4000, blocks = 256 * 3;
     for (int rep = 0; rep < 4; ++rep) {   // first repetition = warm-up
-        IO_HIPCHK(hipEventRecord(e0, s));
+        IO_HIPCHK(hipEventRecord(gd.e0, s));
         hipLaunchKernelGGL(dffw::probe_mfma_kernel, dim3(blocks), dim3(256), 0, s, (float *)buf, iters, 7u + rep);
-        IO_HIPCHK(hipEventRecord(e1, s));
-        IO_HIPCHK(hipEventSynchronize(e1));
-        IO_HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        IO_HIPCHK(hipGetLastError());
+        IO_HIPCHK(hipEventRecord(gd.e1, s));
+        IO_HIPCHK(hipEventSynchronize(gd.e1));
+        IO_HIPCHK(hipEventElapsedTime(&ms, gd.e0, gd.e1));
         if (rep && ms < best_m) best_m = ms;
-        IO_HIPCHK(hipEventRecord(e0, s));
+        IO_HIPCHK(hipEventRecord(gd.e0, s));
         hipLaunchKernelGGL(dffw::probe_stream_kernel<0>, dim3(256 * 8), dim3(256), 0, s, (const float4 *)buf, (float4 *)(buf + bytes), bytes / 16);
-        IO_HIPCHK(hipEventRecord(e1, s));
-        IO_HIPCHK(hipEventSynchronize(e1));
-        IO_HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        IO_HIPCHK(hipGetLastError());
+        IO_HIPCHK(hipEventRecord(gd.e1, s));
+        IO_HIPCHK(hipEventSynchronize(gd.e1));
+        IO_HIPCHK(hipEventElapsedTime(&ms, gd.e0, gd.e1));
         if (rep && ms < best_c) best_c = ms;
-        IO_HIPCHK(hipEventRecord(e0, s));
+        IO_HIPCHK(hipEventRecord(gd.e0, s));
         hipLaunchKernelGGL(dffw::probe_stream_kernel<1>, dim3(256 * 8), dim3(256), 0, s, (const float4 *)buf, (float4 *)(buf + bytes), 2 * bytes / 16);
-        IO_HIPCHK(hipEventRecord(e1, s));
-        IO_HIPCHK(hipEventSynchronize(e1));
-        IO_HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        IO_HIPCHK(hipGetLastError());
+        IO_HIPCHK(hipEventRecord(gd.e1, s));
+        IO_HIPCHK(hipEventSynchronize(gd.e1));
+        IO_HIPCHK(hipEventElapsedTime(&ms, gd.e0, gd.e1));
         if (rep && ms < best_r) best_r = ms;
     }
+    if (!(best_m < 1e29f && best_c < 1e29f && best_r < 1e29f) || best_m <= 0.f || best_c <= 0.f || best_r <= 0.f)
+        return dffw_fail(DFFW_EHIP, "probe kernels were not timed");
     *mfma_tflops = (float)((double)blocks * 4 * iters * 10 * (2.0 * 16 * 16 * 32) / (best_m * 1e-3) / 1e12);
     // the better of the two streaming forms: copy of 1 GiB (read + write counted) and a pure read of 2 GiB
     *hbm_gbs = (float)std::max(2.0 * (double)bytes / (best_c * 1e-3) / 1e9, 2.0 * (double)bytes / (best_r * 1e-3) / 1e9);
-    (void)hipFree(buf);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return DFFW_OK;
 }

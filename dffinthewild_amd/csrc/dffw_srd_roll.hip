@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 
     int xslot = 0;
     f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
+    StepTrace trc(a.trace, wave, lane, NWAVES);
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         // Step s of a column: phase 1 = stage A of slice s (t = conv.0) on waves 2-3 (mostly) NEXT TO stage C of slice s-2
@@ -221,8 +222,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
             const bool produce = s < a.N;
             const unsigned fslot_off = F_OFF + (s % 3) * FSLOTB;
             // (1) this step's x slice has landed (for every wave after the barrier); feat[s-1] is complete
+            trc.stamp(0);
             if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            trc.stamp(1);
             if (s == 0 && tid * 16 < FSLOTB) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[-1] = 0: ring slot 2
 
             // ---- stage C: attention for slice z = s-2 out of feat[z-1], feat[z], feat[z+1]; wave w = pairs of rows 2w, 2w+1 ----
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     *reinterpret_cast<uint2 *>(a.out + pix * rec + (g & 1) * 4) = make_uint2(h01, h23);
                 }
             }
+            trc.stamp(2);
             // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ---------------------
             if (produce) {
 #pragma unroll
@@ -316,7 +320,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                 }
             }
             // (2) t complete, stage C has read its three feat slices
+            trc.stamp(3);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            trc.stamp(4);
             if (produce) {
                 // ---- stage B: feat[s] = relu(conv.2(t) + shift + x) ----------------------------------------------------
                 {
@@ -343,7 +349,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     vq0 = v;
                 }
                 // (3) feat[s] complete for everyone's reads of x: the x slot is free, queue the slice RX-1 ahead into it
+                trc.stamp(5);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                trc.stamp(6);
                 issue_next();
                 xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
             } else {
@@ -352,6 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
             if (s == a.N) {
                 if (tid * 16 < FSLOTB) lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[N] = 0
             }
+            trc.next();
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave

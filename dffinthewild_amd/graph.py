@@ -4,7 +4,7 @@ Every conv of ``DFF_net`` (reference ``Depth_Estimation_Test/Depth_Estimation_Ne
 131-330``) is one :class:`ConvSpec` row; the state-dict keys the reference's ``nn.Sequential``
 nesting produces (384 for ``Network``) are derived from the rows, so that a
 checkpoint written by the reference loads into :class:`dffinthewild_amd.Network` unchanged.
-The HIP engine carries the same table in C++ (``csrc/dffw_graph.h``); ``tests/test_boundary.py``
+The HIP engine carries the same table in C++ (``class Table`` in ``csrc/dffw_engine.cpp``); ``tests/test_boundary.py``
 checks the two against each other through ``dffw_param_info``.
 """
 from dataclasses import dataclass

@@ -267,7 +267,7 @@ def test_config3_batch32_two_goldens_and_properties(lib_built, monkeypatch):
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback
-    (conv_igemm, DFFW_NO_TILE), the persistent warp-specialised conv_stream (DFFW_STREAM), the un-split
+    (conv_igemm, DFFW_NO_TILE), the un-split
     few-tile launches, the unfused attention convs / pooling, and the narrow (4-wave, 16-channel-stage) tile variants."""
     path = [p for p in GOLDEN if which in p][0]
     g, meta, FS, fd, sd = case(path)

@@ -158,35 +158,6 @@ def test_conv_small_grids(eng, case, prec, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
-@pytest.mark.parametrize("cin,cout,B,N,H,W,residual,wgs", [(64, 32, 4, 10, 64, 64, False, 0), (32, 64, 2, 7, 64, 80, True, 0), (32, 32, 4, 5, 36, 64, True, 40),
-                                                           (64, 64, 8, 3, 32, 32, False, 16), (192, 128, 16, 10, 8, 8, False, 0), (128, 64, 16, 10, 16, 16, True, 8)])
-def test_conv_pp_ping_pong(eng, cin, cout, B, N, H, W, residual, wgs, prec, monkeypatch):
-    """conv_pp (dffw_conv_pp.hip; rejected experiment, `make PP=1`, skipped otherwise): the 3x3x3 stride-1 layers with >= 32 input channels (SPP stacks, dres0, hourglass
-    conv0/2/4: DEN.py:155-176, 37-40, 240-264) on persistent workgroups whose two wave groups alternate contraction and
-    fill / epilogue.  Slab splits (64 / 128 output channels as 2 / 8 slabs of 32 or 16), edge tiles in every direction
-    (7 slices, 36 rows, 80 columns vs 5 x 4 x 16 tiles), 2..12 channel-group stages, one unit pair per workgroup and long
-    unit streams (wgs), residual + ReLU epilogue, all three arithmetics; against F.conv3d and against conv_tile (DFFW_NO_PP)."""
-    x = rnd(B, cin, N, H, W, seed=31)
-    w = rnd(cout, cin, 3, 3, 3, seed=32, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
-    bn = bn_params(cout, 33)
-    res = rnd(B, cout, N, H, W, seed=34) if residual else None
-    ref = ref_bn(F.conv3d(x, w, None, 1, 1), bn)
-    ref = F.relu(ref + res) if residual else F.relu(ref)
-    if wgs:
-        monkeypatch.setenv("DFFW_PP_WGS", str(wgs))
-    monkeypatch.setenv("DFFW_PP", "1")
-    got = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
-    if not eng.last_conv_kernel().startswith("dffw::conv_pp<"):
-        pytest.skip("libdffw.so was built without the ping-pong experiment (make PP=1)")
-    assert rel(got, ref) <= TOL[prec], rel(got, ref)
-    monkeypatch.delenv("DFFW_PP")
-    alt = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
-    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
-    assert rel(alt, ref) <= TOL[prec]
-    assert rel(got, alt) <= TOL[prec] * 0.2
-
-
-@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("cout,N,H,W,zsplit,residual,wgs", [(8, 10, 128, 128, 1, True, 0), (16, 5, 128, 128, 1, False, 24), (8, 1, 64, 256, 1, False, 8),
                                                              (16, 10, 64, 256, 2, True, 40), (16, 7, 128, 128, 3, False, 0), (8, 2, 128, 128, 2, True, 16)])
 def test_conv_roll_rolling_window(eng, cout, N, H, W, zsplit, residual, wgs, prec, monkeypatch):

@@ -12,6 +12,44 @@ import torch
 from oracle import pipeline_ref as ref
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "io_jet.npz"))
+# outputs of the reference's own loader classes (oracle/make_goldens_pack.py: test_Dataloader.py / Test_dataloader.py compiled in
+# place, decode calls replaced by seeded arrays)
+PACK_CASES = ["fs6", "hci", "ddff", "smartphone", "middlebury", "real_scenes"]
+
+
+def pack_case(name):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"io_pack_{name}.npz"))
+    crop = tuple(int(v) for v in g["crop"])
+    return g, str(g["layout"]), (None if crop[0] < 0 else crop), bool(int(g["norm64"]))
+
+
+@pytest.mark.parametrize("name", PACK_CASES)
+def test_oracle_pack_stack_matches_reference_loaders(name):
+    """oracle pack_stack == the tensor the reference's loader returns, bit for bit, for all six loaders: FS6 and Middlebury
+    (float64 normalisation of a uint8 / float64 array, one rounding), HCI / DDFF / Smartphone / Real_Scenes (float32 arrays);
+    crops of the Smartphone (84 / 63 per side) and Real_Scenes (1/12 per side) loaders; -1 padding to multiples of 32."""
+    g, layout, crop, norm64 = pack_case(name)
+    want = g["FS"]
+    got = ref.pack_stack(g["raw"], layout, crop, norm64=norm64)
+    assert got.shape == want.shape and got.dtype == want.dtype == np.float32
+    assert np.array_equal(got, want)
+    if name in ("fs6", "middlebury"):                                   # the float32 arithmetic would NOT reproduce these loaders
+        assert not np.array_equal(ref.pack_stack(g["raw"], layout, crop), want)
+
+
+def test_real_scene_inputs_match_reference_loader():
+    """focus_dists = 1/d and the relative fields of view exactly as End_to_End/Test_dataloader.py:27-54 returns them (golden from the
+    reference's Real_Scenes class), through the oracle and the host-side helper; the crop helper gives the loader's border."""
+    from dffinthewild_amd import pipeline
+    g, _, crop, _ = pack_case("real_scenes")
+    d, f = [float(v) for v in g["focus_distance_m"]], float(g["focal_length"])
+    ofd, ofov = ref.real_scene_inputs(d, f)
+    assert np.array_equal(ofd, g["focus_dists"]) and np.array_equal(ofov, g["rel_fov"])
+    fd, fov = pipeline.real_scene_inputs(d, f, device="cpu")
+    assert np.array_equal(fd[0].numpy(), g["focus_dists"]) and np.array_equal(fov[0].numpy(), g["rel_fov"])
+    H, W = g["raw"].shape[:2]
+    assert pipeline.real_scene_crop(H, W) == crop
+    assert tuple(g["before_pad"]) == (crop[2], crop[3], 3, 10)
 
 
 def test_oracle_colorize_matches_matplotlib_golden():
@@ -152,6 +190,41 @@ def test_pack_stack_bit_exact(pl, layout, shape, crop, dtype):
     big = torch.from_numpy(np.stack([raw, raw[::-1].copy()])).cuda()
     got2 = pl.pack_stack(big, layout, crop)
     assert np.array_equal(got2[0].cpu().numpy(), want) and np.array_equal(got2[1].cpu().numpy(), ref.pack_stack(raw[::-1], layout, crop))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PACK_CASES)
+def test_pack_stack_matches_reference_loaders(pl, lib_built, name):
+    """dffw_pack_stack == the reference loader's tensor bit for bit (goldens of all six loaders), from the uint8 source and from its
+    float32 copy; dffw_forward_raw on the same source == forward of the loader's tensor (the stem's raw loader does the same
+    arithmetic while staging)."""
+    g, layout, crop, norm64 = pack_case(name)
+    want = g["FS"]
+    norm = "f64" if norm64 else "f32"
+    for raw in (g["raw"], g["raw"].astype(np.float32)):
+        got = pl.pack_stack(torch.from_numpy(raw).cuda(), layout, crop, norm=norm)
+        assert got.shape == (1,) + want.shape
+        assert np.array_equal(got[0].cpu().numpy(), want), (name, raw.dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ddff", "middlebury", "real_scenes"])
+def test_forward_raw_matches_forward_of_reference_loader_tensor(pl, lib_built, name):
+    from dffinthewild_amd import graph, synth
+    from dffinthewild_amd.Depth_Estimation_Network import Network
+    g, layout, crop, norm64 = pack_case(name)
+    FS = torch.from_numpy(g["FS"]).unsqueeze(0).cuda()
+    N = FS.shape[2]
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(list(graph.param_entries(graph.dff_net_convs())), seed=0, profile="smooth").items()}
+    model = Network()
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    fd = torch.linspace(0.1, 1.5, N).reshape(1, N, 1, 1).cuda()
+    with torch.no_grad():
+        a = model(FS, fd)
+        b = model.forward_raw(torch.from_numpy(g["raw"]).cuda(), fd, layout, crop=crop, norm="f64" if norm64 else "f32")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), name
 
 
 @pytest.mark.gpu
