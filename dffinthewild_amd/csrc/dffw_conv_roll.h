@@ -20,7 +20,10 @@ constexpr int ROLL_CHUNKS_PAIR = 18;   // pixel-pair form: 3 slices x 3 filter r
 
 void roll_tile(int *ty, int *tx);   // column footprint of the instantiated kernel
 hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n);
+// the launch's epilogue is one the straight-line routine covers (epilogue_lean, dffw_device.h) -> the LEAN instantiation runs; `res_variant`:
+// the kernel family has an instantiation that prefetches a residual
+bool roll_lean(int prec, const ConvArgs &a, bool res_variant);
+void conv_roll_kernel_name(int prec, const ConvArgs &a, bool pair, char *buf, int n);   // the instantiation launch_conv_roll picks for `a`
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
 // transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one
@@ -28,20 +31,20 @@ constexpr int ROLL_CHUNKS_T = 9;
 constexpr int ROLL_CHUNKS_T32_0 = 9, ROLL_CHUNKS_T32_1 = 18;
 void roll_t32_tile(int py, int *ty, int *tx);   // input-grid column of sweep py
 hipError_t launch_conv_roll_t32(int prec, int py, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_t32_kernel_name(int prec, int py, bool res, char *buf, int n);
+void conv_roll_t32_kernel_name(int prec, int py, const ConvArgs &a, char *buf, int n);
 // fused EFD block / strided 3x3x3 conv, 8 -> 16 channels (tiles are 4 x 16 columns of the OUTPUT grid); both filters packed as
 // ROLL_CHUNKS_8 chunks [dz][3 chunks of 4 taps x 8 channels]
 constexpr int ROLL_CHUNKS_8 = 9;
 void efd_roll_tile(int *ty, int *tx);
 hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_efd_kernel_name(int prec, bool dual, char *buf, int n);
+void conv_roll_efd_kernel_name(int prec, const ConvArgs &a, bool dual, char *buf, int n);
 // strided 3x3x3 over 16 (kh = 1) or 32 (kh = 2) input channels: 16 -> 16 (nt = 1: columns of 4 x 16 output pixels), 16 / 32 -> 32
 // (nt = 2: 4 x 8; 64 output channels = two launches with RollArgs::pair = first output tile).  Filter packed per (16-channel output
 // tile, 16-channel input half) as ROLL_CHUNKS chunks [dz][5 chunks of 2 in-slice taps x 16 channels]: [output tile][half][chunk]
 void s2_roll_tile(int nt, int *ty, int *tx);
 hipError_t launch_conv_roll_s2(int prec, int nt, int kh, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_s2_kernel_name(int prec, int nt, int kh, char *buf, int n);
+void conv_roll_s2_kernel_name(int prec, int nt, int kh, const ConvArgs &a, char *buf, int n);
 hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
-void conv_roll_t_kernel_name(int prec, bool res, char *buf, int n);   // res: the launch adds a residual (split-bf16 only)
+void conv_roll_t_kernel_name(int prec, const ConvArgs &a, char *buf, int n);
 
 }  // namespace dffw

@@ -32,7 +32,9 @@ namespace dffw {
 // row = 4 x 16 = 64 = two chunks, the filter's unused corner entries are zeros): 18 chunks per 32 pixels instead of
 // 2 x 15, i.e. 1.67x fewer MFMAs.  LDS rows are stored even columns first, odd columns second, so that the 8 pairs of
 // an operand read stay on consecutive addresses; a wave's tile is 2 rows x 8 pairs.
-template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES, bool PAIR>
+// LEAN: the launch's epilogue is "out = [relu](acc [+ residual])" (roll_lean(), dffw_conv_roll.h): only the straight-line routine
+// epilogue_lean is compiled in (with the generic one beside it the 16-output kernel needed 263 registers = one wave per SIMD)
+template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES, bool PAIR, bool LEAN>
 __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const RollArgs t) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
@@ -174,9 +176,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
         voff[0] = (prow * a.Wo + pcol) * (PARTS * 8) + ((PARTS == 2) ? (g & 1) * 8 : (g & 1) * 4);
     }
     const bool packed = !PAIR && (a.Cout == 8 && !a.outf && MTW % 2 == 0);   // two 8-channel result tiles share one epilogue
-    // the common epilogue "out = [relu](acc [+ residual])" takes the straight-line routine (dffw_device.h: epilogue_lean)
-    const bool lean = PARTS == 2 && a.out && !a.out_pre && !a.cls_w && !a.outf && !a.res1 && !a.res_bcast && a.relu != 2 && (RES || !a.res0) &&
-                      (PAIR || packed || a.Cout == 16);
+    static_assert(!LEAN || PARTS == 2, "the straight-line epilogue exists for split-bf16 storage");
     const bool lean_relu = a.relu == 1;
 
     // Ring protocol.  Window n of the stream reads slices n, n+1, n+2 (ring slots n, n+1, n+2 mod RING).  The prologue
@@ -333,11 +333,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
             if ((a.dbg & 4) && acc[0][0] != 12345.f) continue;
 
             // ---- epilogue of output slice zbeg + st (shared with conv_tile / conv_igemm) ----------------------------
-            if constexpr (PARTS == 2) {
-                if (lean) {
-                    uint16_t *ob = a.out + ubase;
+            if constexpr (LEAN) {
+                {
+                    uint16_t *ob = a.out ? a.out + ubase : nullptr, *obp = a.out_pre ? a.out_pre + ubase : nullptr;
+                    const f32x4 nocls = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (PAIR) {
-                        epilogue_lean<PREC, RES>(ob, voff[0], acc[0], RES ? make_uint4(rq[0][0], rq[0][1], rq[0][2], rq[0][3]) : uint4{}, lean_relu);
+                        epilogue_lean<PREC, RES>(ob, obp, voff[0], acc[0], RES ? make_uint4(rq[0][0], rq[0][1], rq[0][2], rq[0][3]) : uint4{}, lean_relu, nocls);
                     } else if (packed) {
 #pragma unroll
                         for (int j = 0; j + 1 < MTW; j += 2) {
@@ -348,19 +349,18 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
                                 q[i] = __uint_as_float(sw[0]);
                             }
                             const int vo = (lane >= 32) ? voff[j + 1] - 8 : voff[j];
-                            epilogue_lean<PREC, RES>(ob, vo, q, RES ? make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]) : uint4{}, lean_relu);
+                            epilogue_lean<PREC, RES>(ob, obp, vo, q, RES ? make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]) : uint4{}, lean_relu, nocls);
                         }
                     } else {
 #pragma unroll
                         for (int j = 0; j < MTW; ++j)
-                            epilogue_lean<PREC, RES>(ob, voff[j], acc[j], RES ? make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]) : uint4{}, lean_relu);
+                            epilogue_lean<PREC, RES>(ob, obp, voff[j], acc[j], RES ? make_uint4(rq[j][0], rq[j][1], rq[j][2], rq[j][3]) : uint4{}, lean_relu, nocls);
                     }
                     trc.stamp(4);
                     trc.next();
                     continue;
                 }
-            }
-            if constexpr (PAIR) {
+            } else if constexpr (PAIR) {
                 // lane rows 0-1 hold the even pixel's 8 channels, rows 2-3 the odd pixel's: both are "rows g & 1" of their
                 // own pixel record, exactly the packed form of the 8-channel epilogue (no register shuffling needed)
                 const int64_t opix = obase + (int64_t)prow * a.Wo + pcol;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
 // (two adjacent output pixels), a wave 2 full rows of 1 KiB.  Two passes (py = 0, 1) per input slice, each with its own
 // epilogue.  Streaming skeleton (column stream, ring of LDS slices, counted waits, inline-asm operand reads, residual
 // prefetch) as in conv_roll above; the input footprint needs one extra row / column on the high side only.
-template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES>
+template <int PREC, int TY, int TX, int NWAVES, int RING, bool RES, bool LEAN>
 __global__ __launch_bounds__(NWAVES * 64) void conv_roll_t(const ConvArgs a, const RollArgs t) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
@@ -519,6 +519,10 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll_t(const ConvArgs a, con
         voff[j] = (2 * ty * a.Wo + 2 * r + (g >> 1)) * (PARTS * 8) + ((PARTS == 2) ? (g & 1) * 8 : (g & 1) * 4);
     }
     const int rowstep = a.Wo * (PARTS * 8);   // elements from output row 2*ty to 2*ty + 1
+    static_assert(!LEAN || PARTS == 2, "the straight-line epilogue exists for split-bf16 storage");
+    const bool lean_relu = a.relu == 1, lean_cls = a.cls_w != nullptr;
+    f32x4 clsw = {0.f, 0.f, 0.f, 0.f};
+    if (LEAN && a.cls_w) clsw = *reinterpret_cast<const f32x4 *>(a.cls_w + (g & 1) * 4);
 
     constexpr int INFLIGHT = RES ? (RING > 4 ? PPW : 0) : (RING - 4) * PPW;
 #pragma unroll
@@ -632,6 +636,30 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll_t(const ConvArgs a, con
             if ((a.dbg & 4) && acc[0][0][0] != 12345.f) continue;
 
             // ---- epilogues: output rows 2*row (py = 0) and 2*row + 1 (py = 1); lane rows 0-1 = pixel 2*r, rows 2-3 = pixel 2*r + 1
+            if constexpr (LEAN) {
+                {   // straight-line routine (dffw_device.h: epilogue_lean), with or without the fused classifier
+                    uint16_t *ob = a.out ? a.out + ubase : nullptr, *obp = a.out_pre ? a.out_pre + ubase : nullptr;
+#pragma unroll
+                    for (int py = 0; py < 2; ++py)
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) {
+                            const int vo = voff[j] + py * rowstep;
+                            uint4 q4 = uint4{};
+                            if constexpr (RES) {
+                                const u32x4 q = rq[py * MTW + j];
+                                q4 = make_uint4(q[0], q[1], q[2], q[3]);
+                            }
+                            if (lean_cls) {
+                                const float cls = epilogue_lean<PREC, RES, true>(ob, obp, vo, acc[py][j], q4, lean_relu, clsw);
+                                const int64_t opix = obase + (int64_t)(2 * (wave * MTW + j) + py) * a.Wo + 2 * r + (g >> 1);
+                                epilogue_cls(a, cls, g, opix, true, 2);
+                            } else {
+                                epilogue_lean<PREC, RES, false>(ob, obp, vo, acc[py][j], q4, lean_relu, clsw);
+                            }
+                        }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -659,7 +687,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll_t(const ConvArgs a, con
 // 2y + PY (both x phases) with only that row phase's taps resident (9 / 18 chunks = 72 / 144 VGPRs); each sweep streams the
 // input once (it is a quarter of the output's size).  A chunk = one tap x 32 channels (K octet g = channel octet g), so every
 // operand address is the lane's base plus an immediate.  Skeleton as conv_roll_t; ring of 4 slices (20 KB each).
-template <int PREC, int PY, int RING, bool RES>
+template <int PREC, int PY, int RING, bool RES, bool LEAN>
 __global__ __launch_bounds__(256) void conv_roll_t32(const ConvArgs a, const RollArgs t) {
     constexpr int TY = PY ? 4 : 8, TX = 16, NWAVES = 4;   // phase 1 carries twice the filter: one input row per wave instead of two
     constexpr int PARTS = Fmt<PREC>::PARTS;
@@ -766,6 +794,9 @@ __global__ __launch_bounds__(256) void conv_roll_t32(const ConvArgs a, const Rol
         voff[j] = ((2 * ty + PY) * a.Wo + 2 * r) * (PARTS * 16) + lanepart;
     }
     constexpr int pxstep_c = 16;   // (x PARTS) elements from output pixel 2r to 2r + 1
+    static_assert(!LEAN || PARTS == 2, "the straight-line epilogue exists for split-bf16 storage");
+    f32x4 clsw = {0.f, 0.f, 0.f, 0.f};
+    if (LEAN && a.cls_w) clsw = *reinterpret_cast<const f32x4 *>(a.cls_w + g * 4);
 
     constexpr int INFLIGHT = RES ? (RING > 4 ? PPW : 0) : (RING - 4) * PPW;
 #pragma unroll
@@ -879,6 +910,29 @@ __global__ __launch_bounds__(256) void conv_roll_t32(const ConvArgs a, const Rol
             if ((a.dbg & 4) && acc[0][0][0] != 12345.f) continue;
 
             // ---- epilogues: output pixels 2*r (px = 0) and 2*r + 1 (px = 1) of row 2*row + PY ------------------------------------
+            if constexpr (LEAN) {   // straight-line routine (dffw_device.h: epilogue_lean), with or without the fused classifier
+                uint16_t *ob = a.out ? a.out + ubase : nullptr, *obp = a.out_pre ? a.out_pre + ubase : nullptr;
+                const bool lean_relu = a.relu == 1;
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        const int vo = voff[j] + px * (PARTS * pxstep_c);
+                        uint4 q4 = uint4{};
+                        if constexpr (RES) {
+                            const u32x4 q = rq[px * MTW + j];
+                            q4 = make_uint4(q[0], q[1], q[2], q[3]);
+                        }
+                        if (a.cls_w) {
+                            const float cls = epilogue_lean<PREC, RES, true>(ob, obp, vo, acc[px][j], q4, lean_relu, clsw);
+                            const int64_t opix = obase + (int64_t)(2 * (wave * MTW + j) + PY) * a.Wo + 2 * r + px;
+                            epilogue_cls(a, cls, g, opix, true);
+                        } else {
+                            epilogue_lean<PREC, RES, false>(ob, obp, vo, acc[px][j], q4, lean_relu, clsw);
+                        }
+                    }
+                continue;
+            }
 #pragma unroll
             for (int px = 0; px < 2; ++px)
 #pragma unroll
@@ -907,7 +961,7 @@ __global__ __launch_bounds__(256) void conv_roll_t32(const ConvArgs a, const Rol
 // the footprints of one slice of x (9 x 33 pixels for a 4 x 16 output tile, even columns first so that the stride-2 operand
 // reads stay contiguous) and of the pooled volume (6 x 18), K = [x: 3 slices x 3 chunks of 4 taps x 8 channels | pooled: same].
 // With DUAL = false it is the plain strided conv (dres4.conv1).  Streaming skeleton as conv_roll.
-template <int PREC, int RING, bool DUAL>
+template <int PREC, int RING, bool DUAL, bool LEAN>
 __global__ __launch_bounds__(256) void conv_roll_efd(const ConvArgs a, const RollArgs t) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
@@ -1100,10 +1154,15 @@ __global__ __launch_bounds__(256) void conv_roll_efd(const ConvArgs a, const Rol
             sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
             if (!live) continue;
             if ((a.dbg & 4) && acc[0] != 12345.f) continue;
-            const int64_t opix = obase + (int64_t)wave * a.Wo + r;
-            float cls = 0.f;
-            epilogue_quad<PREC, false, true, false>(a, acc, 0, g, opix, true, cls, uint4{}, uint4{}, ubase, voff);
-            epilogue_cls(a, cls, g, opix, true);
+            if constexpr (LEAN) {
+                epilogue_lean<PREC, false>(a.out ? a.out + ubase : nullptr, a.out_pre ? a.out_pre + ubase : nullptr, voff, acc, uint4{}, a.relu == 1,
+                                           f32x4{0.f, 0.f, 0.f, 0.f});
+            } else {
+                const int64_t opix = obase + (int64_t)wave * a.Wo + r;
+                float cls = 0.f;
+                epilogue_quad<PREC, false, true, false>(a, acc, 0, g, opix, true, cls, uint4{}, uint4{}, ubase, voff);
+                epilogue_cls(a, cls, g, opix, true);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
@@ -1125,7 +1184,7 @@ __global__ __launch_bounds__(256) void conv_roll_efd(const ConvArgs a, const Rol
 // each with its half filter (120 VGPRs); the odd half hands its partial tile to its partner through LDS in front of the step's
 // barrier (double-buffered by step parity) and the partner runs the epilogue.  t.pair = first 16-channel output tile of this launch
 // (64 output channels = two launches over the same input).
-template <int PREC, int NT, int KH, int RING>
+template <int PREC, int NT, int KH, int RING, bool LEAN>
 __global__ __launch_bounds__(NT * KH == 4 ? 512 : 256) void conv_roll_s2(const ConvArgs a, const RollArgs t) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
@@ -1319,9 +1378,14 @@ __global__ __launch_bounds__(NT * KH == 4 ? 512 : 256) void conv_roll_s2(const C
             sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
             if (!live || kh) continue;
             if ((a.dbg & 4) && acc[0] != 12345.f) continue;
-            const int64_t opix = obase + (int64_t)orow * a.Wo + ocol;
-            float cls = 0.f;
-            epilogue_quad<PREC, false, true, false>(a, acc, nt, g, opix, true, cls, uint4{}, uint4{}, ubase, voff);
+            if constexpr (LEAN) {
+                epilogue_lean<PREC, false>(a.out ? a.out + ubase : nullptr, a.out_pre ? a.out_pre + ubase : nullptr, voff + nt * 16, acc, uint4{},
+                                           a.relu == 1, f32x4{0.f, 0.f, 0.f, 0.f});
+            } else {
+                const int64_t opix = obase + (int64_t)orow * a.Wo + ocol;
+                float cls = 0.f;
+                epilogue_quad<PREC, false, true, false>(a, acc, nt, g, opix, true, cls, uint4{}, uint4{}, ubase, voff);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave (see conv_roll)
@@ -1333,17 +1397,29 @@ __global__ __launch_bounds__(NT * KH == 4 ? 512 : 256) void conv_roll_s2(const C
 #define DFFW_ROLL_NW 4
 #define DFFW_ROLL_RING 6
 
+// The launch's epilogue fits the straight-line routine (epilogue_lean, dffw_device.h): split-bf16 storage, something to write,
+// no relu-before-residual, no second / broadcast residual, no fp32 planar output; a residual only where the kernel family
+// prefetches it (`res_variant`); whole 16-channel (or packed 8-channel) result tiles.
+bool roll_lean(int prec, const ConvArgs &a, bool res_variant) {
+    return prec == P_BF16X3 && (a.out || a.out_pre || a.cls_w) && !a.outf && !a.res1 && !a.res_bcast && a.relu != 2 && (res_variant || !a.res0) &&
+           (a.Cout == 8 || a.Cout % 16 == 0);
+}
+static const char *tf(bool b) { return b ? "true" : "false"; }
+
 void roll_tile(int *ty, int *tx) {
     *ty = DFFW_ROLL_TY;
     *tx = DFFW_ROLL_TX;
 }
 
-void conv_roll_kernel_name(int prec, bool res, bool pair, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_roll<%d, %d, %d, %d, %d, %s, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, res ? "true" : "false", pair ? "true" : "false");
+void conv_roll_kernel_name(int prec, const ConvArgs &a, bool pair, char *buf, int n) {
+    const bool res = a.res0 != nullptr && prec == P_BF16X3;
+    snprintf(buf, n, "dffw::conv_roll<%d, %d, %d, %d, %d, %s, %s, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, tf(res), tf(pair),
+             tf(roll_lean(prec, a, true) && !a.cls_w));
 }
 
-void conv_roll_t_kernel_name(int prec, bool res, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_roll_t<%d, %d, %d, %d, %d, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, res ? "true" : "false");
+void conv_roll_t_kernel_name(int prec, const ConvArgs &a, char *buf, int n) {
+    const bool res = a.res0 != nullptr && prec == P_BF16X3;
+    snprintf(buf, n, "dffw::conv_roll_t<%d, %d, %d, %d, %d, %s, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, tf(res), tf(roll_lean(prec, a, true)));
 }
 
 hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
@@ -1351,22 +1427,26 @@ hipError_t launch_conv_roll_t(int prec, const ConvArgs &a, const RollArgs &t, hi
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(DFFW_ROLL_NW * 64);
     const bool res = a.res0 != nullptr && prec == P_BF16X3;
-#define DFFW_ROLLT_LAUNCH(P, R) hipLaunchKernelGGL((conv_roll_t<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R>), grid, block, 0, s, a, t)
+    const bool lean = roll_lean(prec, a, true);
+#define DFFW_ROLLT_LAUNCH(P, R, L) hipLaunchKernelGGL((conv_roll_t<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R, L>), grid, block, 0, s, a, t)
     switch (prec) {
         case P_BF16X3:
-            if (res) DFFW_ROLLT_LAUNCH(P_BF16X3, true);
-            else DFFW_ROLLT_LAUNCH(P_BF16X3, false);
+            if (res && lean) DFFW_ROLLT_LAUNCH(P_BF16X3, true, true);
+            else if (res) DFFW_ROLLT_LAUNCH(P_BF16X3, true, false);
+            else if (lean) DFFW_ROLLT_LAUNCH(P_BF16X3, false, true);
+            else DFFW_ROLLT_LAUNCH(P_BF16X3, false, false);
             break;
-        case P_FP16: DFFW_ROLLT_LAUNCH(P_FP16, false); break;
-        case P_BF16: DFFW_ROLLT_LAUNCH(P_BF16, false); break;
+        case P_FP16: DFFW_ROLLT_LAUNCH(P_FP16, false, false); break;
+        case P_BF16: DFFW_ROLLT_LAUNCH(P_BF16, false, false); break;
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_ROLLT_LAUNCH
     return hipGetLastError();
 }
 
-void conv_roll_t32_kernel_name(int prec, int py, bool res, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_roll_t32<%d, %d, %d, %s>", prec, py, py ? 6 : 4, res ? "true" : "false");
+void conv_roll_t32_kernel_name(int prec, int py, const ConvArgs &a, char *buf, int n) {
+    const bool res = a.res0 != nullptr && prec == P_BF16X3;
+    snprintf(buf, n, "dffw::conv_roll_t32<%d, %d, %d, %s, %s>", prec, py, py ? 6 : 4, tf(res), tf(roll_lean(prec, a, true)));
 }
 
 hipError_t launch_conv_roll_t32(int prec, int py, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
@@ -1374,18 +1454,21 @@ hipError_t launch_conv_roll_t32(int prec, int py, const ConvArgs &a, const RollA
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
     const bool res = a.res0 != nullptr && prec == P_BF16X3;
-#define DFFW_T32_LAUNCH(P, R)                                                                      \
-    do {                                                                                           \
-        if (py) hipLaunchKernelGGL((conv_roll_t32<P, 1, 6, R>), grid, block, 0, s, a, t);         \
-        else hipLaunchKernelGGL((conv_roll_t32<P, 0, 4, R>), grid, block, 0, s, a, t);            \
+    const bool lean = roll_lean(prec, a, true);
+#define DFFW_T32_LAUNCH(P, R, L)                                                                      \
+    do {                                                                                              \
+        if (py) hipLaunchKernelGGL((conv_roll_t32<P, 1, 6, R, L>), grid, block, 0, s, a, t);         \
+        else hipLaunchKernelGGL((conv_roll_t32<P, 0, 4, R, L>), grid, block, 0, s, a, t);            \
     } while (0)
     switch (prec) {
         case P_BF16X3:
-            if (res) DFFW_T32_LAUNCH(P_BF16X3, true);
-            else DFFW_T32_LAUNCH(P_BF16X3, false);
+            if (res && lean) DFFW_T32_LAUNCH(P_BF16X3, true, true);
+            else if (res) DFFW_T32_LAUNCH(P_BF16X3, true, false);
+            else if (lean) DFFW_T32_LAUNCH(P_BF16X3, false, true);
+            else DFFW_T32_LAUNCH(P_BF16X3, false, false);
             break;
-        case P_FP16: DFFW_T32_LAUNCH(P_FP16, false); break;
-        case P_BF16: DFFW_T32_LAUNCH(P_BF16, false); break;
+        case P_FP16: DFFW_T32_LAUNCH(P_FP16, false, false); break;
+        case P_BF16: DFFW_T32_LAUNCH(P_BF16, false, false); break;
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_T32_LAUNCH
@@ -1402,8 +1485,8 @@ void efd_roll_tile(int *ty, int *tx) {
     *tx = 16;
 }
 
-void conv_roll_efd_kernel_name(int prec, bool dual, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_roll_efd<%d, %d, %s>", prec, 5, dual ? "true" : "false");
+void conv_roll_efd_kernel_name(int prec, const ConvArgs &a, bool dual, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll_efd<%d, %d, %s, %s>", prec, 5, tf(dual), tf(roll_lean(prec, a, false) && !a.cls_w));
 }
 
 hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
@@ -1411,15 +1494,19 @@ hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, 
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
     const bool dual = t.wroll2 != nullptr;
-#define DFFW_EFD_LAUNCH(P)                                                                       \
-    do {                                                                                         \
-        if (dual) hipLaunchKernelGGL((conv_roll_efd<P, 5, true>), grid, block, 0, s, a, t);     \
-        else hipLaunchKernelGGL((conv_roll_efd<P, 5, false>), grid, block, 0, s, a, t);         \
+    const bool lean = roll_lean(prec, a, false) && !a.cls_w;
+#define DFFW_EFD_LAUNCH(P, L)                                                                       \
+    do {                                                                                            \
+        if (dual) hipLaunchKernelGGL((conv_roll_efd<P, 5, true, L>), grid, block, 0, s, a, t);     \
+        else hipLaunchKernelGGL((conv_roll_efd<P, 5, false, L>), grid, block, 0, s, a, t);         \
     } while (0)
     switch (prec) {
-        case P_BF16X3: DFFW_EFD_LAUNCH(P_BF16X3); break;
-        case P_FP16: DFFW_EFD_LAUNCH(P_FP16); break;
-        case P_BF16: DFFW_EFD_LAUNCH(P_BF16); break;
+        case P_BF16X3:
+            if (lean) DFFW_EFD_LAUNCH(P_BF16X3, true);
+            else DFFW_EFD_LAUNCH(P_BF16X3, false);
+            break;
+        case P_FP16: DFFW_EFD_LAUNCH(P_FP16, false); break;
+        case P_BF16: DFFW_EFD_LAUNCH(P_BF16, false); break;
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_EFD_LAUNCH
@@ -1431,8 +1518,8 @@ void s2_roll_tile(int nt, int *ty, int *tx) {
     *tx = nt == 2 ? 8 : 16;
 }
 
-void conv_roll_s2_kernel_name(int prec, int nt, int kh, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_roll_s2<%d, %d, %d, %d>", prec, nt, kh, kh == 2 ? 5 : (nt == 2 ? 6 : 4));
+void conv_roll_s2_kernel_name(int prec, int nt, int kh, const ConvArgs &a, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_roll_s2<%d, %d, %d, %d, %s>", prec, nt, kh, kh == 2 ? 5 : (nt == 2 ? 6 : 4), tf(roll_lean(prec, a, false) && !a.cls_w));
 }
 
 hipError_t launch_conv_roll_s2(int prec, int nt, int kh, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
@@ -1441,16 +1528,20 @@ hipError_t launch_conv_roll_s2(int prec, int nt, int kh, const ConvArgs &a, cons
     const int want = t.wgs > 0 ? t.wgs : (kh == 2 ? 256 : 512);
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8))));
-#define DFFW_S2_LAUNCH(P)                                                                                   \
-    do {                                                                                                    \
-        if (kh == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 2, 5>), grid, dim3(512), 0, s, a, t);          \
-        else if (nt == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 1, 6>), grid, dim3(256), 0, s, a, t);     \
-        else hipLaunchKernelGGL((conv_roll_s2<P, 1, 1, 4>), grid, dim3(256), 0, s, a, t);                  \
+    const bool lean = roll_lean(prec, a, false) && !a.cls_w;
+#define DFFW_S2_LAUNCH(P, L)                                                                                   \
+    do {                                                                                                       \
+        if (kh == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 2, 5, L>), grid, dim3(512), 0, s, a, t);          \
+        else if (nt == 2) hipLaunchKernelGGL((conv_roll_s2<P, 2, 1, 6, L>), grid, dim3(256), 0, s, a, t);     \
+        else hipLaunchKernelGGL((conv_roll_s2<P, 1, 1, 4, L>), grid, dim3(256), 0, s, a, t);                  \
     } while (0)
     switch (prec) {
-        case P_BF16X3: DFFW_S2_LAUNCH(P_BF16X3); break;
-        case P_FP16: DFFW_S2_LAUNCH(P_FP16); break;
-        case P_BF16: DFFW_S2_LAUNCH(P_BF16); break;
+        case P_BF16X3:
+            if (lean) DFFW_S2_LAUNCH(P_BF16X3, true);
+            else DFFW_S2_LAUNCH(P_BF16X3, false);
+            break;
+        case P_FP16: DFFW_S2_LAUNCH(P_FP16, false); break;
+        case P_BF16: DFFW_S2_LAUNCH(P_BF16, false); break;
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_S2_LAUNCH
@@ -1458,25 +1549,29 @@ hipError_t launch_conv_roll_s2(int prec, int nt, int kh, const ConvArgs &a, cons
 }
 
 hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
-    // persistent: two resident workgroups per CU (registers allow 2 waves per SIMD) walk the columns
+    // persistent grid: two resident workgroups per CU (72 KiB of LDS each), a multiple of the 8 XCDs, never more
+    // workgroups than an XCD has columns
     const int want = t.wgs > 0 ? t.wgs : 512;
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(DFFW_ROLL_NW * 64);
     // the hand-prefetched residual exists for the split-bf16 storage only; fp16/bf16 layers with a residual load it in the epilogue
     const bool res = a.res0 != nullptr && prec == P_BF16X3;
-#define DFFW_ROLL_LAUNCH(P, R, Q) hipLaunchKernelGGL((conv_roll<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R, Q>), grid, block, 0, s, a, t)
-#define DFFW_ROLL_LAUNCH_Q(P, R)        \
-    do {                                \
-        if (t.pair) DFFW_ROLL_LAUNCH(P, R, true);  \
-        else DFFW_ROLL_LAUNCH(P, R, false);        \
+    const bool lean = roll_lean(prec, a, true) && !a.cls_w;
+#define DFFW_ROLL_LAUNCH(P, R, Q, L) hipLaunchKernelGGL((conv_roll<P, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, R, Q, L>), grid, block, 0, s, a, t)
+#define DFFW_ROLL_LAUNCH_Q(P, R, L)                   \
+    do {                                              \
+        if (t.pair) DFFW_ROLL_LAUNCH(P, R, true, L);  \
+        else DFFW_ROLL_LAUNCH(P, R, false, L);        \
     } while (0)
     switch (prec) {
         case P_BF16X3:
-            if (res) DFFW_ROLL_LAUNCH_Q(P_BF16X3, true);
-            else DFFW_ROLL_LAUNCH_Q(P_BF16X3, false);
+            if (res && lean) DFFW_ROLL_LAUNCH_Q(P_BF16X3, true, true);
+            else if (res) DFFW_ROLL_LAUNCH_Q(P_BF16X3, true, false);
+            else if (lean) DFFW_ROLL_LAUNCH_Q(P_BF16X3, false, true);
+            else DFFW_ROLL_LAUNCH_Q(P_BF16X3, false, false);
             break;
-        case P_FP16: DFFW_ROLL_LAUNCH_Q(P_FP16, false); break;
-        case P_BF16: DFFW_ROLL_LAUNCH_Q(P_BF16, false); break;
+        case P_FP16: DFFW_ROLL_LAUNCH_Q(P_FP16, false, false); break;
+        case P_BF16: DFFW_ROLL_LAUNCH_Q(P_BF16, false, false); break;
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_ROLL_LAUNCH_Q

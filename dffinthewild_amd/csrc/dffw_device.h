@@ -305,16 +305,31 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
     }
 }
 
-// Lean epilogue of the streaming kernels for the common case "out = relu(acc [+ residual])" in split-bf16 storage: the same
-// arithmetic and the same instructions as epilogue_quad<PREC, PRE, FAST> takes for that case (bit-identical results), but
-// straight-line: the generic routine tests nine ConvArgs fields per call and its ~25 taken branches, SGPR spills and AGPR round
-// trips cost ~1100 cycles per operand tile in the rolling kernels (step timeline, profiles/r03_step_timeline_*.txt), a third
-// of a step.  `out` = wave-uniform pointer of the step's first output element, `voff` = the lane's element offset (16-byte piece).
+// Lean epilogue of the streaming kernels in split-bf16 storage: the same arithmetic and the same instruction sequence per value
+// as epilogue_quad<PREC, PRE, FAST> (bit-identical results), but straight-line.  The generic routine tests nine ConvArgs fields
+// per call; its ~25 taken branches, SGPR spills and AGPR round trips cost ~1100 cycles per operand tile in the rolling kernels
+// (step timeline, profiles/r03_step_timeline.txt), a third of a step.  Covers
+//     pre  = acc                      -> out_pre (if non-null)
+//     v    = [relu](acc [+ residual]) -> out     (if non-null)
+//     cls  = sum_i clsw[i] * v[i]     (CLS; returned, the caller finishes it with epilogue_cls)
+// i.e. every epilogue of the network except relu-before-residual (relu == 2), a second residual, broadcast residuals and fp32
+// planar outputs, which stay on epilogue_quad (host side: roll_lean(), dffw_conv_roll.hip, picks the LEAN instantiation).  `out` /
+// `out_pre` = wave-uniform pointers of the step's first output element, `voff` = the lane's element offset (its 16-byte piece).
 // MUST be called by all 64 lanes (v_permlane16_swap).
-template <int PREC, bool RES>
-__device__ __forceinline__ void epilogue_lean(uint16_t *__restrict__ out, int voff, const f32x4 &acc, uint4 rq, bool relu) {
+template <int PREC, bool RES, bool CLS = false>
+__device__ __forceinline__ float epilogue_lean(uint16_t *__restrict__ out, uint16_t *__restrict__ out_pre, int voff, const f32x4 &acc, uint4 rq,
+                                               bool relu, const f32x4 &clsw) {
     static_assert(Fmt<PREC>::PARTS == 2, "split-bf16 storage only");
     float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
+    auto store = [&](uint16_t *base) {
+        uint32_t h01, h23, l01, l23;
+        Fmt<PREC>::split2(v0, v1, h01, l01);
+        Fmt<PREC>::split2(v2, v3, h23, l23);
+        swap16(h01, l01);
+        swap16(h23, l23);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(base) + (uint32_t)(voff * 2)) = make_uint4(h01, h23, l01, l23);
+    };
+    if (out_pre) store(out_pre);
     if constexpr (RES) {
         swap16(rq.x, rq.z);
         swap16(rq.y, rq.w);
@@ -332,12 +347,15 @@ __device__ __forceinline__ void epilogue_lean(uint16_t *__restrict__ out, int vo
         v2 = relu_bits(v2);
         v3 = relu_bits(v3);
     }
-    uint32_t h01, h23, l01, l23;
-    Fmt<PREC>::split2(v0, v1, h01, l01);
-    Fmt<PREC>::split2(v2, v3, h23, l23);
-    swap16(h01, l01);
-    swap16(h23, l23);
-    *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(out) + (uint32_t)(voff * 2)) = make_uint4(h01, h23, l01, l23);
+    float cls = 0.f;
+    if constexpr (CLS) {
+        cls = fmaf(clsw[0], v0, cls);
+        cls = fmaf(clsw[1], v1, cls);
+        cls = fmaf(clsw[2], v2, cls);
+        cls = fmaf(clsw[3], v3, cls);
+    }
+    if (out) store(out);
+    return cls;
 }
 
 // finish the fused 1x1x1 classifier: sum the partial dots of the 4 lane rows, row 0 writes the score

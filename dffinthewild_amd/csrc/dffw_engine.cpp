@@ -1418,7 +1418,7 @@ struct Run {
                 t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
                 t.wgs = sw.roll_wgs;
                 char kn[96];
-                conv_roll_t32_kernel_name(e->prec, py, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                conv_roll_t32_kernel_name(e->prec, py, a, kn, sizeof kn);
                 g_last_kernel = kn;
                 if (e->profiling) {
                     const double opx = (double)out.B * No * Ho * Wo * 0.5;   // this sweep's output pixels
@@ -1458,7 +1458,7 @@ struct Run {
                     t.wgs = sw.roll_wgs;
                     t.pair = li * ntk;     // first 16-channel output tile of this launch
                     char kn[96];
-                    conv_roll_s2_kernel_name(e->prec, ntk, khn, kn, sizeof kn);
+                    conv_roll_s2_kernel_name(e->prec, ntk, khn, a, kn, sizeof kn);
                     g_last_kernel = kn;
                     if (e->profiling) {
                         const double opx = (double)out.B * No * Ho * Wo;
@@ -1492,7 +1492,7 @@ struct Run {
                 t.total_tiles = in0.B * t.tiles_y * t.tiles_x;
                 t.wgs = sw.roll_wgs;
                 char kn[96];
-                conv_roll_efd_kernel_name(e->prec, false, kn, sizeof kn);
+                conv_roll_efd_kernel_name(e->prec, a, false, kn, sizeof kn);
                 g_last_kernel = kn;
                 if (e->profiling) {
                     const double opx = (double)out.B * No * Ho * Wo;
@@ -1526,7 +1526,7 @@ struct Run {
                 if (sw.roll_wgs) t.wgs = sw.roll_wgs;
                 t.pair = 1;
                 char kn[96];
-                conv_roll_t_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, kn, sizeof kn);
+                conv_roll_t_kernel_name(e->prec, a, kn, sizeof kn);
                 g_last_kernel = kn;
                 if (e->profiling) {
                     const double opx = (double)out.B * No * Ho * Wo;
@@ -1570,12 +1570,12 @@ struct Run {
                 if (sw.roll_wgs) t.wgs = sw.roll_wgs;
                 {
                     char kn[96];
-                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, pc.roll_pair, kn, sizeof kn);
+                    conv_roll_kernel_name(e->prec, a, pc.roll_pair, kn, sizeof kn);
                     g_last_kernel = kn;
                 }
                 if (e->profiling) {
                     char kn[96];
-                    conv_roll_kernel_name(e->prec, a.res0 != nullptr && e->prec == P_BF16X3, pc.roll_pair, kn, sizeof kn);
+                    conv_roll_kernel_name(e->prec, a, pc.roll_pair, kn, sizeof kn);
                     const double opx = (double)out.B * No * Ho * Wo;
                     const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
                                          + opx * L.cout * (o.outf ? 4.0 : elem_bytes() * (o.out_pre ? 2 : 1))
@@ -1923,7 +1923,7 @@ static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr
                 t.total_tiles = x.B * t.tiles_y * t.tiles_x;
                 t.wgs = r.sw.roll_wgs;
                 char kn[64];
-                conv_roll_efd_kernel_name(r.e->prec, true, kn, sizeof kn);
+                conv_roll_efd_kernel_name(r.e->prec, a, true, kn, sizeof kn);
                 g_last_kernel = kn;
                 const double opx = (double)x.B * x.N * Ho * Wo;
                 r.prof_begin(kn, p, 2.0 * opx * 27.0 * 8 * 16 * 2, ((double)x.pixels() * 8 + opx * 8 + opx * 16) * r.elem_bytes());
