@@ -239,6 +239,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
             trc.stamp(1);
 
             f32x4 acc[MTW];
+            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < MTW; ++j) acc[j] = bias4;
             if (live && !(a.dbg & 2)) {
@@ -303,15 +304,28 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
 #pragma unroll
                         for (int pt = 0; pt < PARTS; ++pt)
                             if (j + pt) asm volatile("" : "+v"(xc[j][pt]));
-                    if constexpr (PARTS == 2) {
+                    if constexpr (MTW == 1 && PARTS == 2) {
+                        // one operand tile per wave: the three products of a chunk would form one dependent chain (a dependent
+                        // 16x16x32 MFMA issues every ~26 cycles, an independent one every 16): the cross terms go to a second
+                        // accumulator, summed after the loop
+                        acc2 = mma<F16>(w[c][1], xc[0][0], acc2);
+                        acc[0] = mma<F16>(w[c][0], xc[0][0], acc[0]);
+                        acc2 = mma<F16>(w[c][0], xc[0][1], acc2);
+                    } else {
+                        if constexpr (PARTS == 2) {
 #pragma unroll
-                        for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][1], xc[j][0], acc[j]);
+                            for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][1], xc[j][0], acc[j]);
 #pragma unroll
-                        for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][0], xc[j][1], acc[j]);
+                            for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][0], xc[j][1], acc[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][0], xc[j][0], acc[j]);
                     }
-#pragma unroll
-                    for (int j = 0; j < MTW; ++j) acc[j] = mma<F16>(w[c][0], xc[j][0], acc[j]);
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (MTW == 1 && PARTS == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[0][i] += acc2[i];
                 }
             }
 

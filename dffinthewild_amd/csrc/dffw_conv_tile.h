@@ -74,6 +74,7 @@ bool tile_cfg_has_sums(const TileCfg *c);     // a row-sums instantiation (DFFW_
 int tile_cfg_count();
 const TileCfg *tile_cfg_at(int i);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
-void conv_tile_kernel_name(int prec, const TileCfg *cfg, bool splitk, char *buf, int n);
+bool tile_lean(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t);   // the launch runs the LEAN instantiation (straight-line epilogue)
+void conv_tile_kernel_name(int prec, const TileCfg *cfg, bool splitk, bool lean, char *buf, int n);
 
 }  // namespace dffw

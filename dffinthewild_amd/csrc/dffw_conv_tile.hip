@@ -33,7 +33,10 @@ namespace dffw {
 // SPLITK: the split-K variant (raw fp32 partial sums, stage range from blockIdx.z).  Compile-time because as a
 // runtime branch its partial-store path cost every kernel ~50 VGPRs at the peak (one resident wave per SIMD on the
 // 64-channel kernels); only the configurations that few-tile layers actually use are instantiated with it.
-template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4, bool SPLITK = false>
+// LEAN: the launch's epilogue is one the straight-line routine covers (tile_lean(): split-bf16 storage, out / out_pre / fused
+// classifier, at most one residual in the output's geometry, ReLU after it): epilogue_lean_t instead of epilogue_quad's run-time
+// option tree (which costs ~1000 cycles per operand tile and 16-channel group)
+template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4, bool SPLITK = false, bool LEAN = false>
 __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const TileArgs t) {
     using T = TileT<GEO, TZ, TY, TX, CG>;
     using G = GeoT<GEO>;
@@ -485,7 +488,123 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                 if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
                 return ok;
             };
-            if (SPLITK && splitk) {
+            if constexpr (LEAN) {
+                static_assert(!LEAN || (PARTS == 2 && !SPLITK), "straight-line epilogue: split-bf16 storage, no split-K / raw / row-sums variant");
+                const bool relu1 = a.relu == 1, has_res = a.res0 != nullptr, has_cls = a.cls_w != nullptr;
+                uint16_t *ob = a.out ? a.out + ubase : nullptr, *obp = a.out_pre ? a.out_pre + ubase : nullptr;
+                const uint16_t *rb = has_res ? a.res0 + ubase : nullptr;
+                auto valid = [&](int j) -> bool {
+                    bool ok = true;
+                    if (!interior) {
+                        const int c = tcrd[j];
+                        ok = cur.gz0 + (c >> 16) < a.Ng && cur.gy0 + ((c >> 8) & 255) < a.Hg && cur.gx0 + (c & 255) < a.Wg;
+                    }
+                    if ((a.dbg & 4) && acc[0][j][0] != 12345.f) ok = false;
+                    return ok;
+                };
+                auto pixel = [&](int j) -> int64_t {   // only the classifier's score store needs it
+                    const int c = tcrd[j];
+                    return obase + (((c >> 16) * a.Ho + ((c >> 8) & 255) * G::OS) * a.Wo + (c & 255) * G::OS);
+                };
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (STEMP) {
+                    // pixel-pair stem: lane rows 0-1 hold pixel x's 8 channels, rows 2-3 pixel x+2's -- each lane is "row g & 1" of its own record
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        float cls = 0.f;
+                        f32x4 v = acc[0][j];
+                        if constexpr (!BIAS_IN_ACC) v += *reinterpret_cast<const f32x4 *>(a.bias + (g & 1) * 4);
+                        epilogue_lean_t<PREC>(ob, obp, voff[j], v[0], v[1], v[2], v[3], false, uint4{}, relu1, false, zero4, cls, valid(j));
+                    }
+                } else if (NT == 1 && a.Cout == 8) {
+                    // 8 output channels occupy only lane rows 0-1 of a result tile: operand tiles j and j+1 share one epilogue
+#pragma unroll
+                    for (int j = 0; j < MTW; j += 2) {
+                        if (j + 1 < MTW) {
+                            float q[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][j][i]), __float_as_uint(acc[0][j + 1][i]), false, false);
+                                q[i] = __uint_as_float(sw[0]);   // lanes 0-31: tile j, lanes 32-63: lanes 0-31 of tile j+1
+                            }
+                            const bool p0 = valid(j), p1 = valid(j + 1);
+                            const bool up = lane >= 32;
+                            const bool pv = up ? p1 : p0;
+                            const int vo = up ? voff[j + 1] - 8 : voff[j];
+                            if constexpr (!BIAS_IN_ACC) {
+                                const f32x4 bb = *reinterpret_cast<const f32x4 *>(a.bias + (g & 1) * 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) q[i] += bb[i];
+                            }
+                            uint4 rq = uint4{};
+                            if (has_res && pv) rq = *reinterpret_cast<const uint4 *>(rb + vo);
+                            float cls = 0.f;
+                            f32x4 cw = zero4;
+                            if (has_cls) cw = *reinterpret_cast<const f32x4 *>(a.cls_w + (g & 1) * 4);
+                            epilogue_lean_t<PREC>(ob, obp, vo, q[0], q[1], q[2], q[3], has_res, rq, relu1, has_cls, cw, cls, pv);
+                            if (has_cls) epilogue_cls(a, cls, g, up ? pixel(j + 1) : pixel(j), pv, 2);
+                        } else {
+                            const bool pv = valid(j) && g < 2;   // the odd last tile: its rows 2-3 carry no channels
+                            f32x4 v = acc[0][j];
+                            if constexpr (!BIAS_IN_ACC) v += bias4[0];
+                            uint4 rq = uint4{};
+                            if (has_res && pv) rq = *reinterpret_cast<const uint4 *>(rb + voff[j]);
+                            float cls = 0.f;
+                            f32x4 cw = zero4;
+                            if (has_cls && g < 2) cw = *reinterpret_cast<const f32x4 *>(a.cls_w + g * 4);
+                            epilogue_lean_t<PREC>(ob, obp, voff[j], v[0], v[1], v[2], v[3], has_res, rq, relu1, has_cls, cw, cls, pv);
+                            if (has_cls) epilogue_cls(a, cls, g, pixel(j), valid(j));
+                        }
+                    }
+                } else {
+                    // residual pieces one operand tile ahead of their use where the registers are there (<= 2 output tiles per
+                    // workgroup), else requested right before it (what the generic routine does)
+                    constexpr bool AHEAD = NT <= 2 && NWAVES == 4;
+                    uint4 rn[AHEAD ? NT : 1];
+                    bool pvn = valid(0);
+                    if constexpr (AHEAD) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            rn[nt] = uint4{};
+                            if (has_res && pvn) rn[nt] = *reinterpret_cast<const uint4 *>(rb + (voff[0] + (ntb + nt) * 16));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j) {
+                        const bool pv = pvn;
+                        uint4 rq[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            if constexpr (AHEAD) rq[nt] = rn[nt];
+                            else {
+                                rq[nt] = uint4{};
+                                if (has_res && pv) rq[nt] = *reinterpret_cast<const uint4 *>(rb + (voff[j] + (ntb + nt) * 16));
+                            }
+                        }
+                        if (j + 1 < MTW) {
+                            pvn = valid(j + 1);
+                            if constexpr (AHEAD) {
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) {
+                                    rn[nt] = uint4{};
+                                    if (has_res && pvn) rn[nt] = *reinterpret_cast<const uint4 *>(rb + (voff[j + 1] + (ntb + nt) * 16));
+                                }
+                            }
+                        }
+                        float cls = 0.f;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            f32x4 v = acc[nt][j];
+                            if constexpr (!BIAS_IN_ACC) v += bias4[nt];
+                            f32x4 cw = zero4;
+                            if (has_cls) cw = *reinterpret_cast<const f32x4 *>(a.cls_w + (ntb + nt) * 16 + g * 4);
+                            epilogue_lean_t<PREC>(ob, obp, voff[j] + (ntb + nt) * 16, v[0], v[1], v[2], v[3], has_res, rq[nt], relu1, has_cls, cw, cls, pv);
+                        }
+                        if (has_cls) epilogue_cls(a, cls, g, pixel(j), pv);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if (SPLITK && splitk) {
                 // raw partial sums: 4 consecutive channels of the lane's pixel as one 16-byte store
                 float *pz = t.partial + (int64_t)blockIdx.z * t.partial_stride;
                 const int cpad = NTT * 16;
@@ -697,7 +816,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(38, G3S2, 2, 4, 4, 8, 16, 1)   \
     X(39, G3S2, 1, 4, 4, 8, 16, 1)
 
-#if DFFW_TILE_PREC == 0   // configuration table and look-ups live in one of the three per-precision objects
+#if DFFW_TILE_PREC == 0 && !defined(DFFW_TILE_LEAN)   // configuration table and look-ups live in one of the per-precision objects
 bool tile_cfg_has_sums(const TileCfg *c) { return c && c->geo == G2S1 && c->nw == 4 && (c->id == 34 || c->id == 19); }
 bool tile_cfg_has_splitk(const TileCfg *c) {
     switch (c->id) {
@@ -736,13 +855,44 @@ const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt) {
     return nullptr;
 }
 
-void conv_tile_kernel_name(int prec, const TileCfg *c, bool splitk, char *buf, int n) {
-    // exactly as rocprofv3 --kernel-trace prints the instantiation (all ten template arguments)
-    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw, splitk ? "true" : "false");
+// the launch takes the LEAN instantiation (straight-line epilogue): split-bf16 storage, no split-K / raw-stack / row-sums variant,
+// something to write, ReLU (if any) after the residual, at most one residual in the output's own geometry, whole 16-channel
+// result tiles (or the packed 8-channel form)
+bool tile_lean(int prec, const TileCfg *c, const ConvArgs &a, const TileArgs &t) {
+    return prec == P_BF16X3 && t.ksplit <= 1 && !(a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)) && (a.out || a.out_pre || a.cls_w) && !a.outf && !a.res1 &&
+           !a.res_bcast && a.relu != 2 && (a.Cout % 16 == 0 || (a.Cout == 8 && c->nt == 1)) && !getenv("DFFW_NO_LEAN_TILE") &&
+           c->id != 23 && c->id != 27;   // (these two transposed-conv configurations need 7 / 10 registers more with it: a wave per SIMD lost)
+}
+
+void conv_tile_kernel_name(int prec, const TileCfg *c, bool splitk, bool lean, char *buf, int n) {
+    // exactly as rocprofv3 --kernel-trace prints the instantiation (all eleven template arguments)
+    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw,
+             splitk ? "true" : "false", lean ? "true" : "false");
 }
 
 #endif
 
+#ifdef DFFW_TILE_LEAN
+// ---- the LEAN instantiations of the split-bf16 arithmetic: their own object (dffw_conv_tile_p0l.o), built beside the others ----
+hipError_t launch_conv_tile_lean0(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
+    switch (cfg->id) {
+#define X_LAUNCH(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                       \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((conv_tile<P_BF16X3, GEO, NT, TZ, TY, TX, CG, PIPE, 4, false, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.pass_split ? 4 : 1)), dim3(256), 0, s, a, t); \
+        break;
+        DFFW_TILE_CONFIGS(X_LAUNCH)
+#undef X_LAUNCH
+#define X_LAUNCH8(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                                      \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((conv_tile<P_BF16X3, GEO, NT, TZ, TY, TX, CG, PIPE, 8, false, true>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.pass_split ? 4 : 1)), dim3(512), 0, s, a, t); \
+        break;
+        DFFW_TILE_CONFIGS_W8(X_LAUNCH8)
+#undef X_LAUNCH8
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#else
 template <int PREC>
 static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
     switch (t.ksplit > 1 ? 1000 + cfg->id : ((a.dbg & DFFW_ARGS_SUMS) ? 3000 + cfg->id : ((a.dbg & DFFW_ARGS_RAW) ? 2000 + cfg->id : cfg->id))) {
@@ -800,7 +950,9 @@ hipError_t DFFW_CAT(launch_conv_tile_prec, DFFW_TILE_PREC)(const TileCfg *cfg, c
 #if DFFW_TILE_PREC == 0
 hipError_t launch_conv_tile_prec1(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
 hipError_t launch_conv_tile_prec2(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
+hipError_t launch_conv_tile_lean0(const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s);
 hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, const TileArgs &t, hipStream_t s) {
+    if (tile_lean(prec, cfg, a, t)) return launch_conv_tile_lean0(cfg, a, t, s);
     switch (prec) {
         case P_BF16X3: return launch_conv_tile_prec0(cfg, a, t, s);
         case P_FP16: return launch_conv_tile_prec1(cfg, a, t, s);
@@ -809,5 +961,6 @@ hipError_t launch_conv_tile(int prec, const TileCfg *cfg, const ConvArgs &a, con
     return hipErrorInvalidValue;
 }
 #endif
+#endif   // DFFW_TILE_LEAN
 
 }  // namespace dffw

@@ -358,6 +358,49 @@ __device__ __forceinline__ float epilogue_lean(uint16_t *__restrict__ out, uint1
     return cls;
 }
 
+// conv_tile's form of the lean epilogue: residual, classifier and the two stores are wave-uniform run-time options (one uniform
+// branch each instead of a template parameter: conv_tile already has ~50 instantiations per arithmetic), `pv` predicates the
+// stores of edge tiles, `cls` is the classifier partial carried across the 16-channel tiles of a pixel.  Same arithmetic and
+// order as epilogue_quad (out_pre store, + residual, ReLU, classifier, out store); MUST be called by all 64 lanes.
+template <int PREC>
+__device__ __forceinline__ void epilogue_lean_t(uint16_t *__restrict__ out, uint16_t *__restrict__ out_pre, int voff, float v0, float v1, float v2,
+                                                float v3, bool has_res, uint4 rq, bool relu, bool has_cls, const f32x4 &clsw, float &cls, bool pv) {
+    static_assert(Fmt<PREC>::PARTS == 2, "split-bf16 storage only");
+    auto store = [&](uint16_t *base) {
+        uint32_t h01, h23, l01, l23;
+        Fmt<PREC>::split2(v0, v1, h01, l01);
+        Fmt<PREC>::split2(v2, v3, h23, l23);
+        swap16(h01, l01);
+        swap16(h23, l23);
+        if (pv) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(base) + (uint32_t)(voff * 2)) = make_uint4(h01, h23, l01, l23);
+    };
+    if (out_pre) store(out_pre);
+    if (has_res) {
+        swap16(rq.x, rq.z);
+        swap16(rq.y, rq.w);
+        float r0, r1, r2, r3;
+        Fmt<PREC>::join2(rq.x, rq.z, r0, r1);
+        Fmt<PREC>::join2(rq.y, rq.w, r2, r3);
+        v0 += r0;
+        v1 += r1;
+        v2 += r2;
+        v3 += r3;
+    }
+    if (relu) {
+        v0 = relu_bits(v0);
+        v1 = relu_bits(v1);
+        v2 = relu_bits(v2);
+        v3 = relu_bits(v3);
+    }
+    if (has_cls) {
+        cls = fmaf(clsw[0], v0, cls);
+        cls = fmaf(clsw[1], v1, cls);
+        cls = fmaf(clsw[2], v2, cls);
+        cls = fmaf(clsw[3], v3, cls);
+    }
+    if (out) store(out);
+}
+
 // finish the fused 1x1x1 classifier: sum the partial dots of the 4 lane rows, row 0 writes the score
 // `rows`: how many 16-lane rows hold channels of the SAME pixel (4 normally; 2 when two 8-channel operand
 // tiles were packed into one register set, then rows 0-1 and 2-3 are different pixels)

@@ -1663,7 +1663,7 @@ struct Run {
                 return out;
             }
             auto kernel_name = [&](char *kn, int n) {
-                conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)), kn, n);
+                conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)), tile_lean(e->prec, cfg, a, t), kn, n);
             };
             {
                 char kn[96];
@@ -1829,7 +1829,9 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
                 const double px = (double)x.pixels();
                 // algorithmic: two 1x3x3 C -> C convs + the 3x1x1 and 1x1x1 attention convs; x read once, out (+ pooled) written once
                 r.prof_begin(kn, p, 2.0 * px * (2 * 9 + 4) * x.C * x.C, (with_pool ? 2.25 : 2.0) * px * x.C * r.elem_bytes());
+#ifdef DFFW_TRACE_BUILD
                 a.trace = r.trace_begin(p, 1024, 4);
+#endif
                 r.check(x.C == 16 ? launch_srd_roll16(r.e->prec, a, r.s) : launch_srd_roll(r.e->prec, a, r.s), "srd_roll");
                 r.prof_end();
                 r.trace_end();

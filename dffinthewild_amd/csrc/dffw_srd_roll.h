@@ -16,7 +16,10 @@ struct SrdArgs {
     int B, N, H, W;
     int tiles_y, tiles_x, total_tiles;   // 8 x 16 columns per sample, B * tiles_y * tiles_x
     int wgs;                  // workgroups to launch (0: three per CU)
-    unsigned long long *trace;   // debug step timeline (make TRACE=1, DFFW_TRACE_LAYER), or null
+#ifdef DFFW_TRACE_BUILD
+    unsigned long long *trace;   // debug step timeline (make TRACE=1, DFFW_TRACE_LAYER); the field exists in trace builds only (a larger
+                                 // argument block changes the kernels' register allocation)
+#endif
 };
 
 constexpr int SRD_CHUNKS = 3;

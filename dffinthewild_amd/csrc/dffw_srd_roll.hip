@@ -212,7 +212,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 
     int xslot = 0;
     f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
+#ifdef DFFW_TRACE_BUILD
     StepTrace trc(a.trace, wave, lane, NWAVES);
+#else
+    StepTrace trc(nullptr, wave, lane, NWAVES);
+#endif
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         // Step s of a column: phase 1 = stage A of slice s (t = conv.0) on waves 2-3 (mostly) NEXT TO stage C of slice s-2

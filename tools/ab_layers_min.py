@@ -1,0 +1,35 @@
+"""A/B of per-layer times on one box: runs bench.py's profiled forward several times per variant (alternating) and compares the
+per-layer minimum.  usage: ab_layers_min.py REPS name=ENV1=V1,ENV2=V2 name2=...   (an empty env list = the default library)"""
+import csv, os, subprocess, sys, tempfile
+reps = int(sys.argv[1])
+variants = []
+for spec in sys.argv[2:]:
+    name, _, envs = spec.partition("=")
+    env = dict(e.split("=", 1) for e in envs.split(",") if e)
+    variants.append((name, env))
+best = {n: {} for n, _ in variants}
+order = []
+for r in range(reps):
+    for name, env in variants:
+        with tempfile.NamedTemporaryFile(suffix=".tsv", delete=False) as f:
+            path = f.name
+        subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-other-configs", "--sustain-seconds", "0", "--steps", "3", "--warmup", "2",
+                        "--dump-layers", path], env=dict(os.environ, **env), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        rows = list(csv.reader(open(path), delimiter="\t"))[1:]
+        os.unlink(path)
+        for i, row in enumerate(rows):
+            key = (i, row[1])
+            if name == variants[0][0] and r == 0:
+                order.append(key)
+            best[name][key] = min(best[name].get(key, 1e9), float(row[4]))
+            best[name].setdefault(("k", i), row[0])
+names = [n for n, _ in variants]
+print("layer".ljust(46) + "".join(n.rjust(10) for n in names))
+tot = {n: 0.0 for n in names}
+for key in order:
+    vals = [best[n].get(key, float("nan")) for n in names]
+    for n, v in zip(names, vals):
+        tot[n] += v
+    flag = " *" if max(vals) - min(vals) > 0.03 * max(vals) and max(vals) > 0.02 else ""
+    print(key[1][:45].ljust(46) + "".join(f"{v:10.4f}" for v in vals) + flag)
+print("TOTAL".ljust(46) + "".join(f"{tot[n]:10.3f}" for n in names))
