@@ -2031,12 +2031,44 @@ static Act hourglass(Run &r, const std::string &p, const Act &xa, const Act &xb,
     return sum;
 }
 
-static void regress(Run &r, const char *tag, const float *score, int B, int N, int h, int w, int H, int W, const float *fd,
-                    const int64_t fst[4], float *out) {
-    if (!r.ok() || r.dry || !out) return;
-    r.prof_begin("dffw::regress_kernel", tag, 0.0, (double)B * N * h * w * 4.0 + (double)B * H * W * 4.0);
-    r.check(launch_regress(score, B, N, h, w, H, W, fd, fst[0], fst[1], fst[2], fst[3], out, r.s), tag);
-    r.prof_end();
+// The four regression heads (mid_out, pred1..3) run as ONE launch at the end of the forward (DFFW_NO_REGRESS_MERGE: one launch each,
+// where the score volume is ready): a head is queued here, its score volume stays allocated until flush_regress.
+struct RegressQueue {
+    RegressHeads hd{};
+    void *keep[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nkeep = 0;
+    double bytes = 0.0;
+};
+static void regress(Run &r, RegressQueue &q, const char *tag, float *score, int B, int N, int h, int w, int H, int W, const float *fd,
+                    const int64_t fst[4], float *out, bool merge) {
+    if (!merge) {
+        if (r.ok() && !r.dry && out) {
+            r.prof_begin("dffw::regress_kernel", tag, 0.0, (double)B * N * h * w * 4.0 + (double)B * H * W * 4.0);
+            r.check(launch_regress(score, B, N, h, w, H, W, fd, fst[0], fst[1], fst[2], fst[3], out, r.s), tag);
+            r.prof_end();
+        }
+        r.drop_raw(score);
+        return;
+    }
+    // (the score volume is kept in the dry run that sizes the workspace exactly as in the real one)
+    q.keep[q.nkeep++] = score;
+    if (!out || r.dry) return;
+    const int k = q.hd.n++;
+    q.hd.score[k] = score;
+    q.hd.depth[k] = out;
+    q.hd.h[k] = h;
+    q.hd.w[k] = w;
+    q.bytes += (double)B * N * h * w * 4.0 + (double)B * H * W * 4.0;
+}
+static void flush_regress(Run &r, RegressQueue &q, int B, int N, int H, int W, const float *fd, const int64_t fst[4]) {
+    if (q.hd.n && r.ok() && !r.dry) {
+        r.prof_begin("dffw::regress_kernel", "regress.mid_out+pred1+pred2+pred3", 0.0, q.bytes);
+        r.check(launch_regress_heads(q.hd, B, N, H, W, fd, fst[0], fst[1], fst[2], fst[3], r.s), "regress");
+        r.prof_end();
+    }
+    for (int k = 0; k < q.nkeep; ++k) r.drop_raw(q.keep[k]);
+    q.hd.n = 0;
+    q.nkeep = 0;
 }
 
 // raw != null: FS is not given; the stem reads the raw stack (or, when the tiled stem kernel does not serve this
@@ -2113,6 +2145,8 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     // confidence head -> mid_out                                                   DEN.py:83-90
     // (on side stream 0 next to dres0 / deconv_1 below 16M stack pixels: two 1/8-resolution convs and a regression head that
     // nothing else waits for -- measured +2.7 % at batch 1, +2.3 % at batch 8, -0.3 % at batch 32 where dres0 fills the chip)
+    RegressQueue rq;
+    const bool merge_heads = !getenv("DFFW_NO_REGRESS_MERGE");
     const int h8 = H / 8, w8 = W / 8;
     float *conf = (float *)r.raw((int64_t)B * N * h8 * w8 * sizeof(float));
     const bool conf_side = r.concurrent && (int64_t)B * N * H * W < (16 << 20) && !r.sw.on(SW_NO_CONF_FORK);
@@ -2127,8 +2161,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
         r.conv(P + ".confidence.2", c, of);
         r.drop(c);
         r.tap_f32("conf", conf, (int64_t)B * N * h8 * w8);
-        regress(r, "regress.mid_out", conf, B, N, h8, w8, H, W, fd, fst, out[0]);
-        r.drop_raw(conf);
+        regress(r, rq, "regress.mid_out", conf, B, N, h8, w8, H, W, fd, fst, out[0], merge_heads);
     }
     r.on(-1);
 
@@ -2149,8 +2182,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     Act s1 = hourglass(r, P + ".dres2", x1, v3, nullptr, nullptr, x1, &pre_a, &out_a, P + ".classif1.0", cost1, false);
     r.drop(x1); r.drop(v3);
     r.tap_f32("cost1", cost1, (int64_t)B * N * h4 * w4);
-    regress(r, "regress.pred1", cost1, B, N, h4, w4, H, W, fd, fst, out[1]);
-    r.drop_raw(cost1);
+    regress(r, rq, "regress.pred1", cost1, B, N, h4, w4, H, W, fd, fst, out[1], merge_heads);
 
     Act x2 = r.conv(P + ".deconv_2.0", s1);
     r.drop(s1);
@@ -2160,8 +2192,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     Act s2 = hourglass(r, P + ".dres3", x2, v2, &pre_a, &out_a, x2, &pre_b, &out_b, P + ".classif2.0", cost2, false);
     r.drop(x2); r.drop(v2); r.drop(pre_a); r.drop(out_a);
     r.tap_f32("cost2", cost2, (int64_t)B * N * h2 * w2);
-    regress(r, "regress.pred2", cost2, B, N, h2, w2, H, W, fd, fst, out[2]);
-    r.drop_raw(cost2);
+    regress(r, rq, "regress.pred2", cost2, B, N, h2, w2, H, W, fd, fst, out[2], merge_heads);
 
     Act x3 = r.conv(P + ".deconv_3.0", s2);
     r.drop(s2);
@@ -2170,8 +2201,8 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     r.drop(x3); r.drop(v1); r.drop(pre_b); r.drop(out_b);
     r.drop(s3);
     r.tap_f32("cost3", cost3, (int64_t)B * N * H * W);
-    regress(r, "regress.pred3", cost3, B, N, H, W, H, W, fd, fst, out[3]);
-    r.drop_raw(cost3);
+    regress(r, rq, "regress.pred3", cost3, B, N, H, W, H, W, fd, fst, out[3], merge_heads);
+    flush_regress(r, rq, B, N, H, W, fd, fst);
     return r.err;
 }
 

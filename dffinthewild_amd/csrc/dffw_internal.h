@@ -113,6 +113,15 @@ hipError_t launch_head_tail(int prec, const uint16_t *v, double *partial, const 
                             int C, hipStream_t s);
 hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov, float *out, float *flow, int B, int C, int N,
                            int H, int W, int alpha_from_sample0, hipStream_t s);
+// regression heads (DEN.py:83-90, 110-126) that share the output size and the focus distances: score volumes (B,N,h_k,w_k) -> depth maps (B,H,W)
+struct RegressHeads {
+    const float *score[4];
+    float *depth[4];
+    int h[4], w[4];
+    int n;
+};
+hipError_t launch_regress_heads(const RegressHeads &hd, int B, int N, int H, int W, const float *fd, int64_t fsb, int64_t fsn, int64_t fsh,
+                                int64_t fsw, hipStream_t s);
 hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd,
                           int64_t fsb, int64_t fsn, int64_t fsh, int64_t fsw, float *depth, hipStream_t s);
 

@@ -1120,9 +1120,14 @@ __device__ __forceinline__ float softplus_fast(float v) {
     return __builtin_amdgcn_logf(w) * 0.693147182464599609375f * (e / (w - 1.f));
 }
 
-__global__ __launch_bounds__(256) void regress_kernel(const float *__restrict__ score, int B, int N, int h, int w, int H,
-                                                      int W, const float *__restrict__ fd, int64_t fsb, int64_t fsn,
-                                                      int64_t fsh, int64_t fsw, float *__restrict__ depth) {
+// Up to four regression heads in ONE launch (blockIdx.y = head): the heads at 1/8, 1/4 and 1/2 resolution are 30-us launches of a
+// few thousand workgroups each; side by side with the full-resolution head they fill the gaps of each other's load chains.
+__global__ __launch_bounds__(256) void regress_kernel(const RegressHeads hd, int B, int N, int H, int W, const float *__restrict__ fd, int64_t fsb,
+                                                      int64_t fsn, int64_t fsh, int64_t fsw) {
+    const int head = blockIdx.y;
+    const float *__restrict__ score = hd.score[head];
+    float *__restrict__ depth = hd.depth[head];
+    const int h = hd.h[head], w = hd.w[head];
     const int64_t total = (int64_t)B * H * W;
     const float sch = (float)h / (float)H, scw = (float)w / (float)W;
     const bool small = total < (1ll << 31);      // 32-bit index arithmetic whenever it fits (two 64-bit divisions per pixel otherwise)
@@ -1182,12 +1187,23 @@ __global__ __launch_bounds__(256) void regress_kernel(const float *__restrict__ 
     }
 }
 
+hipError_t launch_regress_heads(const RegressHeads &hd, int B, int N, int H, int W, const float *fd, int64_t fsb, int64_t fsn, int64_t fsh,
+                                int64_t fsw, hipStream_t s) {
+    if (hd.n < 1 || hd.n > 4) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(regress_kernel, dim3(grid_for(total), (unsigned)hd.n), dim3(256), 0, s, hd, B, N, H, W, fd, fsb, fsn, fsh, fsw);
+    return hipGetLastError();
+}
+
 hipError_t launch_regress(const float *score, int B, int N, int h, int w, int H, int W, const float *fd, int64_t fsb,
                           int64_t fsn, int64_t fsh, int64_t fsw, float *depth, hipStream_t s) {
-    const int64_t total = (int64_t)B * H * W;
-    hipLaunchKernelGGL(regress_kernel, dim3(grid_for(total)), dim3(256), 0, s, score, B, N, h, w, H, W, fd, fsb, fsn, fsh,
-                       fsw, depth);
-    return hipGetLastError();
+    RegressHeads hd{};
+    hd.n = 1;
+    hd.score[0] = score;
+    hd.depth[0] = depth;
+    hd.h[0] = h;
+    hd.w[0] = w;
+    return launch_regress_heads(hd, B, N, H, W, fd, fsb, fsn, fsh, fsw, s);
 }
 
 __global__ void set_raw_kernel(RawStack rs, RawStack *dst) { *dst = rs; }
