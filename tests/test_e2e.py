@@ -126,7 +126,8 @@ def test_hip_e2e_config5_batch8_480x640(lib_built):
     """BASELINE config 5 at its stated size: 8 stacks of 10x3x480x640 in one call.  The stack of the reference golden
     (End_to_End.Network run by oracle/make_goldens_e2e.py at 1x10x480x640) sits at batch positions 1 and 6 among six other
     stacks; both must match the reference (pred3 whole, aligned stack on the golden's sample grid) and each other bit for
-    bit, and equal the batch-1 call (per-sample batch independence)."""
+    bit, and agree with the batch-1 call to 1e-4 (the result does not depend on the batch POSITION; the batch SIZE selects kernel
+    instantiations -- split-K / channel-split launches for few-tile layers -- whose summation order differs at the 1e-5 level)."""
     from oracle.make_goldens_e2e import ALIGNED_SAMPLE
     g, sd, FS1, fd1, fov1 = load(BIG[0])
     B, H, W = 8, int(g["H"]), int(g["W"])

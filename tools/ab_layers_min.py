@@ -17,19 +17,22 @@ for r in range(reps):
                         "--dump-layers", path], env=dict(os.environ, **env), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         rows = list(csv.reader(open(path), delimiter="\t"))[1:]
         os.unlink(path)
-        for i, row in enumerate(rows):
-            key = (i, row[1])
-            if name == variants[0][0] and r == 0:
+        seen = {}
+        for row in rows:
+            seen[row[1]] = seen.get(row[1], 0) + 1
+            key = (seen[row[1]], row[1])                     # layer name + its occurrence (the three pooling launches share a name)
+            if key not in order:
                 order.append(key)
             best[name][key] = min(best[name].get(key, 1e9), float(row[4]))
-            best[name].setdefault(("k", i), row[0])
 names = [n for n, _ in variants]
 print("layer".ljust(46) + "".join(n.rjust(10) for n in names))
 tot = {n: 0.0 for n in names}
 for key in order:
     vals = [best[n].get(key, float("nan")) for n in names]
     for n, v in zip(names, vals):
-        tot[n] += v
-    flag = " *" if max(vals) - min(vals) > 0.03 * max(vals) and max(vals) > 0.02 else ""
+        if v == v:
+            tot[n] += v
+    have = [v for v in vals if v == v]
+    flag = " *" if len(have) > 1 and max(have) - min(have) > 0.03 * max(have) and max(have) > 0.02 else ""
     print(key[1][:45].ljust(46) + "".join(f"{v:10.4f}" for v in vals) + flag)
 print("TOTAL".ljust(46) + "".join(f"{tot[n]:10.3f}" for n in names))
