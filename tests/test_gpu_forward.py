@@ -262,13 +262,33 @@ def test_config3_batch32_two_goldens_and_properties(lib_built, monkeypatch):
             assert torch.equal(a, b), env              # same kernels, only their stream placement differs
 
 
+@pytest.mark.parametrize("which", ["batch2_bcast", "full_10x256"])
+def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monkeypatch):
+    """conv_tile's LEAN instantiations (straight-line epilogue) run the same arithmetic in the same order as the generic
+    epilogue_quad, and the four regression heads in one launch the same as one launch each: all four outputs bit for bit."""
+    path = [p for p in GOLDEN if which in p][0]
+    g, meta, FS, fd, sd = case(path)
+    model = model_for(sd, (meta["wseed"], meta["profile"]))
+    with torch.no_grad():
+        base = [o.clone() for o in model(FS.cuda(), fd.cuda())]
+        for env in ("DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_REGRESS_MERGE"):
+            monkeypatch.setenv(env, "1")
+            alt = model(FS.cuda(), fd.cuda())
+            torch.cuda.synchronize()
+            monkeypatch.delenv(env)
+            for a, b in zip(alt, base):
+                assert torch.equal(a, b), env
+
+
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK", "DFFW_NO_SMALL", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
-                                 "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR"])
+                                 "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR",
+                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_REGRESS_MERGE"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback
     (conv_igemm, DFFW_NO_TILE), the un-split
-    few-tile launches, the unfused attention convs / pooling, and the narrow (4-wave, 16-channel-stage) tile variants."""
+    few-tile launches, the unfused attention convs / pooling, the narrow (4-wave, 16-channel-stage) tile variants, conv_tile on its
+    generic epilogue (DFFW_NO_LEAN_TILE) and one regression launch per head (DFFW_NO_REGRESS_MERGE)."""
     path = [p for p in GOLDEN if which in p][0]
     g, meta, FS, fd, sd = case(path)
     model = model_for(sd, (meta["wseed"], meta["profile"]))
