@@ -1625,7 +1625,10 @@ struct Run {
             t.nsplit = 1;
             // few-tile layers (the 1/16..1/32-resolution pyramid, or batch 1): split the output channels over
             // grid.y so that at least ~one workgroup per CU exists
-            if (t.total_tiles < 256 && pc.nt > 1 && !o.cls && !sw.on(SW_NO_SPLIT)) {
+            // (3x3x3 stride-1 and transposed layers also at exactly one tile per CU -- the 16x16-grid layers at batch 32: two 32-channel
+            // workgroups per tile keep three workgroups resident instead of two, -10 % on those layers; the stride-2 layers lose 40 % with it)
+            const int split_below = (cfg->geo == G3S1 || cfg->geo == G3T) ? 257 : 256;
+            if (t.total_tiles < split_below && pc.nt > 1 && !o.cls && !sw.on(SW_NO_SPLIT)) {
                 const int want = (256 + t.total_tiles - 1) / t.total_tiles;   // split factor that would fill the chip
                 for (int nts = pc.nt / 2; nts >= 1; nts /= 2) {               // coarsest split first
                     const TileCfg *c2 = tile_cfg_find_like(tp.cfg, nts);
