@@ -113,6 +113,7 @@ struct StepTrace {
         p = (base && lane == 0) ? base + ((int64_t)blockIdx.x * nwaves + wave) * (DFFW_TRACE_STEPS * 8) : nullptr;
         n = -DFFW_TRACE_SKIP;
     }
+    __device__ __forceinline__ void no_skip() { n = 0; }   // short streams: record from the first step
     __device__ __forceinline__ void stamp(int k) {
         if (p && n >= 0 && n < DFFW_TRACE_STEPS) p[n * 8 + k] = __builtin_amdgcn_s_memtime();
     }
@@ -127,6 +128,7 @@ struct StepTrace {
     }
 #else
     __device__ __forceinline__ StepTrace(unsigned long long *, int, int, int) {}
+    __device__ __forceinline__ void no_skip() {}
     __device__ __forceinline__ void stamp(int) {}
     __device__ __forceinline__ void next() {}
 #endif

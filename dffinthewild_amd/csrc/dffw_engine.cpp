@@ -17,6 +17,7 @@
 
 #include "../../include/dffw.h"
 #include "dffw_conv_roll.h"
+#include "dffw_conv_wino.h"
 #include "dffw_srd_roll.h"
 #include "dffw_conv_tile.h"
 #include "dffw_internal.h"
@@ -312,6 +313,7 @@ struct PackedConv {
     uint16_t *wroll_s2 = nullptr;  // device: a 3x3x3 stride-(1,2,2) 16 -> 16 / 32 filter in conv_roll_s2's order (15 chunks per 16-channel output tile)
     uint16_t *wroll_t32 = nullptr; // device: a transposed 3x3x3 32 -> 16 filter in conv_roll_t32's order (row phase 0: 9 chunks, then phase 1: 18)
     uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
+    uint16_t *wwino = nullptr;     // device: a 3x3x3 stride-1 32 -> 32k filter as conv_wino32's transformed fragments U = G g G^T (dffw_conv_wino.h)
     uint16_t *watt = nullptr;      // device: an 8 -> 8 attention conv (3x1x1 or 1x1x1) as srd_roll's stage-C fragments
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
@@ -349,6 +351,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll_t32 = nullptr;
     if (pc.wroll_s2) (void)hipFree(pc.wroll_s2);
     pc.wroll_s2 = nullptr;
+    if (pc.wwino) (void)hipFree(pc.wwino);
+    pc.wwino = nullptr;
     if (pc.wsrd) (void)hipFree(pc.wsrd);
     pc.wsrd = nullptr;
     if (pc.watt) (void)hipFree(pc.watt);
@@ -639,6 +643,33 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 }
         HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- conv_wino32: the in-plane taps in Winograd F(2x2, 3x3) form for the 32-input-channel 3x3x3 stride-1 layers.  U[xi][nu] =
+    // sum_ky,kx G[xi][ky] G[nu][kx] w[dz][ky][kx] in float64 (BatchNorm scale folded), then the usual hi + lo split; fragment order
+    // [slab of 32 outputs][position xi*4+nu][dz][nt][part][lane][8] with row = output channel, K = the 32 input channels
+    if (geo == G3S1 && cin_pad == 32 && L.cin == 32 && L.cout % 32 == 0 && !stem && !shortcut_w && prec == P_BF16X3 && !getenv("DFFW_NO_WINO")) {
+        static const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+        const int slabs = L.cout / 32;
+        std::vector<uint16_t> wr((size_t)slabs * WINO_U_SLAB, 0);
+        for (int sl = 0; sl < slabs; ++sl)
+            for (int pos = 0; pos < 16; ++pos)
+                for (int dz = 0; dz < 3; ++dz)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int cout = sl * 32 + nt * 16 + (lane & 15), cin = (lane >> 4) * 8 + j;
+                                double acc = 0.0;
+                                for (int ky = 0; ky < 3; ++ky)
+                                    for (int kx = 0; kx < 3; ++kx)
+                                        acc += Gm[pos >> 2][ky] * Gm[pos & 3][kx] * wval(cout, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
+                                uint16_t hi, lo;
+                                host_split(prec, (float)acc, hi, lo);
+                                const size_t base = (((((size_t)sl * 16 + pos) * 3 + dz) * 2 + nt) * 2) * 512 + (size_t)lane * 8 + j;
+                                wr[base] = hi;
+                                wr[base + 512] = lo;
+                            }
+        HIPCHK(hipMalloc((void **)&pc.wwino, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wwino, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- srd_roll stage C: the attention convs of the 8-channel SRD block (DEN.py:322-323) in pixel-pair form.  Result row
     // m = (pixel m >> 3 of the pair, channel m & 7).  3x1x1: chunk 0 K octet g = (pixel g >> 1, slice g & 1), chunk 1 even g =
@@ -1116,7 +1147,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, wino_min_units = 0;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1136,6 +1167,7 @@ struct Switches {
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
+        s.wino_min_units = geti("DFFW_WINO_MIN_UNITS", 0, 0);   // workgroups a 32-channel 3x3x3 layer needs for conv_wino32 (0: never)
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
@@ -1397,6 +1429,31 @@ struct Run {
             }
             a.outf = o.sums;
             a.dbg |= DFFW_ARGS_SUMS;
+        }
+        // 3x3x3 stride 1 over 32 input channels (SPP dres8_*, dres0.0, dres3.conv2 / conv4, confidence.0): Winograd F(2x2, 3x3) in-plane
+        if (pc.wwino && in0.C == 32 && !o.in1 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre && !o.cls && !o.discard && !o.sums && o.relu != 2 &&
+            Ho % WINO_TY == 0 && Wo % WINO_TX == 0 && (int64_t)in0.B * (Ho / WINO_TY) * (Wo / WINO_TX) * (L.cout / 32) >= sw.wino_min_units &&
+            sw.wino_min_units > 0) {
+            if (dry) return out;
+            WinoArgs t;
+            memset(&t, 0, sizeof t);
+            t.u = pc.wwino;
+            t.tiles_y = Ho / WINO_TY;
+            t.tiles_x = Wo / WINO_TX;
+            a.dbg = 0;
+            char kn[96];
+            conv_wino32_kernel_name(e->prec, a, kn, sizeof kn);
+            g_last_kernel = kn;
+            if (e->profiling) {
+                const double opx = (double)out.B * No * Ho * Wo;
+                const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout * elem_bytes() * (1 + (o.res0 ? 1 : 0));
+                prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout, bytes);
+            }
+            a.trace = trace_begin(name, 512, 8);
+            check(launch_conv_wino32(e->prec, a, t, s), name.c_str());
+            prof_end();
+            trace_end();
+            return out;
         }
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
