@@ -2,49 +2,58 @@
 // (the reference's nn.Conv3d + folded BatchNorm3d of the 32-channel hourglass / SPP layers, Depth_Estimation_Network/DEN.py:5-11, 96-120
 // and submodule.py:117-160).  16 MFMA multiplies per 2x2 outputs and slice tap instead of 36:
 //     U = G g G^T        per (cout, cin, dz): done once at weight-pack time in float64, split into bf16 hi + lo (pack_conv)
-//     V = B^T d B        per 4x4 input patch: fp32 from the stored hi + lo activations, re-split into hi + lo         (phase T)
-//     M[pos] += U[pos][dz] . V[pos][z + dz - 1]    three MFMA products each, fp32 accumulation, 16 positions          (phase M)
-//     y = A^T M A        fp32, then the usual epilogue (BatchNorm shift, residual, ReLU, hi + lo split)               (phase O)
+//     V = B^T d B        per 4x4 input patch: fp32 from the stored hi + lo activations, re-split into hi + lo         (T)
+//     M[pos] += U[pos][dz] . V[pos][z + dz - 1]    three MFMA products each, fp32 accumulation, 16 positions          (M)
+//     y = A^T M A        fp32, then the usual epilogue (BatchNorm shift, residual, ReLU, hi + lo split)               (O)
 // The arithmetic is not the direct kernels' (sums are re-associated by the transforms), so results differ from conv_tile's in the
 // last bits; tools/winograd_emulation.py measured pred3 on the nine goldens at 0.97e-5 .. 4.2e-5 rel-L2 (direct: 0.65e-5 .. 3.7e-5).
 //
 // One workgroup of 8 waves walks one column of 4 x 16 output pixels (16 blocks of 2 x 2) through the slices, slice-stationary: input
-// slice z is transformed once and contributes to the three output slices z+1, z, z-1 (accumulator sets A0, A1, A2, rotated every
-// step), so LDS holds V of ONE slice (16 positions x 16 blocks x 32 channels x hi + lo = 48 KB at a 96-byte pitch, conflict-free
-// ds_read_b128) plus the 32 KB hand-over of finished M values.  Wave w owns positions 2w and 2w+1 for all 16 blocks: its filter
-// fragments U[2][3 dz][2 nt][hi, lo] = 96 VGPRs stay in registers for the whole column, and a step is 36 MFMAs per wave for 2 LDS
-// fragment reads.  Phases of a step, two workgroup barriers:
-//     VALU phase: all 512 threads (16 blocks x 4 transform rows x 8 channel quads) turn the prefetched slice into V, then issue the next
-//                 slice's 16 loads (in flight across the MFMA phase); threads 0-255 (16 blocks x 2 output rows x 8 output-channel quads)
-//                 then run the output transform + epilogue of the slice finished one step earlier
-//     MFMA phase: all 8 waves contract, write the finished accumulator set to the hand-over buffer, rotate.
+// slice z is transformed once and contributes to the three output slices z+1, z, z-1 (three accumulator sets whose roles rotate with
+// the step; the step body is instantiated per rotation so that no register moves).  Wave w owns positions 2w and 2w+1 for all 16
+// blocks: its filter fragments U[2][3 dz][2 nt][hi, lo] = 96 VGPRs stay in registers for the whole column and a step is 36 MFMAs per
+// wave for 4 LDS fragment reads.  LDS (155 KB): V of two slices (16 positions x 16 blocks x 32 channels x hi + lo = 48 KB each at a
+// 96-byte pitch: conflict-free ds_read_b128), the 32 KB hand-over of finished M values, two raw slice footprints (6 x 18 pixel records,
+// filled by LDS-DMA two steps ahead).  A step overlaps three things in one instruction stream, so the transforms' VALU work runs
+// beside the MFMAs:
+//     O(s-2): every thread turns 12 hand-over values into one output pixel x 4 channels (output transform + epilogue)
+//     T(s+1): every thread (block, transform row, channel quad) turns 8 raw records into 4 positions of V[(s+1) & 1]
+//     M(s):   the wave contracts V[s & 1]
+// then barrier, hand-over write of the finished accumulator set, barrier.  Every LDS access is inline asm: behind an outstanding LDS-DMA
+// hipcc would put vmcnt(0) in front of it, i.e. wait for the slice just requested.
 #include "dffw_conv_wino.h"
 #include "dffw_device.h"
 
 #include <cstdio>
+#include <type_traits>
 
 namespace dffw {
 namespace {
 
 constexpr int WB = 16;                          // blocks per column step (2 rows x 8)
-constexpr int W_PITCH = 96;                     // bytes per (position, block) in one V plane: 32 channels x 2 B, padded from 64
+constexpr int W_PITCH = 64;                     // bytes per (position, block) in one V plane: 32 channels x 2 B; channel octet o of block r
+                                                // sits at 16-byte slot o ^ ((r >> 3) << 1): conflict-free ds_read_b128 without padding
 constexpr int W_VPLANE = 16 * WB * W_PITCH;     // one part (hi or lo) of V
-constexpr int W_MFLOATS = 16 * WB * 32;         // hand-over buffer: [position][block][32 output channels] fp32
-constexpr int W_FX = 18, W_FPIX = 6 * W_FX;       // a slice's input footprint: (4 + 2) x (16 + 2) pixels
-constexpr int W_RAWSLOT = 16384;                // ... as 128-byte records, rounded up to 16 wave-instructions of 1 KB; two slots
-constexpr int W_LDS = 2 * W_VPLANE + W_MFLOATS * 4 + 2 * W_RAWSLOT;
+constexpr int W_VBUF = 2 * W_VPLANE;            // V of one slice
+constexpr int W_MOFF = 2 * W_VBUF;              // hand-over buffer: [position][block][32 output channels] fp32
+constexpr int W_MROW = 160, W_MPOS = WB * W_MROW + 128;   // 128 B of channels per block at a 160-byte pitch (conflict-free b128 writes),
+                                                           // positions 128 B out of phase (the two pixels of an O row read both halves at once)
+constexpr int W_MBYTES = 16 * W_MPOS;
+constexpr int W_FX = 18, W_FPIX = 6 * W_FX;     // a slice's input footprint: (4 + 2) x (16 + 2) pixels
+constexpr int W_RAWOFF = W_MOFF + W_MBYTES;
+constexpr int W_RAWSLOT = W_FPIX * 128;         // ... as 128-byte records; two slots
+constexpr int W_BIASOFF = W_RAWOFF + 2 * W_RAWSLOT;   // the slab's 32 BatchNorm shifts (fp32)
+constexpr int W_LDS = W_BIASOFF + 128;
+static_assert(W_LDS <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ void wino_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2w;
 
 }  // namespace
 
-template <int PREC>
+template <int PREC, bool RES>
 __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoArgs t) {
     static_assert(PREC == P_BF16X3, "the Winograd path exists for the split-bf16 storage only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *V = smem;
-    float *Mb = reinterpret_cast<float *>(smem + 2 * W_VPLANE);
-    unsigned char *raw = smem + 2 * W_VPLANE + W_MFLOATS * 4;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
@@ -69,192 +78,249 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
                 for (int part = 0; part < 2; ++part)
                     U[pp][dz][nt][part] = *reinterpret_cast<const short8 *>(
                         t.u + ((((((size_t)slab * 16 + (2 * wave + pp)) * 3 + dz) * 2 + nt) * 2 + part) * 512) + lane * 8);
-    f32x4 acc[2][3][2];
+    f32x4 P[3][2][2];   // three accumulator sets x (position of the wave) x (16-channel output tile)
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[pp][k][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 2; ++nt) P[k][pp][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // MFMA-phase LDS addresses: the wave's V fragments (positions 2w, 2w+1; block r, channel octet g) and its hand-over rows
-    const unsigned vrd = lds0 + ((2 * wave) * WB + r) * W_PITCH + g * 16;
-    const unsigned mwr = lds0 + 2 * W_VPLANE + (((2 * wave) * WB + r) * 32 + g * 4) * 4;
+    // M: the wave's V fragments (positions 2w, 2w+1; block r, channel octet g) and its hand-over rows
+    const unsigned vrd = lds0 + ((2 * wave) * WB + r) * W_PITCH + (g ^ ((r >> 3) << 1)) * 16;
+    const unsigned mwr = lds0 + W_MOFF + (2 * wave) * W_MPOS + r * W_MROW + g * 16;
 
-    // ---- phase T role (all 512 threads): (block, transform row xi, channel quad) ---------------------------------------
+    // T: (block, transform row xi, channel quad); row xi of B^T has two non-zeros: rows (ia, ib) of the patch with signs (sa, sb)
     const int cq = tid & 7, xi = (tid >> 3) & 3, tb = tid >> 5;
     const int tby = tb >> 3, tbx = tb & 7;
-    // row xi of B^T has two non-zeros: rows (ia, ib) of the patch with signs (sa, sb)
     const int ia = xi == 0 ? 0 : 1, ib = xi == 3 ? 3 : 2;
-    const float sa = xi == 2 ? -1.f : 1.f, sb = (xi == 0 || xi == 3) ? -1.f : 1.f;
+    // (row 2 of B^T and of G are both negated against the textbook matrices -- the products U.V do not change -- so that the first sign is +1)
+    const float sb = xi == 1 ? 1.f : -1.f;
     // the slice's 6 x 18 pixel footprint sits in LDS as whole 128-byte records [hi 32 | lo 32] x 2 B (out-of-volume pixels = zeros)
-    const int ra = ((2 * tby + ia) * W_FX + 2 * tbx) * 128 + cq * 8, rb = ((2 * tby + ib) * W_FX + 2 * tbx) * 128 + cq * 8;
+    const unsigned ra = lds0 + W_RAWOFF + ((2 * tby + ia) * W_FX + 2 * tbx) * 128 + cq * 8;
+    const unsigned rb = lds0 + W_RAWOFF + ((2 * tby + ib) * W_FX + 2 * tbx) * 128 + cq * 8;
+    const unsigned vwr = lds0 + ((xi * 4) * WB + tb) * W_PITCH + ((cq >> 1) ^ ((tb >> 3) << 1)) * 16 + (cq & 1) * 8;
 
-    // ---- slice fill by LDS-DMA: 108 pixels x 8 pieces of 16 B, two rounds of 512 lanes; one wave instruction = 1 KB of the slot ------
+    // slice fill by LDS-DMA: 108 pixels x 8 pieces of 16 B, two rounds of 512 lanes; one wave instruction = 1 KB of the slot
     uint32_t foff[2];
-    bool fok[2];
+    bool fok[2], fin[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int p = k * 512 + tid, pix = p >> 3, fy = pix / W_FX, fx = pix - fy * W_FX;
         const int iy = y0 - 1 + fy, ix = x0 - 1 + fx;
-        fok[k] = pix < W_FPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        fin[k] = pix < W_FPIX;
+        fok[k] = fin[k] && iy >= 0 && iy < H && ix >= 0 && ix < W;
         foff[k] = (((uint32_t)(bs * N) * H + iy) * W + ix) * 128u + (p & 7) * 16u;   // (the launcher checks the volume is < 4 GB)
     }
     const uint32_t slice_b = (uint32_t)H * W * 128u;
     const unsigned char *inb = reinterpret_cast<const unsigned char *>(a.in0);
-    auto fill = [&](int z) {
-        unsigned char *slot = raw + (z & 1) * W_RAWSLOT;
+    auto fill = [&](int z) __attribute__((always_inline)) {
+        unsigned char *slot = smem + W_RAWOFF + (z & 1) * W_RAWSLOT;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const void *src = fok[k] ? (const void *)(inb + (foff[k] + (uint32_t)z * slice_b)) : (const void *)a.zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(slot + (k * 8 + wave) * 1024), 16, 0, 0);
+            if (fin[k])
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(slot + (k * 8 + wave) * 1024), 16, 0, 0);
         }
     };
+
+    // O: (block, output row, pixel of the row, output-channel quad): one output pixel x 4 channels from 3 x 3 hand-over values.
+    // A^T row 0 = (1, 1, 1, 0), row 1 = (0, 1, -1, -1): output row orow uses M rows orow .. orow+2, pixel px columns px .. px+2
+    const int oq = tid & 7, opx = (tid >> 3) & 1, orow = (tid >> 4) & 1, ob = tid >> 5;
+    const unsigned mrd = lds0 + W_MOFF + (orow * 4 + opx) * W_MPOS + ob * W_MROW + oq * 16;
+    const float sgr = orow ? -1.f : 1.f, sgc = opx ? -1.f : 1.f;
+    const int oco = slab * 32 + oq * 4;
+    const int C = a.Cout;
+    const unsigned brd = lds0 + W_BIASOFF + oq * 16;
+    const float rfloor = a.relu ? 0.f : -__builtin_inff();
+    // element offset of the thread's output pixel in slice 0 (the launcher checks the output volume is < 2^31 elements)
+    const uint32_t ooff0 = ((((uint32_t)(bs * N) * H + (y0 + 2 * (ob >> 3) + orow)) * W + (x0 + 2 * (ob & 7) + opx)) * 2u * C) + oco;
+    const uint32_t oslice = (uint32_t)H * W * 2u * C;
+
+#define DFFW_WINO_RAW(J, AH, AL, BH, BL, RA, RB)                                                                                      \
+    asm volatile("ds_read_b64 %0, %4 offset:%6\n\tds_read_b64 %1, %4 offset:%7\n\tds_read_b64 %2, %5 offset:%6\n\tds_read_b64 %3, %5 offset:%7" \
+                 : "=&v"(AH), "=&v"(AL), "=&v"(BH), "=&v"(BL)                                                                          \
+                 : "v"(RA), "v"(RB), "n"((J) * 128), "n"((J) * 128 + 64))
+
+    // T of slice z into V[z & 1] (raw slice in raw[z & 1])
+    auto transform = [&](int z) __attribute__((always_inline)) {
+        const unsigned ras = ra + (z & 1) * W_RAWSLOT, rbs = rb + (z & 1) * W_RAWSLOT;
+        float dp[4][4];
+#define DFFW_WINO_DP(J)                                                                                                                \
+        {                                                                                                                              \
+            u32x2w ah, al, bh, bl;                                                                                                     \
+            DFFW_WINO_RAW(J, ah, al, bh, bl, ras, rbs);                                                                                \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl));                                             \
+            float fa[4], fb[4];                                                                                                        \
+            Fmt<PREC>::join2(ah.x, al.x, fa[0], fa[1]);                                                                                \
+            Fmt<PREC>::join2(ah.y, al.y, fa[2], fa[3]);                                                                                \
+            Fmt<PREC>::join2(bh.x, bl.x, fb[0], fb[1]);                                                                                \
+            Fmt<PREC>::join2(bh.y, bl.y, fb[2], fb[3]);                                                                                \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) dp[J][c] = fa[c] + sb * fb[c];                                               \
+        }
+        DFFW_WINO_DP(0)
+        DFFW_WINO_DP(1)
+        DFFW_WINO_DP(2)
+        DFFW_WINO_DP(3)
+#undef DFFW_WINO_DP
+        const unsigned vws = vwr + (z & 1) * W_VBUF;
+#define DFFW_WINO_VW(NU, EXPR)                                                                                                         \
+        {                                                                                                                              \
+            float v[4];                                                                                                                \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) v[c] = EXPR;                                                                 \
+            uint32_t h0, l0, h1, l1;                                                                                                   \
+            Fmt<PREC>::split2(v[0], v[1], h0, l0);                                                                                     \
+            Fmt<PREC>::split2(v[2], v[3], h1, l1);                                                                                     \
+            const u32x2w vh = {h0, h1}, vl = {l0, l1};                                                                                 \
+            asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"                                             \
+                         ::"v"(vws), "v"(vh), "v"(vl), "n"((NU) * WB * W_PITCH), "n"((NU) * WB * W_PITCH + W_VPLANE));                  \
+        }
+        DFFW_WINO_VW(0, dp[0][c] - dp[2][c])
+        DFFW_WINO_VW(1, dp[1][c] + dp[2][c])
+        DFFW_WINO_VW(2, dp[1][c] - dp[2][c])
+        DFFW_WINO_VW(3, dp[1][c] - dp[3][c])
+#undef DFFW_WINO_VW
+    };
+
+#define DFFW_WINO_M3(E, M0, M1, M2)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6"                      \
+                 : "=&v"(M0), "=&v"(M1), "=&v"(M2)                                                                                      \
+                 : "v"(mrd), "n"(((E) * 4 + 0) * W_MPOS), "n"(((E) * 4 + 1) * W_MPOS), "n"(((E) * 4 + 2) * W_MPOS))
+
+    // O of output slice zo (its M values are in the hand-over buffer); rh / rl: the thread's residual piece (loaded by the caller)
+    auto output = [&](int zo) __attribute__((always_inline)) {
+        f32x4 y;
+        const uint32_t off = ooff0 + (uint32_t)zo * oslice;
+        u32x2w rh = {0, 0}, rl = {0, 0};
+        if constexpr (RES) {   // (requested here, used after the output transform: the slice fill is older and long done, so the wait is for these two only)
+            rh = *reinterpret_cast<const u32x2w *>(a.res0 + off);
+            rl = *reinterpret_cast<const u32x2w *>(a.res0 + off + C);
+        }
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(y) : "v"(brd));   // (arrives with the first hand-over values below)
+#define DFFW_WINO_OE(E, SG)                                                                                                            \
+        {                                                                                                                              \
+            f32x4 m0, m1, m2;                                                                                                          \
+            DFFW_WINO_M3(E, m0, m1, m2);                                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(y));                                               \
+            y += (SG) * (m0 + sgc * (m1 + m2));                                                                                        \
+        }
+        DFFW_WINO_OE(0, 1.f)
+        DFFW_WINO_OE(1, sgr)
+        DFFW_WINO_OE(2, sgr)
+#undef DFFW_WINO_OE
+        if constexpr (RES) {
+            float r0, r1;
+            Fmt<PREC>::join2(rh.x, rl.x, r0, r1); y[0] += r0; y[1] += r1;
+            Fmt<PREC>::join2(rh.y, rl.y, r0, r1); y[2] += r0; y[3] += r1;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = fmaxf(y[c], rfloor);
+        uint2 vh, vl;
+        Fmt<PREC>::split2(y[0], y[1], vh.x, vl.x);
+        Fmt<PREC>::split2(y[2], y[3], vh.y, vl.y);
+        *reinterpret_cast<uint2 *>(a.out + off) = vh;
+        *reinterpret_cast<uint2 *>(a.out + off + C) = vl;
+    };
+
+    // ---- prologue: slices 0 and 1 requested, slice 0 transformed -------------------------------------------------------
+    if (tid < 32) *reinterpret_cast<float *>(smem + W_BIASOFF + tid * 4) = a.bias[slab * 32 + tid];
     if (N > 0) fill(0);
+    if (N > 1) fill(1);
     // (the builtin, not asm: hipcc's wait-count pass must see that the filter fragments have arrived, or it waits vmcnt(0) -- i.e. for the
     // slice in flight -- in front of every step's first MFMA)
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
     asm volatile("s_barrier" ::: "memory");
-
-    // ---- phase O role (threads 0-255): (block, output row, output-channel quad) ----------------------------------------
-    const int oq = tid & 7, orow = (tid >> 3) & 1, ob = (tid >> 4) & 15;
-    const int oby = ob >> 3, obx = ob & 7;
+    if (N > 0) transform(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     StepTrace tr((blockIdx.x < 512 && blockIdx.y == 0) ? a.trace : nullptr, wave, lane, 8);
     tr.no_skip();
-    for (int s = 0; s <= N + 1; ++s) {
+    // one step; ROT = s % 3 fixes which accumulator set plays which role: filter slice dz accumulates into P[(dz - ROT) mod 3]
+    // (dz = 0: output slice s+1, started here; dz = 1: s; dz = 2: s-1, finished here).  FULL: 2 <= s <= N-3, every part runs.
+    auto step = [&](auto rot, auto full, int s) __attribute__((always_inline)) {
+        constexpr int ROT = decltype(rot)::value;
+        constexpr bool FULL = decltype(full)::value;
         tr.stamp(0);
-        if (s < N) {
-            float dp[4][4];
-            const unsigned char *rs = raw + (s & 1) * W_RAWSLOT;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint2 ah = *reinterpret_cast<const uint2 *>(rs + ra + j * 128), al = *reinterpret_cast<const uint2 *>(rs + ra + j * 128 + 64);
-                const uint2 bh = *reinterpret_cast<const uint2 *>(rs + rb + j * 128), bl = *reinterpret_cast<const uint2 *>(rs + rb + j * 128 + 64);
-                float fa[4], fb[4];
-                Fmt<PREC>::join2(ah.x, al.x, fa[0], fa[1]);
-                Fmt<PREC>::join2(ah.y, al.y, fa[2], fa[3]);
-                Fmt<PREC>::join2(bh.x, bl.x, fb[0], fb[1]);
-                Fmt<PREC>::join2(bh.y, bl.y, fb[2], fb[3]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dp[j][c] = sa * fa[c] + sb * fb[c];
+        const bool do_o = FULL || (s >= 2), do_t = FULL || (s + 1 < N), do_m = FULL || (s < N);
+        if (FULL || s + 2 < N) fill(s + 2);   // into the slot T(s) read one step ago; lands during this step
+        if (do_m) {
+            const unsigned vr = vrd + (s & 1) * W_VBUF;
+#define DFFW_WINO_POS(PP)                                                                                                              \
+            {                                                                                                                          \
+                short8 xh, xl;                                                                                                         \
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"                 \
+                             : "=&v"(xh), "=&v"(xl)                                                                                    \
+                             : "v"(vr), "n"((PP) * WB * W_PITCH), "n"((PP) * WB * W_PITCH + W_VPLANE));                                \
+                _Pragma("unroll") for (int dz = 0; dz < 3; ++dz) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                    \
+                    const int k = (dz - ROT + 3) % 3;                                                                                  \
+                    f32x4 c = dz == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : P[k][PP][nt];                                                      \
+                    c = mma<false>(U[PP][dz][nt][1], xh, c);                                                                           \
+                    c = mma<false>(U[PP][dz][nt][0], xl, c);                                                                           \
+                    c = mma<false>(U[PP][dz][nt][0], xh, c);                                                                           \
+                    P[k][PP][nt] = c;                                                                                                  \
+                }                                                                                                                      \
             }
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    v[c] = nu == 0 ? dp[0][c] - dp[2][c] : nu == 1 ? dp[1][c] + dp[2][c] : nu == 2 ? dp[2][c] - dp[1][c] : dp[1][c] - dp[3][c];
-                uint2 vh, vl;
-                Fmt<PREC>::split2(v[0], v[1], vh.x, vl.x);
-                Fmt<PREC>::split2(v[2], v[3], vh.y, vl.y);
-                unsigned char *dst = V + ((xi * 4 + nu) * WB + tb) * W_PITCH + cq * 8;
-                *reinterpret_cast<uint2 *>(dst) = vh;
-                *reinterpret_cast<uint2 *>(dst + W_VPLANE) = vl;
-            }
+            DFFW_WINO_POS(0)
+            DFFW_WINO_POS(1)
+#undef DFFW_WINO_POS
         }
         tr.stamp(1);
-        if (tid < 256 && s >= 2) {
-            const int zo = s - 2;
-            const int oy = y0 + 2 * oby + orow, ox = x0 + 2 * obx;
-            const int64_t pix = (((int64_t)bs * N + zo) * H + oy) * W + ox;
-            const int C = a.Cout, co = slab * 32 + oq * 4;
-            f32x4 yv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const int x = orow + e;   // row of M this output row uses: A^T row 0 = (1, 1, 1, 0), row 1 = (0, 1, -1, -1)
-                f32x4 m[4];
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) m[nu] = *reinterpret_cast<const f32x4 *>(Mb + ((x * 4 + nu) * WB + ob) * 32 + oq * 4);
-                const float sg = (orow == 1 && e > 0) ? -1.f : 1.f;
-                yv[0] += sg * (m[0] + m[1] + m[2]);
-                yv[1] += sg * (m[1] - m[2] - m[3]);
-            }
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + co);
-#pragma unroll
-            for (int px = 0; px < 2; ++px) {
-                f32x4 v = yv[px] + bv;
-                const int64_t off = (pix + px) * 2 * C + co;
-                if (a.res0) {
-                    const uint2 rh = *reinterpret_cast<const uint2 *>(a.res0 + off), rl = *reinterpret_cast<const uint2 *>(a.res0 + off + C);
-                    float r0, r1;
-                    Fmt<PREC>::join2(rh.x, rl.x, r0, r1); v[0] += r0; v[1] += r1;
-                    Fmt<PREC>::join2(rh.y, rl.y, r0, r1); v[2] += r0; v[3] += r1;
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
-                }
-                uint2 vh, vl;
-                Fmt<PREC>::split2(v[0], v[1], vh.x, vl.x);
-                Fmt<PREC>::split2(v[2], v[3], vh.y, vl.y);
-                *reinterpret_cast<uint2 *>(a.out + off) = vh;
-                *reinterpret_cast<uint2 *>(a.out + off + C) = vl;
-            }
-        }
+        if (do_t) transform(s + 1);
         tr.stamp(2);
-        if (s + 1 < N) fill(s + 1);   // in flight across the MFMA phase
-        wino_barrier();
+        if (do_o) output(s - 2);
         tr.stamp(3);
-        if (s <= N) {
-            if (s < N) {
-                // (inline asm: behind an outstanding LDS-DMA hipcc puts vmcnt(0) in front of every LDS access, which would wait for the slice
-                // just requested instead of letting it land during the MFMAs)
-                short8 xh[2], xl[2];
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(xh[0]), "=&v"(xl[0]), "=&v"(xh[1]), "=&v"(xl[1])
-                             : "v"(vrd), "n"(W_VPLANE), "n"(WB * W_PITCH), "n"(WB * W_PITCH + W_VPLANE));
-#pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                    for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            f32x4 c = acc[pp][dz][nt];
-                            c = mma<false>(U[pp][dz][nt][1], xh[pp], c);
-                            c = mma<false>(U[pp][dz][nt][0], xl[pp], c);
-                            c = mma<false>(U[pp][dz][nt][0], xh[pp], c);
-                            acc[pp][dz][nt] = c;
-                        }
-            }
-            // set 2 (filter slice dz = 2 applied to input slice s) completes output slice s - 1
-            if (s >= 1) {
-                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:64\n\tds_write_b128 %0, %3 offset:%5\n\tds_write_b128 %0, %4 offset:%6"
-                             ::"v"(mwr), "v"(acc[0][2][0]), "v"(acc[0][2][1]), "v"(acc[1][2][0]), "v"(acc[1][2][1]), "n"(WB * 32 * 4), "n"(WB * 32 * 4 + 64));
-            }
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    acc[pp][2][nt] = acc[pp][1][nt];
-                    acc[pp][1][nt] = acc[pp][0][nt];
-                    acc[pp][0][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every thread has read its hand-over values
+        if (s >= 1 && (FULL || s <= N)) {
+            constexpr int k2 = (2 - ROT + 3) % 3;
+            asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:64\n\tds_write_b128 %0, %3 offset:%5\n\tds_write_b128 %0, %4 offset:%6"
+                         ::"v"(mwr), "v"(P[k2][0][0]), "v"(P[k2][0][1]), "v"(P[k2][1][0]), "v"(P[k2][1][1]), "n"(W_MPOS), "n"(W_MPOS + 64));
         }
         tr.stamp(4);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next slice has landed, for every wave
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slice s+2 has landed, V[(s+1) & 1] and the hand-over are written
         tr.stamp(5);
         tr.next();
+    };
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    auto partial = [&](int s) __attribute__((always_inline)) {   // the column's first two and last four steps: parts switched off at run time
+        switch (s % 3) {
+            case 0: step(R0{}, std::false_type{}, s); break;
+            case 1: step(R1{}, std::false_type{}, s); break;
+            default: step(R2{}, std::false_type{}, s); break;
+        }
+    };
+    for (int s = 0; s <= N + 1;) {
+        if (s >= 2 && s + 4 < N && s % 3 == 2) {   // three full steps (2 <= s and s + 2 + 2 < N), straight-line
+            step(R2{}, std::true_type{}, s);
+            step(R0{}, std::true_type{}, s + 1);
+            step(R1{}, std::true_type{}, s + 2);
+            s += 3;
+        } else {
+            partial(s);
+            ++s;
+        }
     }
+#undef DFFW_WINO_RAW
+#undef DFFW_WINO_M3
 }
 
 hipError_t launch_conv_wino32(int prec, const ConvArgs &a, const WinoArgs &t, hipStream_t s) {
-    if ((int64_t)a.B * a.Ni * a.Hi * a.Wi * 128 >= (int64_t)1 << 32) return hipErrorInvalidValue;
+    if ((int64_t)a.B * a.Ni * a.Hi * a.Wi * 128 >= (int64_t)1 << 32 || (int64_t)a.B * a.Ni * a.Hi * a.Wi * 2 * a.Cout >= (int64_t)1 << 31) return hipErrorInvalidValue;
     if (prec != P_BF16X3 || a.C0 != 32 || a.C1 != 0 || a.Cout % 32 || a.Hi % WINO_TY || a.Wi % WINO_TX || !a.out) return hipErrorInvalidValue;
-    auto k = conv_wino32<P_BF16X3>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    auto k = a.res0 ? conv_wino32<P_BF16X3, true> : conv_wino32<P_BF16X3, false>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[a.res0 ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[a.res0 ? 1 : 0] = true;
     }
     const dim3 grid((unsigned)(a.B * t.tiles_y * t.tiles_x), (unsigned)(a.Cout / 32));
     hipLaunchKernelGGL(k, grid, dim3(512), W_LDS, s, a, t);
     return hipGetLastError();
 }
 
-void conv_wino32_kernel_name(int prec, const ConvArgs &, char *buf, int n) { snprintf(buf, n, "dffw::conv_wino32<%d>", prec); }
+void conv_wino32_kernel_name(int prec, const ConvArgs &a, char *buf, int n) { snprintf(buf, n, "dffw::conv_wino32<%d, %s>", prec, a.res0 ? "true" : "false"); }
 
 }  // namespace dffw

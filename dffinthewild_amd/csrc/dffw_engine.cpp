@@ -648,7 +648,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // sum_ky,kx G[xi][ky] G[nu][kx] w[dz][ky][kx] in float64 (BatchNorm scale folded), then the usual hi + lo split; fragment order
     // [slab of 32 outputs][position xi*4+nu][dz][nt][part][lane][8] with row = output channel, K = the 32 input channels
     if (geo == G3S1 && cin_pad == 32 && L.cin == 32 && L.cout % 32 == 0 && !stem && !shortcut_w && prec == P_BF16X3 && !getenv("DFFW_NO_WINO")) {
-        static const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+        static const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {-.5, .5, -.5}, {0, 0, 1}};   // (row 2 negated, like the kernel's B^T row 2)
         const int slabs = L.cout / 32;
         std::vector<uint16_t> wr((size_t)slabs * WINO_U_SLAB, 0);
         for (int sl = 0; sl < slabs; ++sl)
