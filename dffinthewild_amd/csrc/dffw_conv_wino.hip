@@ -33,7 +33,8 @@ namespace {
 constexpr int WB = 16;                          // blocks per column step (2 rows x 8)
 constexpr int W_PITCH = 64;                     // bytes per (position, block) in one V plane: 32 channels x 2 B; channel octet o of block r
                                                 // sits at 16-byte slot o ^ ((r >> 3) << 1): conflict-free ds_read_b128 without padding
-constexpr int W_VPLANE = 16 * WB * W_PITCH;     // one part (hi or lo) of V
+constexpr int W_VPOS = WB * W_PITCH + 16;       // bytes per position: 16 B out of phase, so that T's writes (a lane per position) spread over the banks
+constexpr int W_VPLANE = 16 * W_VPOS;           // one part (hi or lo) of V
 constexpr int W_VBUF = 2 * W_VPLANE;            // V of one slice
 constexpr int W_MOFF = 2 * W_VBUF;              // hand-over buffer: [position][block][32 output channels] fp32
 constexpr int W_MROW = 160, W_MPOS = WB * W_MROW + 128;   // 128 B of channels per block at a 160-byte pitch (conflict-free b128 writes),
@@ -47,6 +48,7 @@ constexpr int W_LDS = W_BIASOFF + 128;
 static_assert(W_LDS <= 160 * 1024, "LDS budget");
 
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2w;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4w;
 
 }  // namespace
 
@@ -87,19 +89,31 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
             for (int nt = 0; nt < 2; ++nt) P[k][pp][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // M: the wave's V fragments (positions 2w, 2w+1; block r, channel octet g) and its hand-over rows
-    const unsigned vrd = lds0 + ((2 * wave) * WB + r) * W_PITCH + (g ^ ((r >> 3) << 1)) * 16;
+    const unsigned vrd = lds0 + (2 * wave) * W_VPOS + r * W_PITCH + (g ^ ((r >> 3) << 1)) * 16;
     const unsigned mwr = lds0 + W_MOFF + (2 * wave) * W_MPOS + r * W_MROW + g * 16;
 
-    // T: (block, transform row xi, channel quad); row xi of B^T has two non-zeros: rows (ia, ib) of the patch with signs (sa, sb)
-    const int cq = tid & 7, xi = (tid >> 3) & 3, tb = tid >> 5;
-    const int tby = tb >> 3, tbx = tb & 7;
-    const int ia = xi == 0 ? 0 : 1, ib = xi == 3 ? 3 : 2;
-    // (row 2 of B^T and of G are both negated against the textbook matrices -- the products U.V do not change -- so that the first sign is +1)
-    const float sb = xi == 1 ? 1.f : -1.f;
-    // the slice's 6 x 18 pixel footprint sits in LDS as whole 128-byte records [hi 32 | lo 32] x 2 B (out-of-volume pixels = zeros)
-    const unsigned ra = lds0 + W_RAWOFF + ((2 * tby + ia) * W_FX + 2 * tbx) * 128 + cq * 8;
-    const unsigned rb = lds0 + W_RAWOFF + ((2 * tby + ib) * W_FX + 2 * tbx) * 128 + cq * 8;
-    const unsigned vwr = lds0 + ((xi * 4) * WB + tb) * W_PITCH + ((cq >> 1) ^ ((tb >> 3) << 1)) * 16 + (cq & 1) * 8;
+    // T runs on the matrix core too: for one block and 16 channels, D[channel][position] = sum over the 32 keys (part, patch pixel) of
+    // d_part[pixel][channel] * (B^T[xi][i] B^T[nu][j]) -- the constant operand holds 0 / +-1, exact in bf16, and summing both parts in the fp32
+    // accumulator IS the hi + lo join.  The data operand wants, per lane, 8 pixels of ONE channel from records that are channel-contiguous:
+    // ds_read_b64_tr_b16 (each lane of a 16-lane group addresses one 8-byte piece [key row i >> 2][channel chunk i & 3]; lane n receives
+    // column n of the group's 4 x 16 block).  Wave w transforms blocks 2w, 2w+1 (both channel groups): 8 reads + 4 MFMAs per step.
+    // (row 2 of B^T and of G are both negated against the textbook matrices: the products U.V do not change)
+    const int li = lane & 15;
+    const int tby = wave >> 2, tbx0 = 2 * (wave & 3);
+    const unsigned trd = lds0 + W_RAWOFF + ((2 * tby + (g & 1) * 2) * W_FX + 2 * tbx0 + (li >> 2)) * 128 + (g >> 1) * 64 + (li & 3) * 8;
+    // write side: lane (g, n) holds channels 4g .. 4g+3 of the group for position n
+    const unsigned twr = lds0 + r * W_VPOS + (2 * wave) * W_PITCH + ((g >> 1) ^ (tby << 1)) * 16 + (g & 1) * 8;
+    const int tcg = tby ? -32 : 32;   // the second channel group's octets: slot bit 1 flipped
+    short8 tconst;
+    {
+        const int xi = r >> 2, nu = r & 3;
+        auto bt = [](int x, int i) { return x == 0 ? (i == 0 ? 1 : i == 2 ? -1 : 0) : x == 1 ? (i == 1 || i == 2 ? 1 : 0) : x == 2 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : (i == 1 ? 1 : i == 3 ? -1 : 0); };
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int v = bt(xi, (g & 1) * 2 + (e >> 2)) * bt(nu, e & 3);
+            tconst[e] = (short)(v == 0 ? 0 : v > 0 ? 0x3F80 : 0xBF80);
+        }
+    }
 
     // slice fill by LDS-DMA: 108 pixels x 8 pieces of 16 B, two rounds of 512 lanes; one wave instruction = 1 KB of the slot
     uint32_t foff[2];
@@ -138,49 +152,33 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
     const uint32_t ooff0 = ((((uint32_t)(bs * N) * H + (y0 + 2 * (ob >> 3) + orow)) * W + (x0 + 2 * (ob & 7) + opx)) * 2u * C) + oco;
     const uint32_t oslice = (uint32_t)H * W * 2u * C;
 
-#define DFFW_WINO_RAW(J, AH, AL, BH, BL, RA, RB)                                                                                      \
-    asm volatile("ds_read_b64 %0, %4 offset:%6\n\tds_read_b64 %1, %4 offset:%7\n\tds_read_b64 %2, %5 offset:%6\n\tds_read_b64 %3, %5 offset:%7" \
-                 : "=&v"(AH), "=&v"(AL), "=&v"(BH), "=&v"(BL)                                                                          \
-                 : "v"(RA), "v"(RB), "n"((J) * 128), "n"((J) * 128 + 64))
-
     // T of slice z into V[z & 1] (raw slice in raw[z & 1])
     auto transform = [&](int z) __attribute__((always_inline)) {
-        const unsigned ras = ra + (z & 1) * W_RAWSLOT, rbs = rb + (z & 1) * W_RAWSLOT;
-        float dp[4][4];
-#define DFFW_WINO_DP(J)                                                                                                                \
+        const unsigned rs = trd + (z & 1) * W_RAWSLOT;
+        const unsigned ws = twr + (z & 1) * W_VBUF;
+        u32x2w ta[4][2];
+        asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%9\n\t"
+                     "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:%10\n\t"
+                     "ds_read_b64_tr_b16 %4, %8 offset:256\n\tds_read_b64_tr_b16 %5, %8 offset:%11\n\t"
+                     "ds_read_b64_tr_b16 %6, %8 offset:288\n\tds_read_b64_tr_b16 %7, %8 offset:%12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]), "=&v"(ta[2][0]), "=&v"(ta[2][1]), "=&v"(ta[3][0]), "=&v"(ta[3][1])
+                     : "v"(rs), "n"(W_FX * 128), "n"(32 + W_FX * 128), "n"(256 + W_FX * 128), "n"(288 + W_FX * 128));
+#define DFFW_WINO_TITEM(IT, BLK, CG)                                                                                                   \
         {                                                                                                                              \
-            u32x2w ah, al, bh, bl;                                                                                                     \
-            DFFW_WINO_RAW(J, ah, al, bh, bl, ras, rbs);                                                                                \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al), "+v"(bh), "+v"(bl));                                             \
-            float fa[4], fb[4];                                                                                                        \
-            Fmt<PREC>::join2(ah.x, al.x, fa[0], fa[1]);                                                                                \
-            Fmt<PREC>::join2(ah.y, al.y, fa[2], fa[3]);                                                                                \
-            Fmt<PREC>::join2(bh.x, bl.x, fb[0], fb[1]);                                                                                \
-            Fmt<PREC>::join2(bh.y, bl.y, fb[2], fb[3]);                                                                                \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) dp[J][c] = fa[c] + sb * fb[c];                                               \
-        }
-        DFFW_WINO_DP(0)
-        DFFW_WINO_DP(1)
-        DFFW_WINO_DP(2)
-        DFFW_WINO_DP(3)
-#undef DFFW_WINO_DP
-        const unsigned vws = vwr + (z & 1) * W_VBUF;
-#define DFFW_WINO_VW(NU, EXPR)                                                                                                         \
-        {                                                                                                                              \
-            float v[4];                                                                                                                \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) v[c] = EXPR;                                                                 \
+            const short8 av = __builtin_bit_cast(short8, (u32x4w){ta[IT][0].x, ta[IT][0].y, ta[IT][1].x, ta[IT][1].y});                \
+            const f32x4 d = mma<false>(av, tconst, f32x4{0.f, 0.f, 0.f, 0.f});                                                         \
             uint32_t h0, l0, h1, l1;                                                                                                   \
-            Fmt<PREC>::split2(v[0], v[1], h0, l0);                                                                                     \
-            Fmt<PREC>::split2(v[2], v[3], h1, l1);                                                                                     \
+            Fmt<PREC>::split2(d[0], d[1], h0, l0);                                                                                     \
+            Fmt<PREC>::split2(d[2], d[3], h1, l1);                                                                                     \
             const u32x2w vh = {h0, h1}, vl = {l0, l1};                                                                                 \
             asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4"                                             \
-                         ::"v"(vws), "v"(vh), "v"(vl), "n"((NU) * WB * W_PITCH), "n"((NU) * WB * W_PITCH + W_VPLANE));                  \
+                         ::"v"((CG) ? ws + tcg : ws), "v"(vh), "v"(vl), "n"((BLK) * W_PITCH), "n"((BLK) * W_PITCH + W_VPLANE));         \
         }
-        DFFW_WINO_VW(0, dp[0][c] - dp[2][c])
-        DFFW_WINO_VW(1, dp[1][c] + dp[2][c])
-        DFFW_WINO_VW(2, dp[1][c] - dp[2][c])
-        DFFW_WINO_VW(3, dp[1][c] - dp[3][c])
-#undef DFFW_WINO_VW
+        DFFW_WINO_TITEM(0, 0, 0)
+        DFFW_WINO_TITEM(1, 0, 1)
+        DFFW_WINO_TITEM(2, 1, 0)
+        DFFW_WINO_TITEM(3, 1, 1)
+#undef DFFW_WINO_TITEM
     };
 
 #define DFFW_WINO_M3(E, M0, M1, M2)                                                                                                    \
@@ -244,14 +242,14 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
         tr.stamp(0);
         const bool do_o = FULL || (s >= 2), do_t = FULL || (s + 1 < N), do_m = FULL || (s < N);
         if (FULL || s + 2 < N) fill(s + 2);   // into the slot T(s) read one step ago; lands during this step
-        if (do_m) {
+        auto contract = [&]() __attribute__((always_inline)) {
             const unsigned vr = vrd + (s & 1) * W_VBUF;
 #define DFFW_WINO_POS(PP)                                                                                                              \
             {                                                                                                                          \
                 short8 xh, xl;                                                                                                         \
                 asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"                 \
                              : "=&v"(xh), "=&v"(xl)                                                                                    \
-                             : "v"(vr), "n"((PP) * WB * W_PITCH), "n"((PP) * WB * W_PITCH + W_VPLANE));                                \
+                             : "v"(vr), "n"((PP) * W_VPOS), "n"((PP) * W_VPOS + W_VPLANE));                                            \
                 _Pragma("unroll") for (int dz = 0; dz < 3; ++dz) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                    \
                     const int k = (dz - ROT + 3) % 3;                                                                                  \
                     f32x4 c = dz == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : P[k][PP][nt];                                                      \
@@ -264,11 +262,90 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
             DFFW_WINO_POS(0)
             DFFW_WINO_POS(1)
 #undef DFFW_WINO_POS
+        };
+        if constexpr (FULL) {
+            // every LDS read of the step is requested up front (they return in order): the MFMAs start when the four fragments are in,
+            // and the transform's and the output's operands arrive behind them
+            const unsigned vr = vrd + (s & 1) * W_VBUF;
+            const unsigned rs = trd + ((s + 1) & 1) * W_RAWSLOT;
+            short8 xh[2], xl[2];
+            u32x2w ta[4][2];
+            f32x4 y, m[3][3];
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7"
+                         : "=&v"(xh[0]), "=&v"(xl[0]), "=&v"(xh[1]), "=&v"(xl[1])
+                         : "v"(vr), "n"(W_VPLANE), "n"(W_VPOS), "n"(W_VPOS + W_VPLANE));
+            asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%9\n\t"
+                         "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:%10\n\t"
+                         "ds_read_b64_tr_b16 %4, %8 offset:256\n\tds_read_b64_tr_b16 %5, %8 offset:%11\n\t"
+                         "ds_read_b64_tr_b16 %6, %8 offset:288\n\tds_read_b64_tr_b16 %7, %8 offset:%12"
+                         : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]), "=&v"(ta[2][0]), "=&v"(ta[2][1]), "=&v"(ta[3][0]), "=&v"(ta[3][1])
+                         : "v"(rs), "n"(W_FX * 128), "n"(32 + W_FX * 128), "n"(256 + W_FX * 128), "n"(288 + W_FX * 128));
+            u32x2w rh = {0, 0}, rl = {0, 0};
+            const uint32_t off = ooff0 + (uint32_t)(s - 2) * oslice;
+            if constexpr (RES) {
+                rh = *reinterpret_cast<const u32x2w *>(a.res0 + off);
+                rl = *reinterpret_cast<const u32x2w *>(a.res0 + off + C);
+            }
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]));
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int k = (dz - ROT + 3) % 3;
+                        f32x4 c = dz == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : P[k][pp][nt];
+                        c = mma<false>(U[pp][dz][nt][1], xh[pp], c);
+                        c = mma<false>(U[pp][dz][nt][0], xl[pp], c);
+                        c = mma<false>(U[pp][dz][nt][0], xh[pp], c);
+                        P[k][pp][nt] = c;
+                    }
+            tr.stamp(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0][0]), "+v"(ta[0][1]), "+v"(ta[1][0]), "+v"(ta[1][1]), "+v"(ta[2][0]), "+v"(ta[2][1]), "+v"(ta[3][0]), "+v"(ta[3][1]));
+            // (the LGKM counter has 4 bits: never more than 15 requests in flight -- the hand-over reads go out only now, and land behind the transform)
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(y) : "v"(brd));
+            DFFW_WINO_M3(0, m[0][0], m[0][1], m[0][2]);
+            DFFW_WINO_M3(1, m[1][0], m[1][1], m[1][2]);
+            DFFW_WINO_M3(2, m[2][0], m[2][1], m[2][2]);
+            const unsigned ws = twr + ((s + 1) & 1) * W_VBUF;
+            u32x2w tvh[4], tvl[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const short8 av = __builtin_bit_cast(short8, (u32x4w){ta[it][0].x, ta[it][0].y, ta[it][1].x, ta[it][1].y});
+                const f32x4 d = mma<false>(av, tconst, f32x4{0.f, 0.f, 0.f, 0.f});
+                uint32_t h0, l0, h1, l1;
+                Fmt<PREC>::split2(d[0], d[1], h0, l0);
+                Fmt<PREC>::split2(d[2], d[3], h1, l1);
+                tvh[it] = u32x2w{h0, h1};
+                tvl[it] = u32x2w{l0, l1};
+            }
+            tr.stamp(2);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(y), "+v"(m[0][0]), "+v"(m[0][1]), "+v"(m[0][2]), "+v"(m[1][0]), "+v"(m[1][1]), "+v"(m[1][2]), "+v"(m[2][0]), "+v"(m[2][1]), "+v"(m[2][2]));
+            asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %0, %3 offset:%10\n\tds_write_b64 %1, %4\n\tds_write_b64 %1, %5 offset:%10\n\t"
+                         "ds_write_b64 %0, %6 offset:%11\n\tds_write_b64 %0, %7 offset:%12\n\tds_write_b64 %1, %8 offset:%11\n\tds_write_b64 %1, %9 offset:%12"
+                         ::"v"(ws), "v"(ws + tcg), "v"(tvh[0]), "v"(tvl[0]), "v"(tvh[1]), "v"(tvl[1]), "v"(tvh[2]), "v"(tvl[2]), "v"(tvh[3]), "v"(tvl[3]),
+                           "n"(W_VPLANE), "n"(W_PITCH), "n"(W_PITCH + W_VPLANE));
+            y += (m[0][0] + sgc * (m[0][1] + m[0][2])) + sgr * ((m[1][0] + sgc * (m[1][1] + m[1][2])) + (m[2][0] + sgc * (m[2][1] + m[2][2])));
+            if constexpr (RES) {
+                float r0, r1;
+                Fmt<PREC>::join2(rh.x, rl.x, r0, r1); y[0] += r0; y[1] += r1;
+                Fmt<PREC>::join2(rh.y, rl.y, r0, r1); y[2] += r0; y[3] += r1;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = fmaxf(y[c], rfloor);
+            uint2 vh, vl;
+            Fmt<PREC>::split2(y[0], y[1], vh.x, vl.x);
+            Fmt<PREC>::split2(y[2], y[3], vh.y, vl.y);
+            *reinterpret_cast<uint2 *>(a.out + off) = vh;
+            *reinterpret_cast<uint2 *>(a.out + off + C) = vl;
+        } else {
+            if (do_m) contract();
+            tr.stamp(1);
+            if (do_t) transform(s + 1);
+            tr.stamp(2);
+            if (do_o) output(s - 2);
         }
-        tr.stamp(1);
-        if (do_t) transform(s + 1);
-        tr.stamp(2);
-        if (do_o) output(s - 2);
         tr.stamp(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every thread has read its hand-over values
         if (s >= 1 && (FULL || s <= N)) {
@@ -302,7 +379,6 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
             ++s;
         }
     }
-#undef DFFW_WINO_RAW
 #undef DFFW_WINO_M3
 }
 

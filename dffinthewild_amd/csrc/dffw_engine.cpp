@@ -1167,7 +1167,11 @@ struct Switches {
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
-        s.wino_min_units = geti("DFFW_WINO_MIN_UNITS", 0, 0);   // workgroups a 32-channel 3x3x3 layer needs for conv_wino32 (0: never)
+        // conv_wino32 (Winograd F(2x2, 3x3) for the 32-input-channel 3x3x3 stride-1 layers) is opt-in: DFFW_WINO_MIN_UNITS = columns a layer needs
+        // to take it (0 / unset: never).  Measured r03 at batch 32 (512 / 2048 columns): 4-7 % under conv_tile per layer in the serial
+        // profile, level on the whole forward (3560 / 3607 vs 3558 / 3643 stacks/s: its one 136 KB workgroup per CU does not share the CU
+        // with the concurrent branches the way conv_tile's do), so the default keeps the direct kernels and their bit-exact history
+        s.wino_min_units = geti("DFFW_WINO_MIN_UNITS", 0, 0);
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
