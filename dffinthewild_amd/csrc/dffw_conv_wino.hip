@@ -12,15 +12,18 @@
 // slice z is transformed once and contributes to the three output slices z+1, z, z-1 (three accumulator sets whose roles rotate with
 // the step; the step body is instantiated per rotation so that no register moves).  Wave w owns positions 2w and 2w+1 for all 16
 // blocks: its filter fragments U[2][3 dz][2 nt][hi, lo] = 96 VGPRs stay in registers for the whole column and a step is 36 MFMAs per
-// wave for 4 LDS fragment reads.  LDS (155 KB): V of two slices (16 positions x 16 blocks x 32 channels x hi + lo = 48 KB each at a
-// 96-byte pitch: conflict-free ds_read_b128), the 32 KB hand-over of finished M values, two raw slice footprints (6 x 18 pixel records,
-// filled by LDS-DMA two steps ahead).  A step overlaps three things in one instruction stream, so the transforms' VALU work runs
-// beside the MFMAs:
-//     O(s-2): every thread turns 12 hand-over values into one output pixel x 4 channels (output transform + epilogue)
-//     T(s+1): every thread (block, transform row, channel quad) turns 8 raw records into 4 positions of V[(s+1) & 1]
-//     M(s):   the wave contracts V[s & 1]
-// then barrier, hand-over write of the finished accumulator set, barrier.  Every LDS access is inline asm: behind an outstanding LDS-DMA
-// hipcc would put vmcnt(0) in front of it, i.e. wait for the slice just requested.
+// wave for 4 LDS fragment reads.  LDS (134 KB): V of two slices (16 positions x 16 blocks x 32 channels x hi + lo = 32.5 KB each; 64-byte
+// block pitch with the channel octets XOR-swizzled by the block's upper half: conflict-free ds_read_b128 without padding), the 42 KB fp32
+// hand-over of finished M values (160-byte block pitch, positions 128 B out of phase), two raw slice footprints (6 x 18 pixel records,
+// filled by LDS-DMA two steps ahead).  A full step runs three independent parts in one instruction stream:
+//     M(s):   the wave contracts V[s & 1] (its two positions, three slice taps)
+//     T(s+1): the input transform of the next slice ON THE MATRIX CORE: wave w takes blocks 2w, 2w+1; the data operand (8 patch pixels of one
+//             channel per lane) comes through ds_read_b64_tr_b16, the other operand is the constant 0 / +-1 matrix B^T (x) B^T, and adding
+//             the hi and lo parts in the fp32 accumulator is the join -- 8 reads + 4 MFMAs + the hi/lo re-split per wave
+//     O(s-2): every thread turns 3 x 3 hand-over values into one output pixel x 4 channels (output transform + epilogue)
+// then barrier, hand-over write of the finished accumulator set, barrier.  Every LDS access is inline asm with counted waits: behind an
+// outstanding LDS-DMA hipcc would put vmcnt(0) in front of it, i.e. wait for the slice just requested.  Measured: 4-7 %
+// under conv_tile per layer, level on the whole forward; opt-in through DFFW_WINO_MIN_UNITS.
 #include "dffw_conv_wino.h"
 #include "dffw_device.h"
 
