@@ -62,6 +62,7 @@ struct TileArgs {
     int ksplit;               // grid.z: split of the contraction depth (channel-group stages) over workgroups, 1 = none
     float *partial;           // ksplit > 1: fp32 partial sums [ksplit][output pixel][nt_total*16], finished by splitk_finish
     int64_t partial_stride;   // elements per split = output pixels * nt_total*16
+    int warm;                 // few-tile launches on cold weights: every workgroup first touches the weight lines of its whole contraction walk
 };
 
 // returns nullptr when no instantiation covers (geo, nt, cg)

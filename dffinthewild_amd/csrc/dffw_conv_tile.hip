@@ -314,6 +314,29 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     } else if (!(a.dbg & 1)) {
         issue_fill(cur, st_lo);
     }
+    if (t.warm) {
+        // Few-tile launches (batch 1, the low-resolution pyramid): the contraction loop requests a chunk's weight fragments only one chunk
+        // ahead, which covers an L2 hit but not the ~1-2 us of a miss -- and with a handful of workgroups per layer nobody else has pulled
+        // the filter into this XCD's L2 (measured r03, one 10x256x256 stack: SPP conv8 = 32 chunks per workgroup in 42 us).  So every
+        // thread first touches its share of the 128-byte lines of the workgroup's whole walk (all its passes, stages, chunks, its output
+        // tiles); the touches travel with the footprint DMA and are waited for with it.
+        uint32_t sink = 0;
+        const int wstride = NTT * PARTS * 64;
+        for (int pass = pass_lo; pass < pass_hi; ++pass) {
+            const int KCp = t.KC[pass];
+            const int nlines = (st_hi - st_lo) * KCp * NT * PARTS * 8;
+            const unsigned char *wb = reinterpret_cast<const unsigned char *>(t.wpk[pass]);
+            for (int i = tid; i < nlines; i += NWAVES * 64) {
+                const int l8 = i & 7, f = (i >> 3) % (NT * PARTS), c = (i >> 3) / (NT * PARTS);
+                const int kc = c % KCp, st = st_lo + c / KCp;
+                const unsigned char *p = wb + ((((int64_t)st * KCp + kc) * wstride + ntb * PARTS * 64 + f * 64) * 16 + l8 * 128);
+                // ("+v": the destination stays live from one touch to the next -- as a plain output hipcc would hand the register to the next
+                // iteration's address arithmetic while the load is still in flight)
+                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
+    }
     stamp(1);
 
     {

@@ -1147,7 +1147,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, wino_min_units = 0;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, wino_min_units = 0, warm_max_wgs = 1024;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1167,6 +1167,10 @@ struct Switches {
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
+        // conv_tile launches of at most this many (tile, channel-split) workgroups touch the weight lines of their whole contraction walk first
+        // (TileArgs::warm; 0: never).  Measured r03 on 10x256x256 stacks, ms per forward at 0 / 256 / 1024 / always: batch 2 1.29 / 1.17 / 1.17 /
+        // 1.17, batch 8 2.74 / 2.65 / 2.63 / 2.63, batch 16 4.71 / 4.66 / 4.62 / 4.66, batch 32 8.58 / 8.57 / 8.57 / 8.70
+        s.warm_max_wgs = geti("DFFW_WARM_MAX_WGS", 0, 1024);
         // conv_wino32 (Winograd F(2x2, 3x3) for the 32-input-channel 3x3x3 stride-1 layers) is opt-in: DFFW_WINO_MIN_UNITS = columns a layer needs
         // to take it (0 / unset: never).  Measured r03 at batch 32 (512 / 2048 columns): 4-7 % under conv_tile per layer in the serial
         // profile, level on the whole forward (3560 / 3607 vs 3558 / 3643 stacks/s: its one 136 KB workgroup per CU does not share the CU
@@ -1704,6 +1708,7 @@ struct Run {
             // stages deep, the stages are dealt to grid.z workgroups (fp32 partials, summed in fixed order by
             // splitk_finish) so that one workgroup no longer walks all of them in sequence
             t.ksplit = 1;
+            t.warm = (t.total_tiles * t.nsplit <= sw.warm_max_wgs) ? 1 : 0;
             float *partial = nullptr;
             const int64_t M_out = (int64_t)out.B * No * Ho * Wo;
             // transposed conv on few tiles: its 4 sub-pixel passes as 4 workgroups (no reduction, any epilogue)

@@ -265,14 +265,15 @@ def test_config3_batch32_two_goldens_and_properties(lib_built, monkeypatch):
 @pytest.mark.parametrize("which", ["batch2_bcast", "full_10x256"])
 def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monkeypatch):
     """conv_tile's LEAN instantiations (straight-line epilogue) run the same arithmetic in the same order as the generic
-    epilogue_quad, and the four regression heads in one launch the same as one launch each: all four outputs bit for bit."""
+    epilogue_quad, the four regression heads in one launch the same as one launch each, and the few-tile launches' weight warm-up
+    (TileArgs::warm) only touches memory: all four outputs bit for bit."""
     path = [p for p in GOLDEN if which in p][0]
     g, meta, FS, fd, sd = case(path)
     model = model_for(sd, (meta["wseed"], meta["profile"]))
     with torch.no_grad():
         base = [o.clone() for o in model(FS.cuda(), fd.cuda())]
-        for env in ("DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_REGRESS_MERGE"):
-            monkeypatch.setenv(env, "1")
+        for env, val in (("DFFW_NO_LEAN_TILE", "1"), ("DFFW_NO_LEAN_ROLL", "1"), ("DFFW_NO_REGRESS_MERGE", "1"), ("DFFW_WARM_MAX_WGS", "0")):
+            monkeypatch.setenv(env, val)
             alt = model(FS.cuda(), fd.cuda())
             torch.cuda.synchronize()
             monkeypatch.delenv(env)
