@@ -326,6 +326,10 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
             const int KCp = t.KC[pass];
             const int nlines = (st_hi - st_lo) * KCp * NT * PARTS * 8;
             const unsigned char *wb = reinterpret_cast<const unsigned char *>(t.wpk[pass]);
+            if (tid * 128 < KCp * 16) {   // ... and of the pass's tap-offset table (4 ints per chunk)
+                const unsigned char *p = reinterpret_cast<const unsigned char *>(t.tab[pass]) + tid * 128;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
+            }
             for (int i = tid; i < nlines; i += NWAVES * 64) {
                 const int l8 = i & 7, f = (i >> 3) % (NT * PARTS), c = (i >> 3) / (NT * PARTS);
                 const int kc = c % KCp, st = st_lo + c / KCp;
