@@ -15,14 +15,14 @@
 // wave for 4 LDS fragment reads.  LDS (134 KB): V of two slices (16 positions x 16 blocks x 32 channels x hi + lo = 32.5 KB each; 64-byte
 // block pitch with the channel octets XOR-swizzled by the block's upper half: conflict-free ds_read_b128 without padding), the 42 KB fp32
 // hand-over of finished M values (160-byte block pitch, positions 128 B out of phase), two raw slice footprints (6 x 18 pixel records,
-// filled by LDS-DMA two steps ahead).  A full step runs three independent parts in one instruction stream:
+// piece pairs XOR-swizzled by the pixel's (x >> 1, y >> 1) parities for the transposing reads; filled by LDS-DMA two steps ahead).  A full step runs three independent parts in one instruction stream:
 //     M(s):   the wave contracts V[s & 1] (its two positions, three slice taps)
 //     T(s+1): the input transform of the next slice ON THE MATRIX CORE: wave w takes blocks 2w, 2w+1; the data operand (8 patch pixels of one
 //             channel per lane) comes through ds_read_b64_tr_b16, the other operand is the constant 0 / +-1 matrix B^T (x) B^T, and adding
 //             the hi and lo parts in the fp32 accumulator is the join -- 8 reads + 4 MFMAs + the hi/lo re-split per wave
 //     O(s-2): every thread turns 3 x 3 hand-over values into one output pixel x 4 channels (output transform + epilogue)
 // then barrier, hand-over write of the finished accumulator set, barrier.  Every LDS access is inline asm with counted waits: behind an
-// outstanding LDS-DMA hipcc would put vmcnt(0) in front of it, i.e. wait for the slice just requested.  Measured: 4-7 %
+// outstanding LDS-DMA hipcc would put vmcnt(0) in front of it, i.e. wait for the slice just requested.  Measured: 9-13 %
 // under conv_tile per layer, level on the whole forward; opt-in through DFFW_WINO_MIN_UNITS.
 #include "dffw_conv_wino.h"
 #include "dffw_device.h"
@@ -47,7 +47,8 @@ constexpr int W_FX = 18, W_FPIX = 6 * W_FX;     // a slice's input footprint: (4
 constexpr int W_RAWOFF = W_MOFF + W_MBYTES;
 constexpr int W_RAWSLOT = W_FPIX * 128;         // ... as 128-byte records; two slots
 constexpr int W_BIASOFF = W_RAWOFF + 2 * W_RAWSLOT;   // the slab's 32 BatchNorm shifts (fp32)
-constexpr int W_LDS = W_BIASOFF + 128;
+constexpr int W_TCOFF = W_BIASOFF + 128;           // the transform's constant operand, one 16-byte fragment per lane (the same in every wave)
+constexpr int W_LDS = W_TCOFF + 1024;
 static_assert(W_LDS <= 160 * 1024, "LDS budget");
 
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2w;
@@ -58,7 +59,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4w;
 template <int PREC, bool RES>
 __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoArgs t) {
     static_assert(PREC == P_BF16X3, "the Winograd path exists for the split-bf16 storage only");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
@@ -103,18 +104,22 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
     // (row 2 of B^T and of G are both negated against the textbook matrices: the products U.V do not change)
     const int li = lane & 15;
     const int tby = wave >> 2, tbx0 = 2 * (wave & 3);
-    const unsigned trd = lds0 + W_RAWOFF + ((2 * tby + (g & 1) * 2) * W_FX + 2 * tbx0 + (li >> 2)) * 128 + (g >> 1) * 64 + (li & 3) * 8;
+    // (raw records are stored with their four 32-byte piece pairs [part][channel group] XOR-ed by ((x >> 1) & 1) | (((y >> 1) & 1) << 1) of the
+    // footprint pixel: the 8 pixels x 32 B one half-wave of a transposing read covers -- 4 columns x 2 rows two apart -- then fall on
+    // 8 different bank groups instead of 2.  Channel group 1 and block 1 each flip bit 0 of that index: address ^ 32.)
+    const int tsw = ((tbx0 + (li >> 3)) & 1) | (((tby + (g & 1)) & 1) << 1);
+    const unsigned trd = lds0 + W_RAWOFF + ((2 * tby + (g & 1) * 2) * W_FX + 2 * tbx0 + (li >> 2)) * 128 + ((((g >> 1) * 2) ^ tsw) * 32) + (li & 3) * 8;
     // write side: lane (g, n) holds channels 4g .. 4g+3 of the group for position n
     const unsigned twr = lds0 + r * W_VPOS + (2 * wave) * W_PITCH + ((g >> 1) ^ (tby << 1)) * 16 + (g & 1) * 8;
     const int tcg = tby ? -32 : 32;   // the second channel group's octets: slot bit 1 flipped
-    short8 tconst;
+    short8 tconst0;
     {
         const int xi = r >> 2, nu = r & 3;
         auto bt = [](int x, int i) { return x == 0 ? (i == 0 ? 1 : i == 2 ? -1 : 0) : x == 1 ? (i == 1 || i == 2 ? 1 : 0) : x == 2 ? (i == 1 ? 1 : i == 2 ? -1 : 0) : (i == 1 ? 1 : i == 3 ? -1 : 0); };
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int v = bt(xi, (g & 1) * 2 + (e >> 2)) * bt(nu, e & 3);
-            tconst[e] = (short)(v == 0 ? 0 : v > 0 ? 0x3F80 : 0xBF80);
+            tconst0[e] = (short)(v == 0 ? 0 : v > 0 ? 0x3F80 : 0xBF80);
         }
     }
 
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
         const int iy = y0 - 1 + fy, ix = x0 - 1 + fx;
         fin[k] = pix < W_FPIX;
         fok[k] = fin[k] && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        foff[k] = (((uint32_t)(bs * N) * H + iy) * W + ix) * 128u + (p & 7) * 16u;   // (the launcher checks the volume is < 4 GB)
+        const int fsw = ((fx >> 1) & 1) | (((fy >> 1) & 1) << 1);               // the slot's piece pair holds the record's pair (slot ^ fsw)
+        foff[k] = (((uint32_t)(bs * N) * H + iy) * W + ix) * 128u + (((((p >> 1) & 3) ^ fsw) << 1) | (p & 1)) * 16u;   // (the launcher checks the volume is < 4 GB)
     }
     const uint32_t slice_b = (uint32_t)H * W * 128u;
     const unsigned char *inb = reinterpret_cast<const unsigned char *>(a.in0);
@@ -150,6 +156,7 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
     const int oco = slab * 32 + oq * 4;
     const int C = a.Cout;
     const unsigned brd = lds0 + W_BIASOFF + oq * 16;
+    const unsigned tcrd = lds0 + W_TCOFF + lane * 16;
     const float rfloor = a.relu ? 0.f : -__builtin_inff();
     // element offset of the thread's output pixel in slice 0 (the launcher checks the output volume is < 2^31 elements)
     const uint32_t ooff0 = ((((uint32_t)(bs * N) * H + (y0 + 2 * (ob >> 3) + orow)) * W + (x0 + 2 * (ob & 7) + opx)) * 2u * C) + oco;
@@ -160,12 +167,14 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
         const unsigned rs = trd + (z & 1) * W_RAWSLOT;
         const unsigned ws = twr + (z & 1) * W_VBUF;
         u32x2w ta[4][2];
-        asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%9\n\t"
-                     "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:%10\n\t"
-                     "ds_read_b64_tr_b16 %4, %8 offset:256\n\tds_read_b64_tr_b16 %5, %8 offset:%11\n\t"
-                     "ds_read_b64_tr_b16 %6, %8 offset:288\n\tds_read_b64_tr_b16 %7, %8 offset:%12\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]), "=&v"(ta[2][0]), "=&v"(ta[2][1]), "=&v"(ta[3][0]), "=&v"(ta[3][1])
-                     : "v"(rs), "n"(W_FX * 128), "n"(32 + W_FX * 128), "n"(256 + W_FX * 128), "n"(288 + W_FX * 128));
+        short8 tconst;
+        asm volatile("ds_read_b64_tr_b16 %0, %9\n\tds_read_b64_tr_b16 %1, %9 offset:%11\n\t"
+                     "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %10 offset:%11\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:256\n\tds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+                     "ds_read_b64_tr_b16 %6, %9 offset:256\n\tds_read_b64_tr_b16 %7, %9 offset:%12\n\tds_read_b128 %8, %13\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]), "=&v"(ta[2][0]), "=&v"(ta[2][1]), "=&v"(ta[3][0]), "=&v"(ta[3][1]),
+                       "=&v"(tconst)
+                     : "v"(rs), "v"(rs ^ 32u), "n"(W_FX * 128), "n"(256 + W_FX * 128), "v"(tcrd));
 #define DFFW_WINO_TITEM(IT, BLK, CG)                                                                                                   \
         {                                                                                                                              \
             const short8 av = __builtin_bit_cast(short8, (u32x4w){ta[IT][0].x, ta[IT][0].y, ta[IT][1].x, ta[IT][1].y});                \
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
 
     // ---- prologue: slices 0 and 1 requested, slice 0 transformed -------------------------------------------------------
     if (tid < 32) *reinterpret_cast<float *>(smem + W_BIASOFF + tid * 4) = a.bias[slab * 32 + tid];
+    if (tid < 64) *reinterpret_cast<short8 *>(smem + W_TCOFF + tid * 16) = tconst0;   // (kept in LDS, not in 4 VGPRs: the kernel sits at the 256-register limit)
     if (N > 0) fill(0);
     if (N > 1) fill(1);
     // (the builtin, not asm: hipcc's wait-count pass must see that the filter fragments have arrived, or it waits vmcnt(0) -- i.e. for the
@@ -273,22 +283,17 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
             const unsigned rs = trd + ((s + 1) & 1) * W_RAWSLOT;
             short8 xh[2], xl[2];
             u32x2w ta[4][2];
-            f32x4 y, m[3][3];
+            short8 tconst;
+            f32x4 y, m[2][3];
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7"
                          : "=&v"(xh[0]), "=&v"(xl[0]), "=&v"(xh[1]), "=&v"(xl[1])
                          : "v"(vr), "n"(W_VPLANE), "n"(W_VPOS), "n"(W_VPOS + W_VPLANE));
-            asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%9\n\t"
-                         "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:%10\n\t"
-                         "ds_read_b64_tr_b16 %4, %8 offset:256\n\tds_read_b64_tr_b16 %5, %8 offset:%11\n\t"
-                         "ds_read_b64_tr_b16 %6, %8 offset:288\n\tds_read_b64_tr_b16 %7, %8 offset:%12"
+            asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%10\n\t"
+                         "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%10\n\t"
+                         "ds_read_b64_tr_b16 %4, %9 offset:256\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+                         "ds_read_b64_tr_b16 %6, %8 offset:256\n\tds_read_b64_tr_b16 %7, %8 offset:%11"
                          : "=&v"(ta[0][0]), "=&v"(ta[0][1]), "=&v"(ta[1][0]), "=&v"(ta[1][1]), "=&v"(ta[2][0]), "=&v"(ta[2][1]), "=&v"(ta[3][0]), "=&v"(ta[3][1])
-                         : "v"(rs), "n"(W_FX * 128), "n"(32 + W_FX * 128), "n"(256 + W_FX * 128), "n"(288 + W_FX * 128));
-            u32x2w rh = {0, 0}, rl = {0, 0};
-            const uint32_t off = ooff0 + (uint32_t)(s - 2) * oslice;
-            if constexpr (RES) {
-                rh = *reinterpret_cast<const u32x2w *>(a.res0 + off);
-                rl = *reinterpret_cast<const u32x2w *>(a.res0 + off + C);
-            }
+                         : "v"(rs), "v"(rs ^ 32u), "n"(W_FX * 128), "n"(256 + W_FX * 128));
             asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]));
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp)
@@ -303,13 +308,22 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
                         c = mma<false>(U[pp][dz][nt][0], xh[pp], c);
                         P[k][pp][nt] = c;
                     }
+            // the residual of the pixel O finishes below: requested behind the contraction (its registers are free now), used ~1000 cycles on
+            u32x2w rh = {0, 0}, rl = {0, 0};
+            const uint32_t off = ooff0 + (uint32_t)(s - 2) * oslice;
+            if constexpr (RES) {
+                rh = *reinterpret_cast<const u32x2w *>(a.res0 + off);
+                rl = *reinterpret_cast<const u32x2w *>(a.res0 + off + C);
+            }
             tr.stamp(1);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[0][0]), "+v"(ta[0][1]), "+v"(ta[1][0]), "+v"(ta[1][1]), "+v"(ta[2][0]), "+v"(ta[2][1]), "+v"(ta[3][0]), "+v"(ta[3][1]));
-            // (the LGKM counter has 4 bits: never more than 15 requests in flight -- the hand-over reads go out only now, and land behind the transform)
+            // (the LGKM counter has 4 bits: never more than 15 requests in flight -- the hand-over reads go out only now, and land behind the
+            // transform; in front of them the transform's constant operand, which is needed at once)
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(tconst) : "v"(tcrd));
             asm volatile("ds_read_b128 %0, %1" : "=&v"(y) : "v"(brd));
             DFFW_WINO_M3(0, m[0][0], m[0][1], m[0][2]);
             DFFW_WINO_M3(1, m[1][0], m[1][1], m[1][2]);
-            DFFW_WINO_M3(2, m[2][0], m[2][1], m[2][2]);
+            asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(tconst));
             const unsigned ws = twr + ((s + 1) & 1) * W_VBUF;
             u32x2w tvh[4], tvl[4];
 #pragma unroll
@@ -323,13 +337,18 @@ __global__ __launch_bounds__(512) void conv_wino32(const ConvArgs a, const WinoA
                 tvl[it] = u32x2w{l0, l1};
             }
             tr.stamp(2);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(y), "+v"(m[0][0]), "+v"(m[0][1]), "+v"(m[0][2]), "+v"(m[1][0]), "+v"(m[1][1]), "+v"(m[1][2]), "+v"(m[2][0]), "+v"(m[2][1]), "+v"(m[2][2]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y), "+v"(m[0][0]), "+v"(m[0][1]), "+v"(m[0][2]), "+v"(m[1][0]), "+v"(m[1][1]), "+v"(m[1][2]));
             asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %0, %3 offset:%10\n\tds_write_b64 %1, %4\n\tds_write_b64 %1, %5 offset:%10\n\t"
                          "ds_write_b64 %0, %6 offset:%11\n\tds_write_b64 %0, %7 offset:%12\n\tds_write_b64 %1, %8 offset:%11\n\tds_write_b64 %1, %9 offset:%12"
                          ::"v"(ws), "v"(ws + tcg), "v"(tvh[0]), "v"(tvl[0]), "v"(tvh[1]), "v"(tvl[1]), "v"(tvh[2]), "v"(tvl[2]), "v"(tvh[3]), "v"(tvl[3]),
                            "n"(W_VPLANE), "n"(W_PITCH), "n"(W_PITCH + W_VPLANE));
-            y += (m[0][0] + sgc * (m[0][1] + m[0][2])) + sgr * ((m[1][0] + sgc * (m[1][1] + m[1][2])) + (m[2][0] + sgc * (m[2][1] + m[2][2])));
+            // (the third row of hand-over values goes into the first row's registers once that row is summed: 24 registers instead of 36)
+            y += m[0][0] + sgc * (m[0][1] + m[0][2]);
+            DFFW_WINO_M3(2, m[0][0], m[0][1], m[0][2]);
+            f32x4 yr = m[1][0] + sgc * (m[1][1] + m[1][2]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m[0][0]), "+v"(m[0][1]), "+v"(m[0][2]));
+            yr += m[0][0] + sgc * (m[0][1] + m[0][2]);
+            y += sgr * yr;
             if constexpr (RES) {
                 float r0, r1;
                 Fmt<PREC>::join2(rh.x, rl.x, r0, r1); y[0] += r0; y[1] += r1;

@@ -1172,9 +1172,9 @@ struct Switches {
         // 1.17, batch 8 2.74 / 2.65 / 2.63 / 2.63, batch 16 4.71 / 4.66 / 4.62 / 4.66, batch 32 8.58 / 8.57 / 8.57 / 8.70
         s.warm_max_wgs = geti("DFFW_WARM_MAX_WGS", 0, 1024);
         // conv_wino32 (Winograd F(2x2, 3x3) for the 32-input-channel 3x3x3 stride-1 layers) is opt-in: DFFW_WINO_MIN_UNITS = columns a layer needs
-        // to take it (0 / unset: never).  Measured r03 at batch 32 (512 / 2048 columns): 4-7 % under conv_tile per layer in the serial
-        // profile, level on the whole forward (3560 / 3607 vs 3558 / 3643 stacks/s: its one 136 KB workgroup per CU does not share the CU
-        // with the concurrent branches the way conv_tile's do), so the default keeps the direct kernels and their bit-exact history
+        // to take it (0 / unset: never).  Measured r03 at batch 32 (512 / 2048 columns): 9-13 % under conv_tile per layer in the serial
+        // profile, level on the whole forward (five alternating runs: 8.797 vs 8.792 ms; its one 134 KB workgroup per CU does not share the
+        // CU with the concurrent SPP branches the way conv_tile's do), so the default keeps the direct kernels and their bit-exact history
         s.wino_min_units = geti("DFFW_WINO_MIN_UNITS", 0, 0);
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
