@@ -24,6 +24,11 @@ hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipS
 // the kernel family has an instantiation that prefetches a residual
 bool roll_lean(int prec, const ConvArgs &a, bool res_variant);
 void conv_roll_kernel_name(int prec, const ConvArgs &a, bool pair, char *buf, int n);   // the instantiation launch_conv_roll picks for `a`
+// conv_rollx (dffw_conv_rollx.hip): the software-pipelined step (epilogue of step n-1 and fill of slice n+5 inside the contraction of step n,
+// buffer-addressed fills) for the pair-form layers in split-bf16 storage; launch_conv_roll / conv_roll_kernel_name route to it when it applies
+bool rollx_pair_ok(int prec, const ConvArgs &a, bool pair);
+hipError_t launch_conv_rollx_pair(const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_rollx_pair_kernel_name(const ConvArgs &a, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
 // transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one

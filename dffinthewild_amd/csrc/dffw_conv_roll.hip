@@ -1426,6 +1426,7 @@ void roll_tile(int *ty, int *tx) {
 }
 
 void conv_roll_kernel_name(int prec, const ConvArgs &a, bool pair, char *buf, int n) {
+    if (rollx_pair_ok(prec, a, pair)) return conv_rollx_pair_kernel_name(a, buf, n);
     const bool res = a.res0 != nullptr && prec == P_BF16X3;
     snprintf(buf, n, "dffw::conv_roll<%d, %d, %d, %d, %d, %s, %s, %s>", prec, DFFW_ROLL_TY, DFFW_ROLL_TX, DFFW_ROLL_NW, DFFW_ROLL_RING, tf(res), tf(pair),
              tf(roll_lean(prec, a, true) && !a.cls_w));
@@ -1563,6 +1564,7 @@ hipError_t launch_conv_roll_s2(int prec, int nt, int kh, const ConvArgs &a, cons
 }
 
 hipError_t launch_conv_roll(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    if (rollx_pair_ok(prec, a, t.pair != 0)) return launch_conv_rollx_pair(a, t, s);
     // persistent grid: two resident workgroups per CU (72 KiB of LDS each), a multiple of the 8 XCDs, never more
     // workgroups than an XCD has columns
     const int want = t.wgs > 0 ? t.wgs : 512;

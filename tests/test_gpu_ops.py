@@ -159,7 +159,9 @@ def test_conv_small_grids(eng, case, prec, monkeypatch):
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("cout,N,H,W,zsplit,residual,wgs", [(8, 10, 128, 128, 1, True, 0), (16, 5, 128, 128, 1, False, 24), (8, 1, 64, 256, 1, False, 8),
-                                                             (16, 10, 64, 256, 2, True, 40), (16, 7, 128, 128, 3, False, 0), (8, 2, 128, 128, 2, True, 16)])
+                                                             (16, 10, 64, 256, 2, True, 40), (16, 7, 128, 128, 3, False, 0), (8, 2, 128, 128, 2, True, 16),
+                                                             (8, 10, 128, 128, 1, False, 0), (8, 7, 64, 256, 3, False, 24), (8, 2, 128, 128, 2, False, 16),
+                                                             (8, 3, 128, 128, 3, False, 8)])
 def test_conv_roll_rolling_window(eng, cout, N, H, W, zsplit, residual, wgs, prec, monkeypatch):
     """conv_roll (dffw_conv_roll.hip): the 16-channel 3x3x3 stride-1 layers of the full-resolution hourglass
     (DEN.py:240-284, dres4.conv0 / conv2) as a rolling window along the slices; every slice count incl. 1 and 2,
@@ -177,8 +179,15 @@ def test_conv_roll_rolling_window(eng, cout, N, H, W, zsplit, residual, wgs, pre
     if wgs:
         monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
     got = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
-    assert eng.last_conv_kernel().startswith("dffw::conv_roll<"), eng.last_conv_kernel()
+    # the pair-form layers without a residual run the software-pipelined step in split-bf16 storage (conv_rollx, round 4)
+    pipelined = cout == 8 and not residual and prec == "bf16x3"
+    assert eng.last_conv_kernel().startswith("dffw::conv_rollx_pair<" if pipelined else "dffw::conv_roll<"), eng.last_conv_kernel()
     assert rel(got, ref) <= TOL[prec], rel(got, ref)
+    if pipelined:   # ... and the serial step must give the same values (three accumulators instead of two: fp32 re-association only)
+        monkeypatch.setenv("DFFW_NO_ROLLX", "1")
+        old = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, residual=None, relu=1, precision=prec)
+        assert eng.last_conv_kernel().startswith("dffw::conv_roll<"), eng.last_conv_kernel()
+        assert rel(got, old) <= 2e-6, rel(got, old)
     monkeypatch.setenv("DFFW_NO_ROLL", "1")
     alt = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
     assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
