@@ -29,6 +29,11 @@ void conv_roll_kernel_name(int prec, const ConvArgs &a, bool pair, char *buf, in
 bool rollx_pair_ok(int prec, const ConvArgs &a, bool pair);
 hipError_t launch_conv_rollx_pair(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_rollx_pair_kernel_name(const ConvArgs &a, char *buf, int n);
+// ... and for 32 -> 16 channels with the contraction split over the two 16-channel input halves (8 waves, columns of 8 x 16; filter packed as
+// [half][ROLL_CHUNKS chunks][part][64 lanes][8], chunk order as conv_roll's plain form)
+bool rollx_k2_ok(int prec, const ConvArgs &a);
+hipError_t launch_conv_rollx_k2(const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_rollx_k2_kernel_name(const ConvArgs &a, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
 // transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one

@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(NT * KH == 4 ? 512 : 256) void conv_roll_s2(const C
 // prefetches it (`res_variant`); whole 16-channel (or packed 8-channel) result tiles.
 bool roll_lean(int prec, const ConvArgs &a, bool res_variant) {
     return prec == P_BF16X3 && (a.out || a.out_pre || a.cls_w) && !a.outf && !a.res1 && !a.res_bcast && a.relu != 2 && (res_variant || !a.res0) &&
-           (a.Cout == 8 || a.Cout % 16 == 0) && !getenv("DFFW_NO_LEAN_ROLL");   // (the switch: generic epilogue, for A/B and the parity tests)
+           (a.Cout == 8 || a.Cout % 16 == 0) && !(a.dbg & DFFW_ARGS_NO_LEAN_ROLL);   // (the switch: generic epilogue, for A/B and the parity tests)
 }
 static const char *tf(bool b) { return b ? "true" : "false"; }
 

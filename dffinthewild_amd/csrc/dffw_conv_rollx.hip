@@ -321,8 +321,317 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- conv_rollx_k2: the same pipelined step for 32 input -> 16 output channels (`dres3.conv0`, DEN.py:240-284: the full-resolution conv
+// of the middle hourglass over the concat of two 16-channel volumes) ------------------------------------------------------------------
+// 16 output channels fill the MFMA result rows (no pixel pairs) and the filter of 32 input channels (27 chunks, 216 VGPRs) does not fit one
+// wave, so the contraction is split over the two 16-channel halves of the input: waves 0-3 hold the filter of half 0 (15 chunks [dz][5
+// chunks of 2 in-slice taps x 16 channels], tap 9 = zeros: conv_roll's order), waves 4-7 that of half 1; wave w and wave w + 4 contract the
+// same two 16-pixel rows of the 8 x 16 column.  After its contraction a wave hands ONE of its two partial tiles to its partner through LDS
+// (double-buffered: the partner may be a step ahead) and keeps the other: in the next step -- inside that step's contraction, as in
+// conv_rollx_pair -- it adds the partner's partial to its own and runs the epilogue of that one tile.  One workgroup of 8 waves per CU
+// (ring of 5 slices x 2 halves x 12 KiB + 16 KiB exchange = 136 KiB), i.e. the same two waves per SIMD as the 4-wave kernels.
+// LDS slice image per half: [row][part][18 pixels][channel octet] in 16-byte entries (rows of 1152 bytes): a DMA piece covers whole 64-byte
+// records of ~0.9 footprint rows; the 16 lanes of an operand read are 16 consecutive pixels at a 32-byte pitch and lane rows g, g + 1 take
+// the two channel octets of the same tap: conflict-free as in conv_roll.
+namespace rollk2 {
+constexpr int TY = 8, TX = 16, FY = TY + 2, FX = TX + 2, NW = 8, RING = 5;
+constexpr int ROWE = 4 * FX;          // 16-byte entries per footprint row of a half: [hi: 18 pixels x 2 octets][lo: the same]
+constexpr int ROWB = ROWE * 16;       // 1152
+constexpr int PARTB = 2 * FX * 16;    // 576: offset of a row's lo part
+constexpr int HPL = 12 * 1024;        // a half's plane: 10 rows of 1152 bytes, padded to 12 DMA pieces
+constexpr int SLOTB = 2 * HPL;
+constexpr int PPW = 3;                // DMA pieces per wave and slice (24 pieces, 8 waves)
+constexpr int NCH = 15;
+constexpr int XCH_OFF = RING * SLOTB, XCHB = 8 * 1024;   // two exchange buffers of 8 tiles x 1 KiB behind the ring
+static_assert(FY * ROWB <= HPL && 2 * (HPL / 1024) == NW * PPW, "piece layout");
+}   // namespace rollk2
+
+template <bool RELU>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_rollx_k2(const ConvArgs a, const RollArgs t) {
+    using namespace rollk2;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[XCH_OFF + 2 * XCHB];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wave >> 2, wq = wave & 3;          // K half (= source tensor of a concat) and the pair of rows this wave contracts
+    const int g = lane >> 4, r = lane & 15;
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, zbeg, nz, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % t.tiles_x;
+        int tt = u / t.tiles_x;
+        const int tyi = tt % t.tiles_y;
+        tt /= t.tiles_y;
+        const int zp = tt % t.zsplit;
+        c.b = tt / t.zsplit;
+        c.gy0 = tyi * TY;
+        c.gx0 = txi * TX;
+        c.zbeg = zp * a.No / t.zsplit;
+        c.nz = (zp + 1) * a.No / t.zsplit - c.zbeg;
+        return c;
+    };
+
+    // ---- fill: a wave's three pieces belong to its own half (waves 0-3: in0 / channels 0-15, waves 4-7: in1 / channels 16-31) ----
+    const bool two = a.C1 != 0;
+    const int recb = two ? 64 : 128;                    // bytes per pixel record of the source tensor ([hi C][lo C])
+    const char *tbase = reinterpret_cast<const char *>((two && half) ? a.in1 : a.in0) + (two ? 0 : half * 32);
+    const int slice_bytes = a.Hi * a.Wi * recb;
+    int fyx[PPW], foff[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int e = (wq * PPW + k) * 64 + lane;                  // 16-byte entry inside the half's plane: [row][part][pixel][octet]
+        const int fy = e / ROWE, j = e - fy * ROWE;
+        const int part = j >= 2 * FX ? 1 : 0, q = j - part * 2 * FX;
+        const int fx = q >> 1, oct = q & 1;
+        fyx[k] = fy | (fx << 8) | (e < FY * ROWE ? 0 : 1 << 16);
+        foff[k] = (fy * a.Wi + fx) * recb + part * (recb / 2) + oct * 16;
+    }
+    int fvo[PPW];
+    const char *fbase = tbase;
+    int fu = ufirst, fq = 0, fslices = 0, fz = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+        fslices = c.nz + 2;
+        fz = c.zbeg - 1;
+        fbase = tbase + ((int64_t)c.b * a.Ni * a.Hi * a.Wi + (int64_t)(c.gy0 - 1) * a.Wi + (c.gx0 - 1)) * recb;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int iy = c.gy0 - 1 + (fyx[k] & 0xFF), ix = c.gx0 - 1 + ((fyx[k] >> 8) & 0xFF);
+            fvo[k] = (!(fyx[k] >> 16) && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) ? foff[k] : (int)0x80000000;
+        }
+    };
+    setup_fill();
+    int fslotb = 0;
+    auto issue_piece = [&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const bool zin = (unsigned)fz < (unsigned)a.Ni && fu < uend;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fbase), 0, zin ? (int)0x80000000 : 0, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + fslotb + (wave * PPW + k) * 1024), 16, fvo[k],
+                                                 zin ? fz * slice_bytes : 0, 0, 0);
+    };
+    auto advance_fill = [&]() {
+        fslotb = (fslotb + SLOTB == RING * SLOTB) ? 0 : fslotb + SLOTB;
+        ++fz;
+        if (++fq == fslices && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) {
+        issue_piece(std::integral_constant<int, 0>{});
+        issue_piece(std::integral_constant<int, 1>{});
+        issue_piece(std::integral_constant<int, 2>{});
+        advance_fill();
+    }
+
+    // ---- operand addressing: tile j of the wave = row 2*wq + j, column r; K octet g of chunk k5 = (tap 2*k5 + (g >> 1), channel octet g & 1)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned aoff[5];
+#pragma unroll
+    for (int k5 = 0; k5 < 5; ++k5) {
+        const int tap9 = 2 * k5 + (g >> 1);
+        const int dy = tap9 < 9 ? tap9 / 3 : 0, dx = tap9 < 9 ? tap9 % 3 : 0;
+        aoff[k5] = lds0 + half * HPL + (2 * wq + dy) * ROWB + ((r + dx) * 2 + (g & 1)) * 16;
+    }
+    // the tile this wave finishes: half 0 keeps its row 2*wq, half 1 its row 2*wq + 1; the other one goes to the partner
+    const int myrow = 2 * wq + half;
+    const int vob = ((myrow * a.Wo + r) * 32 + (g & 1) * 16 + (g >> 1) * 8) * 2;   // byte offset of the lane's 16-byte piece ([hi 16][lo 16] records)
+    const unsigned xch_wr = lds0 + XCH_OFF + ((2 * wq + (half ^ 1)) * 64 + lane) * 16;   // partial of the row the PARTNER finishes
+    const unsigned xch_rd = lds0 + XCH_OFF + (myrow * 64 + lane) * 16;                   // the partner's partial of my row
+
+    short8 w[NCH][2];
+    {
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + (size_t)half * NCH * 2 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            w[c][0] = wp[(c * 2 + 0) * 64];
+            w[c][1] = wp[(c * 2 + 1) * 64];
+        }
+    }
+    f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + g * 4);
+    if (half) bias4 = f32x4{0.f, 0.f, 0.f, 0.f};      // the BatchNorm shift enters once, through half 0's accumulators
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    int sidxb = 0, xpar = 0;              // ring slot of the window's first slice; exchange buffer of the step being contracted
+    f32x4 mine = {0.f, 0.f, 0.f, 0.f};   // this wave's own partial of the tile it finishes (pending step)
+    char *pptr = nullptr;
+
+    auto step = [&](auto LIVE_, auto PEND_, auto PEND2_, char *optr) {
+        constexpr bool LIVE = decltype(LIVE_)::value, PEND = decltype(PEND_)::value, PEND2 = decltype(PEND2_)::value;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        uint32_t h01 = 0, h23 = 0, l01 = 0, l23 = 0;
+        f32x4 theirs = {0.f, 0.f, 0.f, 0.f};
+        // the partner's partial of the pending step: requested first, so that the counted lgkmcnt waits of the contraction cover it (DS
+        // operations retire in order); a dead step waits for it directly
+        if constexpr (PEND) {
+            const unsigned ad = xch_rd + (xpar ^ 1) * XCHB;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(theirs) : "v"(ad));
+            if constexpr (!LIVE) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(theirs));
+        }
+        auto side = [&](auto S) {
+            constexpr int s = decltype(S)::value;
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+            if constexpr (PEND && s == 0) {
+                v0 = mine[0] + theirs[0];
+                v1 = mine[1] + theirs[1];
+                v2 = mine[2] + theirs[2];
+                v3 = mine[3] + theirs[3];
+                if constexpr (RELU) {
+                    v0 = relu_bits(v0);
+                    v1 = relu_bits(v1);
+                    v2 = relu_bits(v2);
+                    v3 = relu_bits(v3);
+                }
+            }
+            if constexpr (PEND && s == 1) {
+                h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v0, v1}, b2));
+                h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v2, v3}, b2));
+            }
+            if constexpr (PEND && s == 2) {
+                v0 -= __uint_as_float(h01 << 16);
+                v1 -= __uint_as_float(h01 & 0xFFFF0000u);
+                v2 -= __uint_as_float(h23 << 16);
+                v3 -= __uint_as_float(h23 & 0xFFFF0000u);
+            }
+            if constexpr (PEND && s == 3) {
+                l01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v0, v1}, b2));
+                l23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v2, v3}, b2));
+            }
+            if constexpr (PEND && s == 4) swap16(h01, l01);
+            if constexpr (PEND && s == 5) swap16(h23, l23);
+            if constexpr (PEND && s == 6) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<u32x4 *>(pptr + (uint32_t)vob) = u32x4{h01, h23, l01, l23};
+            }
+            if constexpr (s == 7) issue_piece(std::integral_constant<int, 0>{});
+            if constexpr (s == 8) issue_piece(std::integral_constant<int, 1>{});
+            if constexpr (s == 9) issue_piece(std::integral_constant<int, 2>{});
+        };
+        if constexpr (LIVE) {
+            int sb[3];
+            sb[0] = sidxb;
+            sb[1] = (sb[0] + SLOTB == RING * SLOTB) ? 0 : sb[0] + SLOTB;
+            sb[2] = (sb[1] + SLOTB == RING * SLOTB) ? 0 : sb[1] + SLOTB;
+            constexpr int DEPTH = 2, NB = DEPTH + 1;
+            short8 x[NB][2][2];   // [buffer][tile][part]
+            auto fetch = [](auto C, short8 (&xx)[NB][2][2], const unsigned (&ao)[5], const int (&sbb)[3]) {
+                constexpr int c = decltype(C)::value;
+                const unsigned ad = ao[c % 5] + sbb[c / 5];
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xx[c % NB][0][0]) : "v"(ad));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[c % NB][0][1]) : "v"(ad), "n"(PARTB));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[c % NB][1][0]) : "v"(ad), "n"(ROWB));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[c % NB][1][1]) : "v"(ad), "n"(ROWB + PARTB));
+            };
+            static_for<DEPTH>([&](auto C) { fetch(C, x, aoff, sb); });
+            f32x4 n[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                n[j][0] = bias4;
+                n[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                n[j][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            static_for<NCH>([&](auto C) {
+                constexpr int c = decltype(C)::value;
+                if constexpr (c + DEPTH < NCH) fetch(std::integral_constant<int, c + DEPTH>{}, x, aoff, sb);
+                constexpr int ahead = (NCH - 1 - c < DEPTH ? NCH - 1 - c : DEPTH) * 4;
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[c % NB][0][0]), "+v"(x[c % NB][0][1]), "+v"(x[c % NB][1][0]), "+v"(x[c % NB][1][1]) : "n"(ahead));
+                if constexpr (PEND && c == 0) asm volatile("" : "+v"(theirs));   // older than chunk 0's reads: landed
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    n[j][0] = mma<false>(w[c][0], x[c % NB][j][0], n[j][0]);
+                    n[j][1] = mma<false>(w[c][1], x[c % NB][j][0], n[j][1]);
+                    n[j][2] = mma<false>(w[c][0], x[c % NB][j][1], n[j][2]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c >= 1 && c <= 10) {
+                    side(std::integral_constant<int, c - 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            // hand the partner its row's partial, keep mine
+            f32x4 give;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s0 = n[0][0][i] + (n[0][1][i] + n[0][2][i]), s1 = n[1][0][i] + (n[1][1][i] + n[1][2][i]);
+                mine[i] = half ? s1 : s0;
+                give[i] = half ? s0 : s1;
+            }
+            const unsigned wad = xch_wr + xpar * XCHB;
+            asm volatile("ds_write_b128 %0, %1" ::"v"(wad), "v"(give) : "memory");
+        } else {
+            static_for<10>([&](auto S) { side(S); });
+        }
+        constexpr int INFLIGHT = PPW + (PEND ? 1 : 0);   // ring of 5: the slice queued in the PREVIOUS step is the next window's last one
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
+        (void)PEND2;
+        sidxb = (sidxb + SLOTB == RING * SLOTB) ? 0 : sidxb + SLOTB;
+        xpar ^= 1;
+        advance_fill();
+        pptr = optr;
+    };
+
+    int hist = 0;
+    auto dispatch = [&](bool live, char *optr) {
+        using T = std::true_type;
+        using F = std::false_type;
+        switch ((live ? 2 : 0) | (hist & 1)) {
+            case 0: step(F{}, F{}, F{}, optr); break;
+            case 1: step(F{}, T{}, F{}, optr); break;
+            case 2: step(T{}, F{}, F{}, optr); break;
+            default: step(T{}, T{}, F{}, optr); break;
+        }
+        hist = live ? 1 : 0;
+    };
+
+    const int64_t ostride = (int64_t)a.Ho * a.Wo * 64;   // bytes per output slice (16 channels, hi + lo)
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        char *optr = reinterpret_cast<char *>(a.out) + ((((int64_t)U.b * a.No + U.zbeg) * a.Ho + U.gy0) * a.Wo + U.gx0) * 64;
+        for (int st = 0; st < U.nz + 2; ++st) {
+            dispatch(st < U.nz, optr);
+            optr += ostride;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+bool rollx_k2_ok(int prec, const ConvArgs &a) {
+    if (prec != P_BF16X3 || (a.dbg & DFFW_ARGS_NO_ROLLX)) return false;
+    if (!a.out || a.out_pre || a.outf || a.res0 || a.res1 || a.res_bcast || a.cls_w || a.relu == 2 || a.Cout != 16) return false;
+    if (!((a.C0 == 32 && a.C1 == 0) || (a.C0 == 16 && a.C1 == 16))) return false;
+    const int64_t recb = a.C1 ? 64 : 128;
+    return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * recb < (1ll << 31);
+}
+
+hipError_t launch_conv_rollx_k2(const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    const int want = t.wgs > 0 ? t.wgs : 256;   // one 8-wave workgroup per CU
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(rollk2::NW * 64);
+    if (a.relu == 1) hipLaunchKernelGGL((conv_rollx_k2<true>), grid, block, 0, s, a, t);
+    else hipLaunchKernelGGL((conv_rollx_k2<false>), grid, block, 0, s, a, t);
+    return hipGetLastError();
+}
+
+void conv_rollx_k2_kernel_name(const ConvArgs &a, char *buf, int n) { snprintf(buf, n, "dffw::conv_rollx_k2<%s>", a.relu == 1 ? "true" : "false"); }
+
 bool rollx_pair_ok(int prec, const ConvArgs &a, bool pair) {
-    if (prec != P_BF16X3 || !pair || getenv("DFFW_NO_ROLLX")) return false;
+    if (prec != P_BF16X3 || !pair || (a.dbg & DFFW_ARGS_NO_ROLLX)) return false;
     if (!a.out || a.out_pre || a.outf || a.res0 || a.res1 || a.res_bcast || a.cls_w || a.relu == 2 || a.Cout != 8) return false;
     if (!((a.C0 == 16 && a.C1 == 0) || (a.C0 == 8 && a.C1 == 8))) return false;
     // 32-bit buffer offsets: a sample's input volume (+ one footprint) stays below 2^31 bytes

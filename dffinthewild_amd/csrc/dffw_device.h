@@ -105,12 +105,14 @@ __device__ __forceinline__ f32x4 mma(short8 a, short8 b, f32x4 c) {
 // Buffer: [workgroup][wave][step][8] u64.  Compiled out of production builds.
 #define DFFW_TRACE_STEPS 32
 #define DFFW_TRACE_SKIP 14
+#define DFFW_TRACE_MAX_WGS 1024
 struct StepTrace {
 #ifdef DFFW_TRACE_BUILD
     unsigned long long *p;
     int n;
     __device__ __forceinline__ StepTrace(unsigned long long *base, int wave, int lane, int nwaves) {
-        p = (base && lane == 0) ? base + ((int64_t)blockIdx.x * nwaves + wave) * (DFFW_TRACE_STEPS * 8) : nullptr;
+        // (the engine sizes the buffer for DFFW_TRACE_MAX_WGS workgroups: a test grid beyond that records nothing instead of writing past it)
+        p = (base && lane == 0 && blockIdx.x < DFFW_TRACE_MAX_WGS) ? base + ((int64_t)blockIdx.x * nwaves + wave) * (DFFW_TRACE_STEPS * 8) : nullptr;
         n = -DFFW_TRACE_SKIP;
     }
     __device__ __forceinline__ void no_skip() { n = 0; }   // short streams: record from the first step

@@ -17,7 +17,6 @@
 
 #include "../../include/dffw.h"
 #include "dffw_conv_roll.h"
-#include "dffw_conv_wino.h"
 #include "dffw_srd_roll.h"
 #include "dffw_conv_tile.h"
 #include "dffw_internal.h"
@@ -308,12 +307,12 @@ struct PackedConv {
                               // for head_tail_finish_kernel (conv + plane mean collapsed into plane sums)
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
+    uint16_t *wroll_k2 = nullptr;  // device: a 3x3x3 stride-1 32 -> 16 filter in conv_rollx_k2's order: [input half][conv_roll's 15 chunks]
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
     uint16_t *wroll_s2 = nullptr;  // device: a 3x3x3 stride-(1,2,2) 16 -> 16 / 32 filter in conv_roll_s2's order (15 chunks per 16-channel output tile)
     uint16_t *wroll_t32 = nullptr; // device: a transposed 3x3x3 32 -> 16 filter in conv_roll_t32's order (row phase 0: 9 chunks, then phase 1: 18)
     uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
-    uint16_t *wwino = nullptr;     // device: a 3x3x3 stride-1 32 -> 32k filter as conv_wino32's transformed fragments U = G g G^T (dffw_conv_wino.h)
     uint16_t *watt = nullptr;      // device: an 8 -> 8 attention conv (3x1x1 or 1x1x1) as srd_roll's stage-C fragments
     int cin_all = 0;       // input channels the packed layer contracts over: own (padded to 8) + folded shortcut's (padded to 8)
 };
@@ -345,14 +344,14 @@ static void free_packed(PackedConv &pc) {
     pc.wroll = nullptr;
     if (pc.wroll_t) (void)hipFree(pc.wroll_t);
     pc.wroll_t = nullptr;
+    if (pc.wroll_k2) (void)hipFree(pc.wroll_k2);
+    pc.wroll_k2 = nullptr;
     if (pc.wroll8) (void)hipFree(pc.wroll8);
     pc.wroll8 = nullptr;
     if (pc.wroll_t32) (void)hipFree(pc.wroll_t32);
     pc.wroll_t32 = nullptr;
     if (pc.wroll_s2) (void)hipFree(pc.wroll_s2);
     pc.wroll_s2 = nullptr;
-    if (pc.wwino) (void)hipFree(pc.wwino);
-    pc.wwino = nullptr;
     if (pc.wsrd) (void)hipFree(pc.wsrd);
     pc.wsrd = nullptr;
     if (pc.watt) (void)hipFree(pc.watt);
@@ -644,32 +643,30 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMalloc((void **)&pc.wroll, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    // ---- conv_wino32: the in-plane taps in Winograd F(2x2, 3x3) form for the 32-input-channel 3x3x3 stride-1 layers.  U[xi][nu] =
-    // sum_ky,kx G[xi][ky] G[nu][kx] w[dz][ky][kx] in float64 (BatchNorm scale folded), then the usual hi + lo split; fragment order
-    // [slab of 32 outputs][position xi*4+nu][dz][nt][part][lane][8] with row = output channel, K = the 32 input channels
-    if (geo == G3S1 && cin_pad == 32 && L.cin == 32 && L.cout % 32 == 0 && !stem && !shortcut_w && prec == P_BF16X3 && !getenv("DFFW_NO_WINO")) {
-        static const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {-.5, .5, -.5}, {0, 0, 1}};   // (row 2 negated, like the kernel's B^T row 2)
-        const int slabs = L.cout / 32;
-        std::vector<uint16_t> wr((size_t)slabs * WINO_U_SLAB, 0);
-        for (int sl = 0; sl < slabs; ++sl)
-            for (int pos = 0; pos < 16; ++pos)
-                for (int dz = 0; dz < 3; ++dz)
-                    for (int nt = 0; nt < 2; ++nt)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 8; ++j) {
-                                const int cout = sl * 32 + nt * 16 + (lane & 15), cin = (lane >> 4) * 8 + j;
-                                double acc = 0.0;
-                                for (int ky = 0; ky < 3; ++ky)
-                                    for (int kx = 0; kx < 3; ++kx)
-                                        acc += Gm[pos >> 2][ky] * Gm[pos & 3][kx] * wval(cout, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
-                                uint16_t hi, lo;
-                                host_split(prec, (float)acc, hi, lo);
-                                const size_t base = (((((size_t)sl * 16 + pos) * 3 + dz) * 2 + nt) * 2) * 512 + (size_t)lane * 8 + j;
-                                wr[base] = hi;
-                                wr[base + 512] = lo;
-                            }
-        HIPCHK(hipMalloc((void **)&pc.wwino, wr.size() * sizeof(uint16_t)));
-        HIPCHK(hipMemcpy(pc.wwino, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // ---- conv_rollx_k2 (dffw_conv_rollx.hip): 3x3x3 stride 1, 32 -> 16 channels (`dres3.conv0`): conv_roll's plain chunk order per 16-channel
+    // input half: [half][dz][k5], K octet g = (tap 2*k5 + (g >> 1), channel half*16 + (g & 1)*8 ..)
+    if (geo == G3S1 && cin_pad == 32 && L.cin == 32 && L.cout == 16 && !stem && !shortcut_w && prec == P_BF16X3) {
+        std::vector<uint16_t> wr((size_t)2 * ROLL_CHUNKS * parts * 512, 0);
+        for (int half = 0; half < 2; ++half)
+            for (int c = 0; c < ROLL_CHUNKS; ++c)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = lane & 15, gq = lane >> 4;
+                        const int cin = half * 16 + (gq & 1) * 8 + j;
+                        const int dz = c / 5, k5 = c % 5, tap9 = 2 * k5 + (gq >> 1);
+                        float val = 0.f;
+                        if (row < L.cout && tap9 < 9) {
+                            const int ky = tap9 / 3, kx = tap9 % 3;
+                            val = (float)wval(row, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
+                        }
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)half * ROLL_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wroll_k2, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wroll_k2, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- srd_roll stage C: the attention convs of the 8-channel SRD block (DEN.py:322-323) in pixel-pair form.  Result row
     // m = (pixel m >> 3 of the pair, channel m & 7).  3x1x1: chunk 0 K octet g = (pixel g >> 1, slice g & 1), chunk 1 even g =
@@ -1138,7 +1135,8 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST)
+    X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1147,10 +1145,12 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, wino_min_units = 0, warm_max_wgs = 1024;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, warm_max_wgs = 1024;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
+    // the switches the kernel launchers consult, as ConvArgs::dbg bits (so that no launcher calls getenv)
+    int path_bits() const;
     static Switches read() {
         Switches s;
         int i = 0;
@@ -1171,11 +1171,6 @@ struct Switches {
         // (TileArgs::warm; 0: never).  Measured r03 on 10x256x256 stacks, ms per forward at 0 / 256 / 1024 / always: batch 2 1.29 / 1.17 / 1.17 /
         // 1.17, batch 8 2.74 / 2.65 / 2.63 / 2.63, batch 16 4.71 / 4.66 / 4.62 / 4.66, batch 32 8.58 / 8.57 / 8.57 / 8.70
         s.warm_max_wgs = geti("DFFW_WARM_MAX_WGS", 0, 1024);
-        // conv_wino32 (Winograd F(2x2, 3x3) for the 32-input-channel 3x3x3 stride-1 layers) is opt-in: DFFW_WINO_MIN_UNITS = columns a layer needs
-        // to take it (0 / unset: never).  Measured r03 at batch 32 (512 / 2048 columns): 9-13 % under conv_tile per layer in the serial
-        // profile, level on the whole forward (five alternating runs: 8.797 vs 8.792 ms; its one 134 KB workgroup per CU does not share the
-        // CU with the concurrent SPP branches the way conv_tile's do), so the default keeps the direct kernels and their bit-exact history
-        s.wino_min_units = geti("DFFW_WINO_MIN_UNITS", 0, 0);
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
@@ -1186,6 +1181,10 @@ struct Switches {
         return s;
     }
 };
+
+inline int Switches::path_bits() const {
+    return (f[SW_NO_LEAN_TILE] ? DFFW_ARGS_NO_LEAN_TILE : 0) | (f[SW_NO_LEAN_ROLL] ? DFFW_ARGS_NO_LEAN_ROLL : 0) | (f[SW_NO_ROLLX] ? DFFW_ARGS_NO_ROLLX : 0);
+}
 
 struct ConvOpt {
     const Act *in1 = nullptr;
@@ -1428,7 +1427,7 @@ struct Run {
         a.relu = o.relu;
         if (!dry && e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
-        a.dbg = sw.debug_flags & 7;   // ablation switches only (1 no fill, 2 no MFMA loop, 4 no stores); bit 5 below is DFFW_NO_SMALL's own
+        a.dbg = (sw.debug_flags & 7) | sw.path_bits();   // ablation switches (1 no fill, 2 no MFMA loop, 4 no stores) + the launchers' path switches
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
         if (o.sums) {
             if (!sums_conv_ok(name, in0.B, in0.N, in0.H, in0.W) || o.relu != 1 || o.res0 || o.res1 || o.cls || o.out_pre || o.in1) {
@@ -1437,31 +1436,6 @@ struct Run {
             }
             a.outf = o.sums;
             a.dbg |= DFFW_ARGS_SUMS;
-        }
-        // 3x3x3 stride 1 over 32 input channels (SPP dres8_*, dres0.0, dres3.conv2 / conv4, confidence.0): Winograd F(2x2, 3x3) in-plane
-        if (pc.wwino && in0.C == 32 && !o.in1 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre && !o.cls && !o.discard && !o.sums && o.relu != 2 &&
-            Ho % WINO_TY == 0 && Wo % WINO_TX == 0 && (int64_t)in0.B * (Ho / WINO_TY) * (Wo / WINO_TX) * (L.cout / 32) >= sw.wino_min_units &&
-            sw.wino_min_units > 0) {
-            if (dry) return out;
-            WinoArgs t;
-            memset(&t, 0, sizeof t);
-            t.u = pc.wwino;
-            t.tiles_y = Ho / WINO_TY;
-            t.tiles_x = Wo / WINO_TX;
-            a.dbg = 0;
-            char kn[96];
-            conv_wino32_kernel_name(e->prec, a, kn, sizeof kn);
-            g_last_kernel = kn;
-            if (e->profiling) {
-                const double opx = (double)out.B * No * Ho * Wo;
-                const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout * elem_bytes() * (1 + (o.res0 ? 1 : 0));
-                prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout, bytes);
-            }
-            a.trace = trace_begin(name, 512, 8);
-            check(launch_conv_wino32(e->prec, a, t, s), name.c_str());
-            prof_end();
-            trace_end();
-            return out;
         }
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
@@ -1612,6 +1586,39 @@ struct Run {
         if (stem_pair) a.bias = pc.bias_pair;
         const TilePack &tp = stem_pair ? pc.tile_pair : pc.tile;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
+        // 32 -> 16 channels on whole 8 x 16 columns: the pipelined rolling window with the contraction split over the two input halves
+        {
+            const int cols = (Ho / 8) * (Wo / 16);
+            const bool halves = o.in1 ? (in0.C == 16 && o.in1->C == 16) : in0.C == 32;
+            if (pc.wroll_k2 && halves && Ho % 8 == 0 && Wo % 16 == 0 && (int64_t)in0.B * cols >= sw.roll_min_units && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLLX)) {
+                ConvArgs ak = a;
+                ak.Ng = No; ak.Hg = Ho; ak.Wg = Wo;
+                ak.M = (int64_t)ak.B * No * Ho * Wo;
+                if (rollx_k2_ok(e->prec, ak)) {
+                    if (dry) return out;
+                    RollArgs t;
+                    memset(&t, 0, sizeof t);
+                    t.wroll = pc.wroll_k2;
+                    t.tiles_y = Ho / 8;
+                    t.tiles_x = Wo / 16;
+                    t.zsplit = ((int64_t)in0.B * cols < 512 && No >= 8) ? 2 : 1;
+                    if (sw.roll_zsplit >= 1 && sw.roll_zsplit <= No) t.zsplit = sw.roll_zsplit;
+                    t.total_tiles = in0.B * t.zsplit * cols;
+                    t.wgs = sw.roll_wgs;
+                    char kn[96];
+                    conv_rollx_k2_kernel_name(ak, kn, sizeof kn);
+                    g_last_kernel = kn;
+                    if (e->profiling) {
+                        const double opx = (double)out.B * No * Ho * Wo;
+                        const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout * elem_bytes() + 27.0 * L.cin * L.cout * elem_bytes();
+                        prof_begin(kn, name, 2.0 * opx * 27.0 * L.cin * L.cout, bytes);
+                    }
+                    check(launch_conv_rollx_k2(ak, t, s), name.c_str());
+                    prof_end();
+                    return out;
+                }
+            }
+        }
         // rolling-window kernel: 16-channel 3x3x3 stride-1 layers whose grid is whole columns and fills the chip
         {
             int rty, rtx;
@@ -1983,7 +1990,7 @@ static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr
                 a.relu = 1;
                 a.zero = r.e->zero_page;
                 a.M = (int64_t)x.B * x.N * Ho * Wo;
-                a.dbg = r.sw.debug_flags & 6;
+                a.dbg = (r.sw.debug_flags & 6) | r.sw.path_bits();
                 RollArgs t;
                 memset(&t, 0, sizeof t);
                 t.wroll = ca->second.wroll8;
@@ -2215,7 +2222,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     // (on side stream 0 next to dres0 / deconv_1 below 16M stack pixels: two 1/8-resolution convs and a regression head that
     // nothing else waits for -- measured +2.7 % at batch 1, +2.3 % at batch 8, -0.3 % at batch 32 where dres0 fills the chip)
     RegressQueue rq;
-    const bool merge_heads = !getenv("DFFW_NO_REGRESS_MERGE");
+    const bool merge_heads = !r.sw.on(SW_NO_REGRESS_MERGE);
     const int h8 = H / 8, w8 = W / 8;
     float *conf = (float *)r.raw((int64_t)B * N * h8 * w8 * sizeof(float));
     const bool conf_side = r.concurrent && (int64_t)B * N * H * W < (16 << 20) && !r.sw.on(SW_NO_CONF_FORK);

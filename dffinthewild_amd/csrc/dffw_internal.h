@@ -43,6 +43,11 @@ struct RawStack {
 #define DFFW_RAW_NORM_F64_BIT 16   // == DFFW_RAW_NORM_F64 of include/dffw.h (device code does not include that header)
 #define DFFW_ARGS_RAW 8
 #define DFFW_ARGS_SUMS 128
+// kernel-path switches of the forward's snapshot (Switches, dffw_engine.cpp) that the launchers consult: carried in ConvArgs::dbg so that the
+// kernel name reported and the instantiation launched cannot disagree (no getenv at launch time)
+#define DFFW_ARGS_NO_LEAN_TILE 16   // DFFW_NO_LEAN_TILE: conv_tile's generic epilogue instead of its LEAN instantiations
+#define DFFW_ARGS_NO_LEAN_ROLL 64   // DFFW_NO_LEAN_ROLL: the same for the rolling-window kernels
+#define DFFW_ARGS_NO_ROLLX 256   // DFFW_NO_ROLLX: conv_roll's serial step instead of conv_rollx's pipelined one
 // (ConvArgs must not grow: the register allocation of the lean transposed-conv kernels is sensitive to its size, a
 // 56-byte larger argument block cost them 38 %)
 struct ConvArgs {

@@ -52,6 +52,10 @@ CONV_CASES = [
     ("c3_one_slice", 8, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 1, 8, 8),
     ("score_c3_32_1", 32, 1, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 3, 8, 8),
     ("score_1x1x1_8_1", 8, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), 3, 16, 16),
+    # output channel counts that do not fill the kernel's power-of-two tile count (48 -> 4 tiles, 96 -> 8): the padding tiles must not store
+    # (the straight-line epilogue has no per-tile channel guard, so these launches must stay on the generic one)
+    ("c3_32_48", 32, 48, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 3, 8, 24),
+    ("c3_32_96", 32, 96, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 2, 8, 16),
 ]
 
 
@@ -194,31 +198,29 @@ def test_conv_roll_rolling_window(eng, cout, N, H, W, zsplit, residual, wgs, pre
     assert rel(alt, ref) <= TOL[prec]
 
 
-@pytest.mark.parametrize("cout,B,N,H,W,residual,relu", [(32, 2, 10, 32, 32, False, 1), (32, 1, 5, 64, 64, True, 1), (64, 2, 3, 16, 32, False, 1),
-                                                         (32, 3, 1, 8, 16, True, 0), (32, 1, 2, 4, 16, False, 0), (64, 1, 7, 28, 48, True, 1)])
-def test_conv_wino32(eng, cout, B, N, H, W, residual, relu, monkeypatch):
-    """conv_wino32 (dffw_conv_wino.hip): the 32-input-channel 3x3x3 stride-1 layers (SPP dres8_*, dres0.0, dres3.conv2 / conv4, confidence.0;
-    DEN.py:96-120, submodule.py:117-160) with the in-plane taps in Winograd F(2x2, 3x3) form.  One workgroup per 4 x 16 column and 32-channel
-    output slab: single slices, one-column grids (every border at once), 64 outputs (two slabs), residual with and without ReLU.  Same
-    tolerance as the direct kernels (5e-5 against fp32 F.conv3d), and within 2e-5 of conv_tile on the same input."""
-    cin = 32
-    x = rnd(B, cin, N, H, W, seed=31)
-    w = rnd(cout, cin, 3, 3, 3, seed=32, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
-    bn = bn_params(cout, 33)
-    res = rnd(B, cout, N, H, W, seed=34) if residual else None
+@pytest.mark.parametrize("N,H,W,zsplit,wgs,relu", [(10, 128, 128, 1, 0, 1), (1, 64, 256, 1, 8, 1), (7, 64, 256, 3, 24, 0), (2, 128, 128, 2, 16, 1), (3, 128, 128, 3, 8, 1),
+                                                    (5, 256, 64, 1, 0, 1)])
+def test_conv_rollx_k2(eng, N, H, W, zsplit, wgs, relu, monkeypatch):
+    """conv_rollx_k2 (dffw_conv_rollx.hip): 3x3x3 stride 1, 32 -> 16 channels (`dres3.conv0`, DEN.py:240-284) as a software-pipelined rolling
+    window with the contraction split over the two 16-channel input halves (8 waves, partial tiles exchanged through LDS): every slice count
+    incl. 1 and 2, split slice ranges, one column per workgroup and long streams, with and without ReLU; against F.conv3d and against
+    conv_tile on the same input (DFFW_NO_ROLLX)."""
+    B, cin, cout = 2, 32, 16
+    x = rnd(B, cin, N, H, W, seed=41)
+    w = rnd(cout, cin, 3, 3, 3, seed=42, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 43)
     ref = ref_bn(F.conv3d(x, w, None, 1, 1), bn)
-    if residual:
-        ref = ref + res
     if relu:
         ref = F.relu(ref)
-    kw = dict(pad=1, bn=bn, residual=res.cuda() if residual else None, relu=relu, precision="bf16x3")
-    monkeypatch.setenv("DFFW_WINO_MIN_UNITS", "1")
-    got = eng.op_conv3d(x.cuda(), w, **kw)
-    assert eng.last_conv_kernel().startswith("dffw::conv_wino32<"), eng.last_conv_kernel()
+    monkeypatch.setenv("DFFW_ROLL_ZSPLIT", str(zsplit))
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    got = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, relu=relu, precision="bf16x3")
+    assert eng.last_conv_kernel().startswith("dffw::conv_rollx_k2<"), eng.last_conv_kernel()
     assert rel(got, ref) <= TOL["bf16x3"], rel(got, ref)
-    monkeypatch.setenv("DFFW_WINO_MIN_UNITS", "0")
-    alt = eng.op_conv3d(x.cuda(), w, **kw)
-    assert not eng.last_conv_kernel().startswith("dffw::conv_wino32<"), eng.last_conv_kernel()
+    monkeypatch.setenv("DFFW_NO_ROLLX", "1")
+    alt = eng.op_conv3d(x.cuda(), w, pad=1, bn=bn, relu=relu, precision="bf16x3")
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
     assert rel(got, alt) <= 2e-5, rel(got, alt)
 
 
