@@ -24,6 +24,7 @@
 // operands, exactly as in the three-launch form.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "dffw_device.h"
@@ -790,13 +791,17 @@ hipError_t launch_of_first(int prec, const SrdArgs &a, hipStream_t s) {
 // 4 x 16 pixels (LDS: 4 x-slices of 8 x 20 pixels + t + the feat ring = 67 KB, two workgroups per CU).  Stage B / C tiles
 // are 2 rows x 8 pixels per wave so that the 2x2 max-pool stays inside a wave.  Streaming skeleton, counted waits, inline-asm
 // LDS access and the MFMA attention (its split result = the 1x1x1 conv's operand in place) as in srd_roll_kernel.
-template <int PREC, bool POOL>
+// ABL (development only, DFFW_SRD_ABL): timing ablations -- 1 no stage C, 2 no stage A, 4 no stage B, 8 no fill, 16 no barriers, 32 no global stores
+template <int PREC, bool POOL, int ABL = 0>
 __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
     constexpr int C = 16, TY = 4, TX = 16, NWAVES = 4;
     constexpr int XY = TY + 4, XX = TX + 4, XPIX = XY * XX;
     constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;
+    // t rows at a pitch of 24 pixels = 768 bytes: a stage-B tile is 2 rows x 8 pixels, and the 16 lanes of a ds_read_b128 row group only cover 16 distinct
+    // 16-byte bank groups when its two rows are a multiple of 256 bytes apart (18-pixel rows, 576 bytes: two-way conflicts on every stage-B read)
+    constexpr int TXTP = 24;
     constexpr int PIXB = C * 2;
     constexpr int NPIECE = 6;                                      // 1 KiB wave instructions per plane (5 hold the 160 pixels; 6 keeps 3 per wave)
     static_assert(NPIECE * 32 >= XPIX, "plane holds the footprint");
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
     constexpr int RX = 4;
     constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
     static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (counted vmcnt waits)");
-    constexpr int TPLANEB = TPIX * PIXB;
+    constexpr int TPLANEB = TYT * TXTP * PIXB;
     constexpr int FPLANEB = TY * TX * PIXB;
     constexpr int FSLOTB = PARTS * FPLANEB;
     constexpr int X_OFF = 0, T_OFF = RX * SLOTB, F_OFF = T_OFF + PARTS * TPLANEB;
@@ -885,7 +890,9 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
         }
     };
 
-    // stage A: the 6 x 18 t pixels are 7 operand tiles (the last one partly idle): waves 0-2 take two, wave 3 one
+    // stage A: the 6 x 18 t pixels are 7 operand tiles: tiles 0-5 = the first 16 pixels of row 0-5 (16 consecutive pixels of ONE row: conflict-free
+    // operand reads; tiles of 16 consecutive indices of the 6 x 18 region wrapped rows and collided two ways), tile 6 = the two remaining pixels of
+    // each row (12 of its 16 lanes busy); waves 0-2 take two tiles, wave 3 one
     constexpr int TA = 2;
     const int nA = wave < 3 ? 2 : 1;
     int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
@@ -893,13 +900,11 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
 #pragma unroll
     for (int j = 0; j < TA; ++j) {
         const int tile = j == 0 ? wave : 4 + wave;
-        int p = tile * 16 + r;
-        ta_ok[j] = p < TPIX;
-        if (p >= TPIX) p = TPIX - 1;
-        ta_y[j] = p / TXT;
-        ta_x[j] = p - ta_y[j] * TXT;
+        ta_ok[j] = tile < TYT || r < 2 * TYT;
+        ta_y[j] = tile < TYT ? tile : (r < 2 * TYT ? r >> 1 : TYT - 1);
+        ta_x[j] = tile < TYT ? r : TX + (r & 1);
         pa[j] = (ta_y[j] * XX + ta_x[j]) * PIXB + (g & 1) * 16;
-        ta_st[j] = T_OFF + p * PIXB + g * 8;
+        ta_st[j] = T_OFF + (ta_y[j] * TXTP + ta_x[j]) * PIXB + g * 8;
     }
     // K octet g of chunk k = (filter tap 2k + (g >> 1), channel octet g & 1); tap 9 carries zero weights
     int tapA[NCH], tapB[NCH];
@@ -908,11 +913,11 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
         const int tap = 2 * k + (g >> 1);
         const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
         tapA[k] = (dy * XX + dx) * PIXB;
-        tapB[k] = (dy * TXT + dx) * PIXB;
+        tapB[k] = (dy * TXTP + dx) * PIXB;
     }
     // stage B / C: wave w = rows 2*(w >> 1), +1 x columns 8*(w & 1) .. +7 (the 2x2 pooling blocks stay inside the wave)
     const int pb_y = 2 * (wave >> 1) + (r >> 3), pb_x = 8 * (wave & 1) + (r & 7);
-    const int pbo = (pb_y * TXT + pb_x) * PIXB + (g & 1) * 16;
+    const int pbo = (pb_y * TXTP + pb_x) * PIXB + (g & 1) * 16;
     const int pb_res = ((pb_y + 2) * XX + pb_x + 2) * PIXB + g * 8;
     const int pb_f = (pb_y * TX + pb_x) * PIXB;
     short8 w0[NCH][PARTS], w2[NCH][PARTS], w3f[2][PARTS], w1f[PARTS];
@@ -973,11 +978,11 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
             const bool produce = s < a.N;
             const unsigned fslot_off = F_OFF + (s % 3) * FSLOTB;
             if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (s == 0 && tid * 16 < FSLOTB) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
 
             // ---- stage C: attention for slice z = s-2 ----------------------------------------------------------------------
-            if (s >= 2) {
+            if (s >= 2 && !(ABL & 1)) {
                 const int z = s - 2;
                 const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
                 // chunk 0: K octet g = (slice z-1 + (g >> 1), channel octet g & 1); chunk 1: (slice z+1, octet g & 1) for g < 2
@@ -1033,7 +1038,7 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
                         swap16(ph01, pl01);
                         swap16(ph23, pl23);
                     }
-                    if ((r & 9) == 0) {
+                    if ((r & 9) == 0 && !(ABL & 32)) {
                         const int64_t pp = (((int64_t)U.b * a.N + z) * (a.H / 2) + (U.gy0 / 2 + (wave >> 1))) * (a.W / 2) + U.gx0 / 2 + 4 * (wave & 1) + ((r & 7) >> 1);
                         if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(a.pooled + pp * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(ph01, ph23, pl01, pl23);
                         else *reinterpret_cast<uint2 *>(a.pooled + pp * rec + g * 4) = make_uint2(ph01, ph23);
@@ -1042,13 +1047,13 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
                 if constexpr (PARTS == 2) {
                     swap16(h01, l01);
                     swap16(h23, l23);
-                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+                    if ((ABL & 32) == 0 || h01 == 0x12345u) *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
                 } else {
                     *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
                 }
             }
             // ---- stage A ---------------------------------------------------------------------------------------------------------
-            if (produce) {
+            if (produce && !(ABL & 2)) {
 #pragma unroll
                 for (int j = 0; j < TA; ++j) {
                     if (j >= nA) break;
@@ -1064,10 +1069,10 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (produce) {
                 // ---- stage B ---------------------------------------------------------------------------------------------------------
-                {
+                if constexpr (!(ABL & 4)) {
                     const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, tapB, TPLANEB, w2, b2);
                     const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
                     u32x2 xh, xl = {0u, 0u};
@@ -1090,8 +1095,8 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
                     vq1 = vq0;
                     vq0 = v;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                issue_next();
+                if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if constexpr (!(ABL & 8)) issue_next();
                 xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
             } else {
                 vq1 = vq0;
@@ -1972,9 +1977,25 @@ hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s) {
     const int want = a.wgs > 0 ? a.wgs : 512;   // two resident workgroups per CU
     const int per_xcd = (a.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    const char *az = getenv("DFFW_SRD_ABL");   // development: timing ablations (wrong results with any bit set)
+    const int abl = az ? atoi(az) : 0;
 #define DFFW_SRD16_LAUNCH(P)                                                                \
     do {                                                                                    \
-        if (a.pooled) hipLaunchKernelGGL((srd_roll16_kernel<P, true>), grid, block, 0, s, a);  \
+        if (a.pooled && P == P_BF16X3 && abl) {                                             \
+            switch (abl) {                                                                  \
+                case 1: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 1>), grid, block, 0, s, a); break;   \
+                case 2: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 2>), grid, block, 0, s, a); break;   \
+                case 4: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 4>), grid, block, 0, s, a); break;   \
+                case 7: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 7>), grid, block, 0, s, a); break;   \
+                case 8: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 8>), grid, block, 0, s, a); break;   \
+                case 16: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 16>), grid, block, 0, s, a); break; \
+                case 32: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 32>), grid, block, 0, s, a); break; \
+                case 40: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 40>), grid, block, 0, s, a); break; \
+                case 23: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 23>), grid, block, 0, s, a); break; \
+                case 6: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 6>), grid, block, 0, s, a); break;   \
+                default: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true>), grid, block, 0, s, a);            \
+            }                                                                               \
+        } else if (a.pooled) hipLaunchKernelGGL((srd_roll16_kernel<P, true>), grid, block, 0, s, a);  \
         else hipLaunchKernelGGL((srd_roll16_kernel<P, false>), grid, block, 0, s, a);          \
     } while (0)
     switch (prec) {
