@@ -793,7 +793,7 @@ hipError_t launch_of_first(int prec, const SrdArgs &a, hipStream_t s) {
 // LDS access and the MFMA attention (its split result = the 1x1x1 conv's operand in place) as in srd_roll_kernel.
 // ABL (development only, DFFW_SRD_ABL): timing ablations -- 1 no stage C, 2 no stage A, 4 no stage B, 8 no fill, 16 no barriers, 32 no global stores
 template <int PREC, bool POOL, int ABL = 0>
-__global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void srd_roll16_kernel(const SrdArgs a) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
     constexpr bool F16 = (PREC == P_FP16);
     constexpr int C = 16, TY = 4, TX = 16, NWAVES = 4;
@@ -964,6 +964,47 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
         return acc;
     };
 
+    // two operand tiles side by side (stage A of the waves that own two): the reads of both run three chunks ahead of the MFMAs and the two
+    // accumulator chains alternate, so one tile's LDS latency and MFMA dependency gaps are covered by the other's work
+    auto tile_mma2 = [&](unsigned base0, unsigned base1, const int (&tapo)[NCH], int loB, const short8 (&wf)[NCH][PARTS], f32x4 &acc0, f32x4 &acc1) {
+        static_assert(PARTS == 2 || PARTS == 1, "");
+        constexpr int NBUF = 3;
+        short8 xh[NBUF][2], xl[NBUF][2];
+        auto fetch = [&](int k) {
+            const unsigned a0 = base0 + tapo[k], a1 = base1 + tapo[k];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k % NBUF][0]) : "v"(a0));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k % NBUF][0]) : "v"(a0 + loB));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k % NBUF][1]) : "v"(a1));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k % NBUF][1]) : "v"(a1 + loB));
+        };
+        fetch(0);
+        fetch(1);
+        fetch(2);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int left = (NCH - 1 - k < 2 ? NCH - 1 - k : 2) * 2 * PARTS;   // reads of later chunks that may still be in flight
+            auto &h0 = xh[k % NBUF][0], &h1 = xh[k % NBUF][1], &l0 = xl[k % NBUF][0], &l1 = xl[k % NBUF][1];
+            if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            if constexpr (PARTS == 1) {
+                l0 = h0;
+                l1 = h1;
+            }
+            if constexpr (PARTS == 2) {
+                acc0 = mma<F16>(wf[k][1], h0, acc0);
+                acc1 = mma<F16>(wf[k][1], h1, acc1);
+                acc0 = mma<F16>(wf[k][0], l0, acc0);
+                acc1 = mma<F16>(wf[k][0], l1, acc1);
+            }
+            acc0 = mma<F16>(wf[k][0], h0, acc0);
+            acc1 = mma<F16>(wf[k][0], h1, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 3 < NCH) fetch(k + 3);
+        }
+    };
+
     constexpr int INFLIGHT = (RX - 2) * PPW;
 #pragma unroll
     for (int q = 0; q < RX - 1; ++q) issue_next();
@@ -1054,10 +1095,19 @@ __global__ __launch_bounds__(256) void srd_roll16_kernel(const SrdArgs a) {
             }
             // ---- stage A ---------------------------------------------------------------------------------------------------------
             if (produce && !(ABL & 2)) {
+                f32x4 accA[TA];
+                if (nA == 2) {
+                    accA[0] = b0;
+                    accA[1] = b0;
+                    tile_mma2(lds0 + X_OFF + xslot * SLOTB + pa[0], lds0 + X_OFF + xslot * SLOTB + pa[1], tapA, PLANEB, w0, accA[0], accA[1]);
+                } else {
+                    accA[0] = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[0], tapA, PLANEB, w0, b0);
+                    accA[1] = b0;
+                }
 #pragma unroll
                 for (int j = 0; j < TA; ++j) {
                     if (j >= nA) break;
-                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], tapA, PLANEB, w0, b0);
+                    const f32x4 acc = accA[j];
                     const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
                     const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     if (ta_ok[j]) {
