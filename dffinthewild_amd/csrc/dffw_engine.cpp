@@ -1136,7 +1136,7 @@ static bool getenv_flag(const char *name) {
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
     X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE)
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -2138,7 +2138,11 @@ static void regress(Run &r, RegressQueue &q, const char *tag, float *score, int 
 }
 static void flush_regress(Run &r, RegressQueue &q, int B, int N, int H, int W, const float *fd, const int64_t fst[4]) {
     if (q.hd.n && r.ok() && !r.dry) {
-        r.prof_begin("dffw::regress_kernel", "regress.mid_out+pred1+pred2+pred3", 0.0, q.bytes);
+        q.hd.nofuse = r.sw.on(SW_NO_REGRESS_FUSED) ? 1 : 0;
+        const bool fused = q.hd.n > 1 && N <= 16 && (int64_t)B * H * W < (1ll << 31) && !q.hd.nofuse;   // launch_regress_heads' own test
+        // algorithmic bytes: the score volumes and depth maps + a dense focus-distance map once (the fused kernel does read it once; per-head launches re-read it)
+        const double bytes = q.bytes + ((fst[2] || fst[3]) ? (double)B * N * H * W * 4.0 : 0.0);
+        r.prof_begin(fused ? "dffw::regress_fused_kernel" : "dffw::regress_kernel", "regress.mid_out+pred1+pred2+pred3", 0.0, bytes);
         r.check(launch_regress_heads(q.hd, B, N, H, W, fd, fst[0], fst[1], fst[2], fst[3], r.s), "regress");
         r.prof_end();
     }

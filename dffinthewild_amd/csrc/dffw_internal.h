@@ -124,6 +124,7 @@ struct RegressHeads {
     float *depth[4];
     int h[4], w[4];
     int n;
+    int nofuse;   // DFFW_NO_REGRESS_FUSED (the forward's switch snapshot): one workgroup row per head (regress_kernel) instead of regress_fused_kernel
 };
 hipError_t launch_regress_heads(const RegressHeads &hd, int B, int N, int H, int W, const float *fd, int64_t fsb, int64_t fsn, int64_t fsh,
                                 int64_t fsw, hipStream_t s);

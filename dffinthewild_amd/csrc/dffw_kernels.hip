@@ -9,6 +9,7 @@
 //  stack_in      focal stack (B,3,N,H,W) fp32 planar -> channels-last 8-channel volume.
 //  regress       bilinear resize + softplus normalisation + focus-distance expectation.
 #include <cstdio>
+#include <cstdlib>
 
 #include "dffw_device.h"
 #include "dffw_internal.h"
@@ -1187,10 +1188,95 @@ __global__ __launch_bounds__(256) void regress_kernel(const RegressHeads hd, int
     }
 }
 
+// regress_fused_kernel: all heads of a pixel in one thread (N <= 16 slices).  As blockIdx.y = head every head re-read the pixel's N focus distances
+// (a dense (B,N,H,W) map: 84 MB per head at batch 32) and the full-resolution head (pred3, h == H) fetched its one score value per slice
+// four times through the bilinear taps.  Here the focus distances are loaded once into registers, the heads run one after the other over them,
+// and a head at output resolution takes the single-load path (hy = hx = 1, ly = lx = 0: the value is the same, bit for bit).  Per head the
+// arithmetic and its order are regress_kernel's.
+template <int NMAX>
+__global__ __launch_bounds__(256) void regress_fused_kernel(const RegressHeads hd, int B, int N, int H, int W, const float *__restrict__ fd, int64_t fsb,
+                                                            int64_t fsn, int64_t fsh, int64_t fsw) {
+    const unsigned total = (unsigned)B * H * W;
+    for (unsigned u = blockIdx.x * blockDim.x + threadIdx.x; u < total; u += gridDim.x * blockDim.x) {
+        const unsigned t = u / (unsigned)W;
+        const int X = (int)(u - t * (unsigned)W);
+        const unsigned bb = t / (unsigned)H;
+        const int Y = (int)(t - bb * (unsigned)H);
+        const float *fp = fd + bb * fsb + Y * fsh + X * fsw;
+        float f[NMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) f[n] = fp[(n < N ? n : N - 1) * fsn];
+        for (int head = 0; head < hd.n; ++head) {
+            const float *__restrict__ score = hd.score[head];
+            const int h = hd.h[head], w = hd.w[head];
+            const float *sp = score + (int64_t)bb * N * h * w;
+            float num = 0.f, den = 0.f;
+            if (h == H && w == W) {
+                const int o = Y * w + X;
+                float sv[NMAX];
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) sv[n] = sp[(int64_t)(n < N ? n : N - 1) * h * w + o];
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) {
+                    if (n < N) {
+                        // (1*(1*s + 0*s) + 0*(1*s + 0*s) of the general path is s itself, so is hy*(hx*s00 + lx*s01) + ly*(...) in fp32 for finite s)
+                        const float p = softplus_fast(sv[n]) + 1e-6f;
+                        den += p;
+                        num += f[n] * p;
+                    }
+                }
+            } else {
+                const float sch = (float)h / (float)H, scw = (float)w / (float)W;
+                float sy = ((float)Y + 0.5f) * sch - 0.5f;
+                float sx = ((float)X + 0.5f) * scw - 0.5f;
+                sy = sy < 0.f ? 0.f : sy;
+                sx = sx < 0.f ? 0.f : sx;
+                const int y0 = (int)sy, x0 = (int)sx;
+                const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float ly = sy - (float)y0, lx = sx - (float)x0;
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const int o00 = y0 * w + x0, o01 = y0 * w + x1, o10 = y1 * w + x0, o11 = y1 * w + x1;
+                for (int n0 = 0; n0 < N; n0 += 5) {
+                    float s00[5], s01[5], s10[5], s11[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const int n = n0 + k < N ? n0 + k : N - 1;
+                        const float *pl = sp + (int64_t)n * h * w;
+                        s00[k] = pl[o00];
+                        s01[k] = pl[o01];
+                        s10[k] = pl[o10];
+                        s11[k] = pl[o11];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        if (n0 + k < N) {
+                            const float v = hy * (hx * s00[k] + lx * s01[k]) + ly * (hx * s10[k] + lx * s11[k]);
+                            const float p = softplus_fast(v) + 1e-6f;
+                            den += p;
+                            float fk = f[0];   // f[n0 + k] with a compile-time register index after unrolling over n0's possible values
+#pragma unroll
+                            for (int q = 1; q < NMAX; ++q) fk = (n0 + k == q) ? f[q] : fk;
+                            num += fk * p;
+                        }
+                    }
+                }
+            }
+            hd.depth[head][u] = num / den;
+        }
+    }
+}
+
 hipError_t launch_regress_heads(const RegressHeads &hd, int B, int N, int H, int W, const float *fd, int64_t fsb, int64_t fsn, int64_t fsh,
                                 int64_t fsw, hipStream_t s) {
     if (hd.n < 1 || hd.n > 4) return hipErrorInvalidValue;
     const int64_t total = (int64_t)B * H * W;
+    // the fused form (one thread = all heads of a pixel) for the shapes the network produces; DFFW_NO_REGRESS_MERGE callers pass one head at a time
+    // and keep regress_kernel
+    if (hd.n > 1 && N <= 16 && total < (1ll << 31) && !hd.nofuse) {
+        if (N <= 10) hipLaunchKernelGGL((regress_fused_kernel<10>), dim3(grid_for(total)), dim3(256), 0, s, hd, B, N, H, W, fd, fsb, fsn, fsh, fsw);
+        else hipLaunchKernelGGL((regress_fused_kernel<16>), dim3(grid_for(total)), dim3(256), 0, s, hd, B, N, H, W, fd, fsb, fsn, fsh, fsw);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(regress_kernel, dim3(grid_for(total), (unsigned)hd.n), dim3(256), 0, s, hd, B, N, H, W, fd, fsb, fsn, fsh, fsw);
     return hipGetLastError();
 }

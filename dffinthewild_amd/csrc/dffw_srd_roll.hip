@@ -32,7 +32,8 @@
 
 namespace dffw {
 
-template <int PREC, bool POOL>
+// ABL (development only, DFFW_SRD_ABL): timing ablations -- 1 no stage C, 2 no stage A, 4 no stage B, 8 no fill, 16 no barriers, 32 no global stores
+template <int PREC, bool POOL, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void srd_roll_kernel(const SrdArgs a, const float *__restrict__ w3g, const float *__restrict__ w1g) {
     // (w3g / w1g = a.w3 / a.w1 as separate read-only parameters: only then does hipcc fetch the attention weights with
     // scalar loads; through the struct it used vector loads inside the loop, and beside LDS-DMA every use of a vector
@@ -229,12 +230,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
             // (1) this step's x slice has landed (for every wave after the barrier); feat[s-1] is complete
             trc.stamp(0);
             if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             trc.stamp(1);
             if (s == 0 && tid * 16 < FSLOTB) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[-1] = 0: ring slot 2
 
             // ---- stage C: attention for slice z = s-2 out of feat[z-1], feat[z], feat[z+1]; wave w = pairs of rows 2w, 2w+1 ----
-            if (s >= 2) {
+            if (s >= 2 && !(ABL & 1)) {
                 const int z = s - 2;
                 const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
                 // chunk 0: K octet g = (pixel g >> 1 of the pair, slice z-1 + (g & 1)); chunk 1: (pixel g >> 1, slice z+1) for even g
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                         swap16(ph01, pl01);
                         swap16(ph23, pl23);
                     }
-                    if (g < 2 && r < 8) {
+                    if (g < 2 && r < 8 && !(ABL & 32)) {
                         const int64_t pp = (((int64_t)U.b * a.N + z) * (a.H / 2) + (U.gy0 / 2 + wave)) * (a.W / 2) + U.gx0 / 2 + pb_pc;
                         if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(a.pooled + pp * rec + (g & 1) * C) = make_uint4(ph01, ph23, pl01, pl23);
                         else *reinterpret_cast<uint2 *>(a.pooled + pp * rec + (g & 1) * 4) = make_uint2(ph01, ph23);
@@ -301,14 +302,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                 if constexpr (PARTS == 2) {
                     swap16(h01, l01);
                     swap16(h23, l23);
-                    *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C) = make_uint4(h01, h23, l01, l23);
+                    if ((ABL & 32) == 0 || h01 == 0x12345u) *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C) = make_uint4(h01, h23, l01, l23);
                 } else {
                     *reinterpret_cast<uint2 *>(a.out + pix * rec + (g & 1) * 4) = make_uint2(h01, h23);
                 }
             }
             trc.stamp(2);
             // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ---------------------
-            if (produce) {
+            if (produce && !(ABL & 2)) {
 #pragma unroll
                 for (int j = 0; j < TA; ++j) {
                     if (j >= nA) break;
@@ -326,11 +327,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
             }
             // (2) t complete, stage C has read its three feat slices
             trc.stamp(3);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             trc.stamp(4);
             if (produce) {
                 // ---- stage B: feat[s] = relu(conv.2(t) + shift + x) ----------------------------------------------------
-                {
+                if constexpr (!(ABL & 4)) {
                     const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
                     const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
                     u32x2 xh, xl = {0u, 0u};
@@ -355,9 +356,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                 }
                 // (3) feat[s] complete for everyone's reads of x: the x slot is free, queue the slice RX-1 ahead into it
                 trc.stamp(5);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 trc.stamp(6);
-                issue_next();
+                if constexpr (!(ABL & 8)) issue_next();
                 xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
             } else {
                 vq1 = vq0;
@@ -2103,9 +2104,25 @@ hipError_t launch_srd_roll(int prec, const SrdArgs &a, hipStream_t s) {
     const int want = a.wgs > 0 ? a.wgs : 768;   // three resident workgroups per CU
     const int per_xcd = (a.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+    const char *az = getenv("DFFW_SRD_ABL");   // development: timing ablations (wrong results with any bit set)
+    const int abl = az ? atoi(az) : 0;
 #define DFFW_SRD_LAUNCH(P)                                                                    \
     do {                                                                                      \
-        if (a.pooled) hipLaunchKernelGGL((srd_roll_kernel<P, true>), grid, block, 0, s, a, a.w3, a.w1);   \
+        if (a.pooled && P == P_BF16X3 && abl) {                                               \
+            switch (abl) {                                                                    \
+                case 1: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 1>), grid, block, 0, s, a, a.w3, a.w1); break;   \
+                case 2: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 2>), grid, block, 0, s, a, a.w3, a.w1); break;   \
+                case 4: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 4>), grid, block, 0, s, a, a.w3, a.w1); break;   \
+                case 6: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 6>), grid, block, 0, s, a, a.w3, a.w1); break;   \
+                case 7: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 7>), grid, block, 0, s, a, a.w3, a.w1); break;   \
+                case 8: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 8>), grid, block, 0, s, a, a.w3, a.w1); break;   \
+                case 16: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 16>), grid, block, 0, s, a, a.w3, a.w1); break; \
+                case 32: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 32>), grid, block, 0, s, a, a.w3, a.w1); break; \
+                case 40: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 40>), grid, block, 0, s, a, a.w3, a.w1); break; \
+                case 23: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 23>), grid, block, 0, s, a, a.w3, a.w1); break; \
+                default: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true>), grid, block, 0, s, a, a.w3, a.w1);            \
+            }                                                                                 \
+        } else if (a.pooled) hipLaunchKernelGGL((srd_roll_kernel<P, true>), grid, block, 0, s, a, a.w3, a.w1);   \
         else hipLaunchKernelGGL((srd_roll_kernel<P, false>), grid, block, 0, s, a, a.w3, a.w1);           \
     } while (0)
     switch (prec) {
