@@ -18,6 +18,7 @@
 #include "../../include/dffw.h"
 #include "dffw_conv_roll.h"
 #include "dffw_srd_roll.h"
+#include "dffw_stem.h"
 #include "dffw_conv_tile.h"
 #include "dffw_internal.h"
 
@@ -1136,7 +1137,7 @@ static bool getenv_flag(const char *name) {
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
     X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED)
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1738,7 +1739,10 @@ struct Run {
                 drop_raw(partial);
                 return out;
             }
+            // the pixel-pair stem on whole tiles from the fp32 stack: the persistent pipelined kernel (dffw_stem.hip)
+            const bool stem_pipe_run = stem_pair && !sw.on(SW_NO_STEM_PIPE) && stem_pipe_ok(e->prec, cfg, a, t);
             auto kernel_name = [&](char *kn, int n) {
+                if (stem_pipe_run) return stem_pipe_kernel_name(a, kn, n);
                 conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)), tile_lean(e->prec, cfg, a, t), kn, n);
             };
             {
@@ -1765,7 +1769,7 @@ struct Run {
                 if (ok()) check(hipMemsetAsync(trace, 0, (size_t)t.total_tiles * 64, s), "trace memset");
                 a.trace = trace;
             }
-            check(launch_conv_tile(e->prec, cfg, a, t, s), name.c_str());
+            check(stem_pipe_run ? launch_stem_pipe(a, t, sw.roll_wgs, s) : launch_conv_tile(e->prec, cfg, a, t, s), name.c_str());
             prof_end();
             if (t.ksplit > 1) {
                 prof_begin("dffw::splitk_finish_kernel", name + " (split-K finish)", 0.0,
