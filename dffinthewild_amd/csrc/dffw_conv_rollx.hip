@@ -29,15 +29,6 @@
 
 namespace dffw {
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 namespace rollx {
 constexpr int TY = 8, TX = 16, FY = TY + 2, FX = TX + 2, HALF = FX / 2, NW = 4, RING = 6;
 constexpr int ROWE = 2 * FX;          // 16-byte entries per footprint row of a tensor plane: [hi: 18 pixels][lo: 18 pixels]

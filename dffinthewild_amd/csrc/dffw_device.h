@@ -3,9 +3,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "dffw_internal.h"
 
 namespace dffw {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) -- for bodies whose asm immediates, wait counts
+// or scheduling hints must be constants of the iteration
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 typedef __attribute__((ext_vector_type(8))) short short8;
 typedef __attribute__((ext_vector_type(4))) short short4v;

@@ -1262,19 +1262,21 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
         }
     };
 
-    // stage A: the 10 x 18 t pixels are 12 operand tiles (the last one partly idle), three per wave
+    // stage A: the 10 x 18 t pixels are 12 operand tiles, three per wave: tiles 0-9 = the first 16 pixels of row 0-9 (16 consecutive pixels of ONE
+    // row: conflict-free operand reads; tiles of 16 consecutive indices of the region wrapped rows and collided two ways, as in srd_roll16 before
+    // round 4), tiles 10-11 = the two remaining pixels of each row (the last one a quarter busy)
     constexpr int TA = 3;
     int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
     bool ta_ok[TA];
 #pragma unroll
     for (int j = 0; j < TA; ++j) {
-        int p = (wave * TA + j) * 16 + r;
-        ta_ok[j] = p < TPIX;
-        if (p >= TPIX) p = TPIX - 1;
-        ta_y[j] = p / TXT;
-        ta_x[j] = p - ta_y[j] * TXT;
+        const int tile = wave * TA + j;
+        const int q = (tile - TYT) * 16 + r;                       // index among the 2 * TYT left-over pixels
+        ta_ok[j] = tile < TYT || q < 2 * TYT;
+        ta_y[j] = tile < TYT ? tile : (q < 2 * TYT ? q >> 1 : TYT - 1);
+        ta_x[j] = tile < TYT ? r : TX + (q & 1);
         pa[j] = (ta_y[j] * XX + ta_x[j]) * XPIXB + (CIN8 ? 0 : (g & 1) * 16);
-        ta_st[j] = T_OFF + p * PIXB + g * 8;
+        ta_st[j] = T_OFF + (ta_y[j] * TXT + ta_x[j]) * PIXB + g * 8;
     }
     // K octets: 8 input channels: chunk k, octet g = filter tap 4k + g; 16 channels: (tap 2k + (g >> 1), channel octet g & 1);
     // taps >= 9 carry zero weights
