@@ -891,11 +891,11 @@ const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt) {
 
 // the launch takes the LEAN instantiation (straight-line epilogue): split-bf16 storage, no split-K / raw-stack / row-sums variant,
 // something to write, ReLU (if any) after the residual, at most one residual in the output's own geometry, and EVERY 16-channel
-// result tile of the kernel a real one (the straight-line epilogue has no per-tile channel guard: Cout = 48 / 80 / 96 / 112 run on 4- /
-// 8-tile kernels whose padding tiles must not store) or the packed 8-channel form
+// result tile of the layer a real one (the straight-line epilogue has no per-tile channel guard: Cout = 48 / 80 / 96 / 112 are packed as 4 / 8
+// tiles whose padding tiles must not store; a channel-split launch, c->nt < nt_total, walks real tiles only) or the packed 8-channel form
 bool tile_lean(int prec, const TileCfg *c, const ConvArgs &a, const TileArgs &t) {
     return prec == P_BF16X3 && t.ksplit <= 1 && !(a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)) && (a.out || a.out_pre || a.cls_w) && !a.outf && !a.res1 &&
-           !a.res_bcast && a.relu != 2 && (a.Cout == c->nt * 16 || (a.Cout == 8 && c->nt == 1)) && !(a.dbg & DFFW_ARGS_NO_LEAN_TILE) &&
+           !a.res_bcast && a.relu != 2 && (a.Cout == t.nt_total * 16 || (a.Cout == 8 && c->nt == 1)) && !(a.dbg & DFFW_ARGS_NO_LEAN_TILE) &&
            c->id != 23 && c->id != 27;   // (these two transposed-conv configurations need 7 / 10 registers more with it: a wave per SIMD lost)
 }
 
