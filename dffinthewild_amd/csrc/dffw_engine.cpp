@@ -1137,7 +1137,7 @@ static bool getenv_flag(const char *name) {
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
     X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE)
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -2043,7 +2043,23 @@ static Act pyramid_scale(Run &r, const std::string &S, const char *tag, Act &t) 
 // hourglassup.forward (DEN.py:212-238)
 static Act pyramid(Run &r, const std::string &S, const Act &v3) {
     ConvOpt rl; rl.relu = 1;
-    Act p8 = r.pool(v3, 1, 2), p16 = r.pool(v3, 1, 4), p32 = r.pool(v3, 1, 8);
+    Act p8, p16, p32;
+    if (v3.H % 8 == 0 && v3.W % 8 == 0 && !r.sw.on(SW_NO_POOL3)) {   // one pass over v3 for the three pyramid scales (pool3_kernel)
+        p8 = r.act(v3.B, v3.N, v3.H / 2, v3.W / 2, v3.C);
+        p16 = r.act(v3.B, v3.N, v3.H / 4, v3.W / 4, v3.C);
+        p32 = r.act(v3.B, v3.N, v3.H / 8, v3.W / 8, v3.C);
+        if (r.ok() && !r.dry) {
+            char kn[48];
+            snprintf(kn, sizeof kn, "dffw::pool3_kernel<%d>", r.e->prec);
+            r.prof_begin(kn, "avgpool (1,2,2)+(1,4,4)+(1,8,8)", 0.0, (double)(v3.pixels() + p8.pixels() + p16.pixels() + p32.pixels()) * v3.C * r.elem_bytes());
+            r.check(launch_pool3(r.e->prec, v3.p, p8.p, p16.p, p32.p, v3.B, v3.N, v3.H, v3.W, v3.C, r.s), "pool3");
+            r.prof_end();
+        }
+    } else {
+        p8 = r.pool(v3, 1, 2);
+        p16 = r.pool(v3, 1, 4);
+        p32 = r.pool(v3, 1, 8);
+    }
     // the three scales are independent chains of 4 convs (DEN.py:216-223): side by side when concurrency is on
     r.forked = r.concurrent;
     r.fork(0);

@@ -91,6 +91,8 @@ hipError_t launch_stack_in(int prec, const float *FS, uint16_t *out, int B, int 
 hipError_t launch_from_ncdhw(int prec, const float *x, uint16_t *out, int B, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_to_ncdhw(int prec, const uint16_t *x, float *out, int B, int C, int N, int H, int W, hipStream_t s);
 hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *out, int B, int N, int H, int W, int C, hipStream_t s);
+// the three average pools (1,2,2), (1,4,4), (1,8,8) of one volume in one pass, each bit-identical to launch_pool's (H, W multiples of 8)
+hipError_t launch_pool3(int prec, const uint16_t *x, uint16_t *o2, uint16_t *o4, uint16_t *o8, int B, int N, int H, int W, int C, hipStream_t s);
 bool srd_attention_supported(int C);
 // pooled: optional (B,N,H/2,W/2,C) volume receiving the (1,2,2) max-pool of the result, or null
 hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, const float *w3, const float *w1, int B, int N,

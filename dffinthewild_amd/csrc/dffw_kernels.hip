@@ -509,6 +509,84 @@ __global__ __launch_bounds__(256) void pool_kernel(const uint16_t *__restrict__ 
     }
 }
 
+// pool3_kernel: the pyramid's three average pools (1,2,2), (1,4,4), (1,8,8) of the same volume (hourglassup.forward, DEN.py:212-216) in ONE pass: as three
+// launches the 32-channel volume was read three times (0.17 GB each at batch 32).  Work item = (8 x 8 block, channel octet); its 8 lanes hold one block row
+// each (8 pixels x 8 channels, joined to fp32 in registers) and every level is summed from those registers in pool_kernel's own order -- the window row
+// left to right, then the xor-shuffle tree over the window's rows -- so the three outputs are bit-identical to the three launches (tested).
+template <int PREC>
+__global__ __launch_bounds__(256) void pool3_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ o2, uint16_t *__restrict__ o4, uint16_t *__restrict__ o8,
+                                                    int B, int N, int H, int W, int C) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    const int H8 = H / 8, W8 = W / 8, C8 = C / 8;
+    const int64_t total = (int64_t)B * N * H8 * W8 * C8 * 8;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int dy = (int)(i0 & 7);
+        const int64_t i = i0 >> 3;
+        const int c8 = (int)(i % C8);
+        int64_t t = i / C8;
+        const int bx = (int)(t % W8);
+        t /= W8;
+        const int by = (int)(t % H8);
+        const int64_t bn = t / H8;
+        float v[8][8];   // [pixel of the row][channel]
+        const uint16_t *row = x + ((bn * H + (by * 8 + dy)) * W + bx * 8) * (int64_t)(PARTS * C) + c8 * 8;
+#pragma unroll
+        for (int dx = 0; dx < 8; ++dx) {
+            const uint16_t *p = row + dx * (PARTS * C);
+            const short8 h = *reinterpret_cast<const short8 *>(p);
+            short8 l = short8{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (PARTS == 2) l = *reinterpret_cast<const short8 *>(p + C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[dx][j] = Fmt<PREC>::join((uint16_t)h[j], (uint16_t)l[j]);
+        }
+        auto emit = [&](uint16_t *out, int k, int Ho, int Wo, int oy, int ox, const float (&sum)[8]) {
+            const float inv = 1.0f / (float)(k * k);
+            short8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint16_t hi, lo;
+                Fmt<PREC>::split(sum[j] * inv, hi, lo);
+                h[j] = (short)hi;
+                l[j] = (short)lo;
+            }
+            uint16_t *q = out + ((bn * Ho + oy) * Wo + ox) * (int64_t)(PARTS * C) + c8 * 8;
+            *reinterpret_cast<short8 *>(q) = h;
+            if constexpr (PARTS == 2) *reinterpret_cast<short8 *>(q + C) = l;
+        };
+        // level k: windows of k columns inside the row (summed left to right from zero, as pool_kernel does), then the tree over k rows
+        auto level = [&](auto K, uint16_t *out) {
+            constexpr int k = decltype(K)::value;
+#pragma unroll
+            for (int wx = 0; wx < 8 / k; ++wx) {
+                float sum[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int dx = 0; dx < k; ++dx) a = a + v[wx * k + dx][j];
+                    sum[j] = a;
+                }
+#pragma unroll
+                for (int off = 1; off < k; off <<= 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum[j] = sum[j] + __shfl_xor(sum[j], off);
+                }
+                if ((dy & (k - 1)) == 0) emit(out, k, H / k, W / k, (by * 8 + dy) / k, bx * (8 / k) + wx, sum);
+            }
+        };
+        level(std::integral_constant<int, 2>{}, o2);
+        level(std::integral_constant<int, 4>{}, o4);
+        level(std::integral_constant<int, 8>{}, o8);
+    }
+}
+
+hipError_t launch_pool3(int prec, const uint16_t *x, uint16_t *o2, uint16_t *o4, uint16_t *o8, int B, int N, int H, int W, int C, hipStream_t s) {
+    if (C % 8 || H % 8 || W % 8) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)B * N * (H / 8) * (W / 8) * (C / 8) * 8;
+    DFFW_PREC_SWITCH(prec, hipLaunchKernelGGL((pool3_kernel<PR>), dim3(grid_for(total)), dim3(256), 0, s, x, o2, o4, o8, B, N, H, W, C));
+    return hipGetLastError();
+}
+
 hipError_t launch_pool(int prec, int mode, int k, const uint16_t *x, uint16_t *out, int B, int N, int H, int W, int C,
                        hipStream_t s) {
     if (C % 8 || H % k || W % k || (k != 2 && k != 4 && k != 8)) return hipErrorInvalidValue;

@@ -272,7 +272,7 @@ def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monk
     model = model_for(sd, (meta["wseed"], meta["profile"]))
     with torch.no_grad():
         base = [o.clone() for o in model(FS.cuda(), fd.cuda())]
-        for env, val in (("DFFW_NO_LEAN_TILE", "1"), ("DFFW_NO_LEAN_ROLL", "1"), ("DFFW_NO_REGRESS_MERGE", "1"), ("DFFW_NO_REGRESS_FUSED", "1"), ("DFFW_NO_STEM_PIPE", "1"), ("DFFW_WARM_MAX_WGS", "0")):
+        for env, val in (("DFFW_NO_LEAN_TILE", "1"), ("DFFW_NO_LEAN_ROLL", "1"), ("DFFW_NO_REGRESS_MERGE", "1"), ("DFFW_NO_REGRESS_FUSED", "1"), ("DFFW_NO_STEM_PIPE", "1"), ("DFFW_NO_POOL3", "1"), ("DFFW_WARM_MAX_WGS", "0")):
             monkeypatch.setenv(env, val)
             alt = model(FS.cuda(), fd.cuda())
             torch.cuda.synchronize()
