@@ -2077,28 +2077,41 @@ static Act pyramid(Run &r, const std::string &S, const Act &v3) {
     r.join(1);
     r.forked = false;
     r.release_deferred();
+    // redir1 / redir2 (1x1x1 conv + BN of x_8 / of conv2's output, DEN.py:209-210,234-237) only feed the residual inputs of conv9 / conv8: they run on the
+    // side streams next to the chain conv1 ... conv4 instead of between its launches (two small gather-GEMM launches off the critical path)
+    r.forked = r.concurrent;
+    r.fork(0);
+    r.on(0);
+    Act rd1 = r.conv(S + ".redir1.0", s8);
+    r.on(-1);
     Act d1 = r.conv(S + ".conv1", s8);
+    r.drop(s8);
     ConvOpt c1 = rl; c1.in1 = &s16;
     Act m1 = r.conv(S + ".combine1.0.0", d1, c1);
     r.drop(d1); r.drop(s16);
     Act c2 = r.conv(S + ".conv2.0.0", m1, rl);
     r.drop(m1);
+    r.fork(1);
+    r.on(1);
+    Act rd2 = r.conv(S + ".redir2.0", c2);
+    r.on(-1);
     Act d2 = r.conv(S + ".conv3", c2);
+    r.drop(c2);
     ConvOpt cc2 = rl; cc2.in1 = &s32;
     Act m2 = r.conv(S + ".combine2.0.0", d2, cc2);
     r.drop(d2); r.drop(s32);
     Act c4 = r.conv(S + ".conv4.0.0", m2, rl);
     r.drop(m2);
-    Act rd2 = r.conv(S + ".redir2.0", c2);
-    r.drop(c2);
+    r.join(1);
     ConvOpt u8o = rl; u8o.res0 = &rd2;
     Act u8 = r.conv(S + ".conv8.0", c4, u8o);
     r.drop(c4); r.drop(rd2);
-    Act rd1 = r.conv(S + ".redir1.0", s8);
-    r.drop(s8);
+    r.join(0);
     ConvOpt u9o = rl; u9o.res0 = &rd1;
     Act u9 = r.conv(S + ".conv9.0", u8, u9o);
     r.drop(u8); r.drop(rd1);
+    r.forked = false;
+    r.release_deferred();
     return u9;
 }
 
