@@ -68,6 +68,8 @@ struct TileArgs {
 // returns nullptr when no instantiation covers (geo, nt, cg)
 // wide: prefer an 8-wave 640-point instantiation when one exists
 const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide = false);
+// the 4-wave configuration with exactly this block shape, or nullptr
+const TileCfg *tile_cfg_find_shape(int geo, int nt, int cg, int tz, int ty, int tx);
 // configuration with the same geometry, channel group and TILE SHAPE as `base` but `nt` output tiles (for splits)
 const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt);
 bool tile_cfg_has_splitk(const TileCfg *c);   // a split-K instantiation of this configuration exists

@@ -824,7 +824,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(37, G3S2, 4, 4, 4, 8, 16, 1)   \
     X(38, G3S2, 2, 4, 4, 8, 16, 1)   \
     X(39, G3S2, 1, 4, 4, 8, 16, 1)   \
-    X(32, G2P, 1, 1, 16, 32, 8, 0)
+    X(32, G2P, 1, 1, 16, 32, 8, 0)   \
+    X(40, G3S1, 1, 5, 8, 8, 16, 1)   \
+    X(41, G3S1, 2, 5, 8, 8, 16, 1)   \
+    X(42, G3S1, 4, 5, 8, 8, 16, 1)   \
+    X(43, G3T, 1, 5, 8, 8, 32, 0)    \
+    X(44, G3T, 2, 5, 8, 8, 32, 1)    \
+    X(45, G3T, 4, 5, 8, 8, 32, 1)
+// (40-45, round 4: 5 x 8 x 8 blocks for grids at most 8 wide -- the 1/32-resolution pyramid layers at 256 x 256: on the 5 x 4 x 16 block half of
+// every operand tile lies outside an 8 x 8 grid, and the 4 x 4 x 8 block re-streams the filter for 128 grid points at a time; tile_cfg_find_shape)
 // 8-wave "wide" variants: 640-point tiles, same work per wave.  Measured +8..17 % on the bandwidth-bound
 // single-stage layers with <= 16 output channels (one more resident wave per SIMD for the same LDS, 17 % less
 // halo per output), -10 % on the 32-channel / multi-stage ones, so the engine asks for them only for the former.
@@ -880,6 +888,12 @@ const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide) {
             if (c.nw == 8 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
     for (const TileCfg &c : g_cfgs)
         if (c.nw == 4 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
+    return nullptr;
+}
+
+const TileCfg *tile_cfg_find_shape(int geo, int nt, int cg, int tz, int ty, int tx) {
+    for (const TileCfg &c : g_cfgs)
+        if (c.nw == 4 && c.geo == geo && c.nt == nt && c.cg == cg && c.tz == tz && c.ty == ty && c.tx == tx) return &c;
     return nullptr;
 }
 

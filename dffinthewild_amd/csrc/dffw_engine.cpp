@@ -301,6 +301,7 @@ struct PackedConv {
     float *bias = nullptr;  // device, nt*16 floats
     std::vector<Variant> variants;
     TilePack tile;
+    TilePack tile_narrow;   // 3x3x3 stride-1 / transposed layers once more on the 5 x 8 x 8 block (grids at most 8 wide, Run::conv decides per call)
     TilePack tile_pair;     // the stem once more, for the pixel-pair kernel (G2P); bias_pair = its BatchNorm shift for both pixels' rows
     float *bias_pair = nullptr;
     float *w32 = nullptr;  // device fp32 [kz][cin][cout] (BatchNorm folded) for kh = kw = 1 layers: fused VALU kernels
@@ -326,7 +327,7 @@ static void free_packed(PackedConv &pc) {
     }
     pc.variants.clear();
     pc.bias = nullptr;
-    for (TilePack *tp : {&pc.tile, &pc.tile_pair}) {
+    for (TilePack *tp : {&pc.tile, &pc.tile_pair, &pc.tile_narrow}) {
         for (int i = 0; i < 4; ++i) {
             if (tp->tab[i]) (void)hipFree(tp->tab[i]);
             if (tp->wpk[i]) (void)hipFree(tp->wpk[i]);
@@ -599,6 +600,14 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         if (cfg && cin_t % cg == 0) {
             const int rc = pack_tile(pc.tile, cfg, cg, false);
             if (rc != DFFW_OK) return rc;
+        }
+        // ... and on the 5 x 8 x 8 block where an instantiation exists (at most 4 output tiles per workgroup: wider layers always split there)
+        if ((geo == G3S1 || geo == G3T) && cfg && cin_t % cg == 0 && L.cout >= 32 && !stem) {
+            const TileCfg *ncfg = tile_cfg_find_shape(geo, std::min(pc.nt, 4), cg, 5, 8, 8);
+            if (ncfg) {
+                const int rc = pack_tile(pc.tile_narrow, ncfg, cg, false);
+                if (rc != DFFW_OK) return rc;
+            }
         }
         const TileCfg *pcfg = (stem && L.cout == 8 && !getenv("DFFW_NO_STEM_PAIR")) ? tile_cfg_find(G2P, 1, 8, wide && !getenv("DFFW_STEM_NARROW")) : nullptr;
         if (pcfg) {
@@ -1137,7 +1146,7 @@ static bool getenv_flag(const char *name) {
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
     X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3)
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1585,8 +1594,11 @@ struct Run {
         const bool stem_pair = o.fs32 && pc.tile_pair.cfg && pc.bias_pair && Wo % pc.tile_pair.cfg->tx == 0 && Ho % pc.tile_pair.cfg->ty == 0 &&
                                !sw.on(SW_NO_STEM_PAIR);
         if (stem_pair) a.bias = pc.bias_pair;
-        const TilePack &tp = stem_pair ? pc.tile_pair : pc.tile;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
+        // grids at most 8 x 8 (the 1/32-resolution pyramid layers at 256 x 256) with enough samples to fill the chip: the 5 x 8 x 8 block
+        const bool narrow = !stem_pair && pc.tile_narrow.cfg && gW <= 8 && gH <= 8 && !sw.on(SW_NO_NARROW) &&
+                            (int64_t)in0.B * (((L.transposed ? in0.N : No) + 4) / 5) * pc.nt >= 256;
+        const TilePack &tp = stem_pair ? pc.tile_pair : (narrow ? pc.tile_narrow : pc.tile);
         // 32 -> 16 channels on whole 8 x 16 columns: the pipelined rolling window with the contraction split over the two input halves
         {
             const int cols = (Ho / 8) * (Wo / 16);
@@ -1695,14 +1707,14 @@ struct Run {
             t.tiles_x = (a.Wg + cfg->tx - 1) / cfg->tx;
             t.total_tiles = a.B * t.tiles_z * t.tiles_y * t.tiles_x;
             t.nt_total = pc.nt;
-            t.nsplit = 1;
+            t.nsplit = pc.nt / cfg->nt;   // (1, except the narrow packs of layers with more than 4 output tiles)
             // few-tile layers (the 1/16..1/32-resolution pyramid, or batch 1): split the output channels over
             // grid.y so that at least ~one workgroup per CU exists
             // (3x3x3 stride-1 and transposed layers also at exactly one tile per CU -- the 16x16-grid layers at batch 32: two 32-channel
             // workgroups per tile keep three workgroups resident instead of two, -10 % on those layers; the stride-2 layers lose 40 % with it)
             const int split_below = (cfg->geo == G3S1 || cfg->geo == G3T) ? 257 : 256;
             if (t.total_tiles < split_below && pc.nt > 1 && !o.cls && !sw.on(SW_NO_SPLIT)) {
-                const int want = (256 + t.total_tiles - 1) / t.total_tiles;   // split factor that would fill the chip
+                const int want = (256 + t.total_tiles - 1) / t.total_tiles;   // split factor that would fill the chip (narrow blocks: 512 measured level)
                 for (int nts = pc.nt / 2; nts >= 1; nts /= 2) {               // coarsest split first
                     const TileCfg *c2 = tile_cfg_find_like(tp.cfg, nts);
                     if (!c2) continue;
