@@ -1205,7 +1205,11 @@ __global__ __launch_bounds__(NT * KH == 4 ? 512 : 256) void conv_roll_s2(const C
     constexpr int CIN = 16 * KH, NWAVES = (NT * KH == 4) ? 8 : 4;
     static_assert(KH == 1 || NT == 2, "the channel-split form is built for two output tiles (8 waves)");
     constexpr int TY = 4, TX = NT == 2 ? 8 : 16, PIXB = 2 * CIN, OCT = 2 * KH;
-    constexpr int XY = 2 * TY + 1, XX = 2 * TX + 1, XPIX = XY * XX, XEV = TX + 1;   // footprint of a slice; XEV even columns per row
+    constexpr int XY = 2 * TY + 1, XXR = 2 * TX + 1, XEV = TX + 1;   // footprint of a slice (XXR columns per row); XEV even columns per row
+    // LDS row pitch: with two output rows per operand tile (NT = 2: rows 2*tl, 2*tl + 1 = input rows two apart) the 16 lanes of a ds_read_b128 row group
+    // only cover 16 distinct bank groups when those rows are a multiple of 256 bytes apart, i.e. when the pitch is a multiple of 4 pixels (17-pixel
+    // rows: every read collided two ways, lds_conflict 0.50 for three rounds); the pad columns read the zero page
+    constexpr int XX = (NT == 2) ? (XXR + 3) / 4 * 4 : XXR, XPIX = XY * XX;
     constexpr int NPIECE = (XPIX * OCT + 63) / 64;                                   // 1 KiB wave instructions per plane (64 x (pixel, octet))
     constexpr int PLANEB = NPIECE * 1024, SLOTB = PARTS * PLANEB;
     constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;             // wave w issues pieces [w * PPW, min(NP, (w + 1) * PPW))
@@ -1253,9 +1257,9 @@ __global__ __launch_bounds__(NT * KH == 4 ? 512 : 256) void conv_roll_s2(const C
             const int part = p / NPIECE, i = p % NPIECE;
             const int ci = i * 64 + lane, sl = ci / OCT, oct = ci % OCT;
             const int fy = sl / XX, pos = sl - fy * XX;
-            const int cx = pos < XEV ? 2 * pos : 2 * (pos - XEV) + 1;   // even columns first, then the odd ones
+            const int cx = pos < XEV ? 2 * pos : 2 * (pos - XEV) + 1;   // even columns first, then the odd ones (pos >= XXR: pad column)
             const int iy = 2 * c.gy0 - 1 + fy, ix = 2 * c.gx0 - 1 + cx;
-            fok[k] = p < NP && sl < XPIX && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            fok[k] = p < NP && sl < XPIX && pos < XXR && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
             fsrc[k] = a.in0 + (int64_t)c.b * a.Ni * xslice + (int64_t)(iy * a.Wi + ix) * rec + part * CIN + oct * 8;
         }
     };
