@@ -221,22 +221,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 #endif
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
-        // Step s of a column: phase 1 = stage A of slice s (t = conv.0) on waves 2-3 (mostly) NEXT TO stage C of slice s-2
-        // (attention out of feat[s-3..s-1]) on waves 0-1; phase 2 = stage B of slice s (feat[s] = conv.2 + x) on all
-        // waves.  feat lives in a ring of 3 fp32 slices: stage B(s) overwrites the slot stage C(s-2) read last.
-        for (int s = 0; s <= a.N + 1; ++s) {
+        // Step s of a column (s = 0 .. N): phase 1 = stage A of slice s (t = conv.0; waves 0-1 two operand tiles, waves 2-3 one); phase 2 = stage B
+        // of slice s (feat[s] = conv.2 + x) and, on the same wave right behind it, stage C of slice s-1 (attention out of feat[s-2..s]).
+        // A wave's stage B and stage C work on the same 32 pixels, so the feat ring (3 slices as hi/lo records) is wave-private: stage C follows
+        // stage B without a barrier, one slice behind, and the column drains in ONE extra step that holds nothing but stage C of the last slice.
+        // (Rounds 1-3 ran stage C two slices behind in phase 1, next to stage A: 2 + 1 operand tiles on the critical path of phase 1, one in
+        // phase 2, N + 2 steps per column.)
+        for (int s = 0; s <= a.N; ++s) {
             const bool produce = s < a.N;
             const unsigned fslot_off = F_OFF + (s % 3) * FSLOTB;
-            // (1) this step's x slice has landed (for every wave after the barrier); feat[s-1] is complete
             trc.stamp(0);
-            if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (produce) {
+                // (1) this step's x slice has landed (for every wave after the barrier)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+                if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
             trc.stamp(1);
-            if (s == 0 && tid * 16 < FSLOTB) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[-1] = 0: ring slot 2
-
-            // ---- stage C: attention for slice z = s-2 out of feat[z-1], feat[z], feat[z+1]; wave w = pairs of rows 2w, 2w+1 ----
-            if (s >= 2 && !(ABL & 1)) {
-                const int z = s - 2;
+            if (s == 0) {   // feat[-1] = 0 (ring slot 2), the wave's own pixels
+                lds_store8(F_OFF + 2 * FSLOTB + pb_f + (g & 1) * 8, 0u, 0u);
+                if constexpr (PARTS == 2) lds_store8(F_OFF + 2 * FSLOTB + FPLANEB + pb_f + (g & 1) * 8, 0u, 0u);
+            }
+            // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ---------------------
+            if (produce && !(ABL & 2)) {
+#pragma unroll
+                for (int j = 0; j < TA; ++j) {
+                    if (j >= nA) break;
+                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], XX * PIXB, PLANEB, w0, b0);
+                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
+                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    if (ta_ok[j]) {
+                        uint32_t h01, h23, l01, l23;
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                        lds_store8(ta_st[j], h01, h23);
+                        if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
+                    }
+                }
+            }
+            trc.stamp(2);
+            if (produce) {
+                // (2) t complete
+                if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                trc.stamp(3);
+                // ---- stage B: feat[s] = relu(conv.2(t) + shift + x) ----------------------------------------------------
+                if constexpr (!(ABL & 4)) {
+                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
+                    const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
+                    u32x2 xh, xl = {0u, 0u};
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
+                    if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
+                    float r0, r1, r2, r3;
+                    Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
+                    Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
+                    f32x4 v;
+                    v[0] = relu_bits(acc[0] + r0);
+                    v[1] = relu_bits(acc[1] + r1);
+                    v[2] = relu_bits(acc[2] + r2);
+                    v[3] = relu_bits(acc[3] + r3);
+                    uint32_t fh01, fh23, fl01, fl23;
+                    Fmt<PREC>::split2(v[0], v[1], fh01, fl01);
+                    Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
+                    lds_store8(fslot_off + pb_f + (g & 1) * 8, fh01, fh23);
+                    if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + (g & 1) * 8, fl01, fl23);
+                    vq1 = vq0;   // fp32 feat of this lane's pixel / channels, two steps deep: stage C adds it back
+                    vq0 = v;
+                }
+            } else {
+                vq1 = vq0;
+                lds_store8(fslot_off + pb_f + (g & 1) * 8, 0u, 0u);   // feat[N] = 0
+                if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + (g & 1) * 8, 0u, 0u);
+            }
+            trc.stamp(4);
+            // ---- stage C: attention for slice z = s-1 out of feat[z-1], feat[z], feat[z+1] = the slice stage B just wrote (or the zeros behind the
+            // last one); wave w = pairs of rows 2w, 2w+1 = the pixels ITS stage B produced: feat never crosses waves, no barrier in between ----
+            if (s >= 1 && !(ABL & 1)) {
+                const int z = s - 1;
                 const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
                 // chunk 0: K octet g = (pixel g >> 1 of the pair, slice z-1 + (g & 1)); chunk 1: (pixel g >> 1, slice z+1) for even g
                 const unsigned ad0 = lds0 + ((g & 1) ? sc : sm) + pb_f, ad1 = lds0 + sp + pb_f;
@@ -307,64 +367,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     *reinterpret_cast<uint2 *>(a.out + pix * rec + (g & 1) * 4) = make_uint2(h01, h23);
                 }
             }
-            trc.stamp(2);
-            // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ---------------------
-            if (produce && !(ABL & 2)) {
-#pragma unroll
-                for (int j = 0; j < TA; ++j) {
-                    if (j >= nA) break;
-                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], XX * PIXB, PLANEB, w0, b0);
-                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
-                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                    if (ta_ok[j]) {
-                        uint32_t h01, h23, l01, l23;
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
-                        lds_store8(ta_st[j], h01, h23);
-                        if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
-                    }
-                }
-            }
-            // (2) t complete, stage C has read its three feat slices
-            trc.stamp(3);
-            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            trc.stamp(4);
+            trc.stamp(5);
             if (produce) {
-                // ---- stage B: feat[s] = relu(conv.2(t) + shift + x) ----------------------------------------------------
-                if constexpr (!(ABL & 4)) {
-                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
-                    const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
-                    u32x2 xh, xl = {0u, 0u};
-                    asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
-                    if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
-                    float r0, r1, r2, r3;
-                    Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
-                    Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
-                    f32x4 v;
-                    v[0] = relu_bits(acc[0] + r0);
-                    v[1] = relu_bits(acc[1] + r1);
-                    v[2] = relu_bits(acc[2] + r2);
-                    v[3] = relu_bits(acc[3] + r3);
-                    uint32_t fh01, fh23, fl01, fl23;
-                    Fmt<PREC>::split2(v[0], v[1], fh01, fl01);
-                    Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
-                    lds_store8(fslot_off + pb_f + (g & 1) * 8, fh01, fh23);
-                    if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + (g & 1) * 8, fl01, fl23);
-                    vq1 = vq0;   // fp32 feat of this lane's pixel / channels, two steps deep: stage C adds it back
-                    vq0 = v;
-                }
-                // (3) feat[s] complete for everyone's reads of x: the x slot is free, queue the slice RX-1 ahead into it
-                trc.stamp(5);
+                // (3) everyone's reads of x and t are done: the x slot is free, queue the slice RX-1 ahead into it
                 if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 trc.stamp(6);
                 if constexpr (!(ABL & 8)) issue_next();
                 xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
-            } else {
-                vq1 = vq0;
-            }
-            if (s == a.N) {
-                if (tid * 16 < FSLOTB) lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});   // feat[N] = 0
             }
             trc.next();
         }
@@ -1016,16 +1025,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
-        for (int s = 0; s <= a.N + 1; ++s) {
+        // a step as in srd_roll_kernel: stage A | barrier | stage B of slice s, then stage C of slice s-1 on the same wave (its own pixels: the feat
+        // ring is wave-private); N + 1 steps per column, the last one holds only stage C of the last slice
+        for (int s = 0; s <= a.N; ++s) {
             const bool produce = s < a.N;
             const unsigned fslot_off = F_OFF + (s % 3) * FSLOTB;
-            if (produce) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (s == 0 && tid * 16 < FSLOTB) lds_store16(F_OFF + 2 * FSLOTB + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
-
-            // ---- stage C: attention for slice z = s-2 ----------------------------------------------------------------------
-            if (s >= 2 && !(ABL & 1)) {
-                const int z = s - 2;
+            if (produce) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+                if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if (s == 0) {   // feat[-1] = 0 (ring slot 2), the wave's own pixels
+                lds_store8(F_OFF + 2 * FSLOTB + pb_f + g * 8, 0u, 0u);
+                if constexpr (PARTS == 2) lds_store8(F_OFF + 2 * FSLOTB + FPLANEB + pb_f + g * 8, 0u, 0u);
+            }
+            // ---- stage A ---------------------------------------------------------------------------------------------------------
+            if (produce && !(ABL & 2)) {
+                f32x4 accA[TA];
+                if (nA == 2) {
+                    accA[0] = b0;
+                    accA[1] = b0;
+                    tile_mma2(lds0 + X_OFF + xslot * SLOTB + pa[0], lds0 + X_OFF + xslot * SLOTB + pa[1], tapA, PLANEB, w0, accA[0], accA[1]);
+                } else {
+                    accA[0] = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[0], tapA, PLANEB, w0, b0);
+                    accA[1] = b0;
+                }
+#pragma unroll
+                for (int j = 0; j < TA; ++j) {
+                    if (j >= nA) break;
+                    const f32x4 acc = accA[j];
+                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
+                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    if (ta_ok[j]) {
+                        uint32_t h01, h23, l01, l23;
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
+                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                        lds_store8(ta_st[j], h01, h23);
+                        if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
+                    }
+                }
+            }
+            if (produce) {
+                if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // ---- stage B ---------------------------------------------------------------------------------------------------------
+                if constexpr (!(ABL & 4)) {
+                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, tapB, TPLANEB, w2, b2);
+                    const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
+                    u32x2 xh, xl = {0u, 0u};
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
+                    if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
+                    float r0, r1, r2, r3;
+                    Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
+                    Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
+                    f32x4 v;
+                    v[0] = relu_bits(acc[0] + r0);
+                    v[1] = relu_bits(acc[1] + r1);
+                    v[2] = relu_bits(acc[2] + r2);
+                    v[3] = relu_bits(acc[3] + r3);
+                    uint32_t fh01, fh23, fl01, fl23;
+                    Fmt<PREC>::split2(v[0], v[1], fh01, fl01);
+                    Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
+                    lds_store8(fslot_off + pb_f + g * 8, fh01, fh23);
+                    if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + g * 8, fl01, fl23);
+                    vq1 = vq0;
+                    vq0 = v;
+                }
+            } else {
+                vq1 = vq0;
+                lds_store8(fslot_off + pb_f + g * 8, 0u, 0u);   // feat[N] = 0
+                if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + g * 8, 0u, 0u);
+            }
+            // ---- stage C: attention for slice z = s-1 (feat[z+1] = what stage B just wrote, or the zeros behind the last slice) ----------------------------------------------------------------------
+            if (s >= 1 && !(ABL & 1)) {
+                const int z = s - 1;
                 const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
                 // chunk 0: K octet g = (slice z-1 + (g >> 1), channel octet g & 1); chunk 1: (slice z+1, octet g & 1) for g < 2
                 const unsigned ad0 = lds0 + ((g >> 1) ? sc : sm) + pb_f + (g & 1) * 16, ad1 = lds0 + sp + pb_f + (g & 1) * 16;
@@ -1094,66 +1166,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
                 }
             }
-            // ---- stage A ---------------------------------------------------------------------------------------------------------
-            if (produce && !(ABL & 2)) {
-                f32x4 accA[TA];
-                if (nA == 2) {
-                    accA[0] = b0;
-                    accA[1] = b0;
-                    tile_mma2(lds0 + X_OFF + xslot * SLOTB + pa[0], lds0 + X_OFF + xslot * SLOTB + pa[1], tapA, PLANEB, w0, accA[0], accA[1]);
-                } else {
-                    accA[0] = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[0], tapA, PLANEB, w0, b0);
-                    accA[1] = b0;
-                }
-#pragma unroll
-                for (int j = 0; j < TA; ++j) {
-                    if (j >= nA) break;
-                    const f32x4 acc = accA[j];
-                    const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
-                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                    if (ta_ok[j]) {
-                        uint32_t h01, h23, l01, l23;
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
-                        lds_store8(ta_st[j], h01, h23);
-                        if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
-                    }
-                }
-            }
-            if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (produce) {
-                // ---- stage B ---------------------------------------------------------------------------------------------------------
-                if constexpr (!(ABL & 4)) {
-                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, tapB, TPLANEB, w2, b2);
-                    const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
-                    u32x2 xh, xl = {0u, 0u};
-                    asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
-                    if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xl) : "v"(xp), "n"(PLANEB));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl));
-                    float r0, r1, r2, r3;
-                    Fmt<PREC>::join2(xh[0], xl[0], r0, r1);
-                    Fmt<PREC>::join2(xh[1], xl[1], r2, r3);
-                    f32x4 v;
-                    v[0] = relu_bits(acc[0] + r0);
-                    v[1] = relu_bits(acc[1] + r1);
-                    v[2] = relu_bits(acc[2] + r2);
-                    v[3] = relu_bits(acc[3] + r3);
-                    uint32_t fh01, fh23, fl01, fl23;
-                    Fmt<PREC>::split2(v[0], v[1], fh01, fl01);
-                    Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
-                    lds_store8(fslot_off + pb_f + g * 8, fh01, fh23);
-                    if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + g * 8, fl01, fl23);
-                    vq1 = vq0;
-                    vq0 = v;
-                }
                 if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if constexpr (!(ABL & 8)) issue_next();
                 xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
-            } else {
-                vq1 = vq0;
-            }
-            if (s == a.N) {
-                if (tid * 16 < FSLOTB) lds_store16(fslot_off + tid * 16, f32x4{0.f, 0.f, 0.f, 0.f});
             }
         }
     }
