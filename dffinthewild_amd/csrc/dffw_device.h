@@ -159,6 +159,9 @@ struct StepTrace {
 // covers 16 pixels x 64 contiguous bytes.  `pvalid`: the lane's grid point exists.
 // relu as a signed-integer max on the bit pattern: one instruction, no float canonicalisation in front
 __device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+// ReLU and a position mask in one v_med3_f32: lim = +inf keeps relu(v), lim = 0 gives 0 (t outside the image = the next conv's padding).
+// (Not inline asm on the accumulator: hipcc does not see an asm blob's reads, so the MFMA -> VALU wait states would be missing.)
+__device__ __forceinline__ float relu_lim_bits(float v, int lim) { return __builtin_amdgcn_fmed3f(v, 0.f, __int_as_float(lim)); }
 
 __device__ __forceinline__ void swap16(uint32_t &a, uint32_t &b) {
     // a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3} (rows = 16-lane groups)

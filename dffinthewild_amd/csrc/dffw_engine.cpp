@@ -679,8 +679,8 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         HIPCHK(hipMemcpy(pc.wroll_k2, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- srd_roll stage C: the attention convs of the 8-channel SRD block (DEN.py:322-323) in pixel-pair form.  Result row
-    // m = (pixel m >> 3 of the pair, channel m & 7).  3x1x1: chunk 0 K octet g = (pixel g >> 1, slice g & 1), chunk 1 even g =
-    // (pixel g >> 1, slice 2).  1x1x1: K octet g = (pixel g >> 1, input channels 4*(g & 1)..+3 as [hi x4 | lo x4] of the split
+    // m = (pixel m >> 3 of the pair, channel m & 7).  3x1x1: chunk 0 K octet g = (pixel g >> 1, slice g & 1), chunk 1 = slice 2 in the
+    // 1x1x1 form (its operand is what stage B of the same step leaves in registers).  1x1x1: K octet g = (pixel g >> 1, input channels 4*(g & 1)..+3 as [hi x4 | lo x4] of the split
     // operand): fragment 0 carries w_hi against both halves (w_hi*a_hi + w_hi*a_lo), fragment 1 w_lo against the hi half.
     if (!L.transposed && L.kh == 1 && L.kw == 1 && L.cin == 8 && L.cout == 8 && !bn && !conv_bias) {
         const int nfrag = L.kd == 3 ? 2 * parts : parts;
@@ -690,13 +690,19 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 const int row = lane & 15, gq = lane >> 4, px = row >> 3, co = row & 7;
                 const bool mine = (gq >> 1) == px;
                 if (L.kd == 3) {
-                    for (int c = 0; c < 2; ++c) {
-                        const int sl = c == 0 ? (gq & 1) : ((gq & 1) == 0 ? 2 : -1);
-                        const float val = (mine && sl >= 0) ? (float)wval(co, j, Tap{0, 0, 0, sl, 0, 0}) : 0.f;
+                    {
+                        const float val = mine ? (float)wval(co, j, Tap{0, 0, 0, gq & 1, 0, 0}) : 0.f;
                         uint16_t hi, lo;
                         host_split(prec, val, hi, lo);
-                        wr[((size_t)c * parts) * 512 + lane * 8 + j] = hi;
-                        if (parts == 2) wr[((size_t)c * parts + 1) * 512 + lane * 8 + j] = lo;
+                        wr[(size_t)lane * 8 + j] = hi;
+                        if (parts == 2) wr[(size_t)512 + lane * 8 + j] = lo;
+                    }
+                    {   // chunk 1 = slice tap 2 against the operand stage B leaves in registers (the 1x1x1 form below)
+                        const float val = mine ? (float)wval(co, 4 * (gq & 1) + (j & 3), Tap{0, 0, 0, 2, 0, 0}) : 0.f;
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        wr[((size_t)parts) * 512 + lane * 8 + j] = hi;
+                        if (parts == 2 && j < 4) wr[((size_t)parts + 1) * 512 + lane * 8 + j] = lo;
                     }
                 } else if (L.kd == 1) {
                     const int ci = 4 * (gq & 1) + (j & 3);
@@ -713,7 +719,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         }
     }
     // the same for the 16-channel block (srd_roll16, no pixel pairs: result row = channel).  3x1x1: chunk 0 K octet g =
-    // (slice g >> 1, channel octet g & 1), chunk 1 g < 2 = (slice 2, octet g).  1x1x1: K octet g = input channels 4g..4g+3 as
+    // (slice g >> 1, channel octet g & 1), chunk 1 = slice 2 in the 1x1x1 form.  1x1x1: K octet g = input channels 4g..4g+3 as
     // [hi x4 | lo x4]; fragment 0 = w_hi against both halves, fragment 1 = w_lo against the hi half.
     if (!L.transposed && L.kh == 1 && L.kw == 1 && L.cin == 16 && L.cout == 16 && !bn && !conv_bias && (L.kd == 3 || L.kd == 1)) {
         const int nfrag = L.kd == 3 ? 2 * parts : parts;
@@ -722,13 +728,19 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
             for (int j = 0; j < 8; ++j) {
                 const int co = lane & 15, gq = lane >> 4;
                 if (L.kd == 3) {
-                    for (int c = 0; c < 2; ++c) {
-                        const int sl = c == 0 ? (gq >> 1) : (gq < 2 ? 2 : -1);
-                        const float val = sl >= 0 ? (float)wval(co, (gq & 1) * 8 + j, Tap{0, 0, 0, sl, 0, 0}) : 0.f;
+                    {
+                        const float val = (float)wval(co, (gq & 1) * 8 + j, Tap{0, 0, 0, gq >> 1, 0, 0});
                         uint16_t hi, lo;
                         host_split(prec, val, hi, lo);
-                        wr[((size_t)c * parts) * 512 + lane * 8 + j] = hi;
-                        if (parts == 2) wr[((size_t)c * parts + 1) * 512 + lane * 8 + j] = lo;
+                        wr[(size_t)lane * 8 + j] = hi;
+                        if (parts == 2) wr[(size_t)512 + lane * 8 + j] = lo;
+                    }
+                    {   // chunk 1 = slice tap 2 against the operand stage B leaves in registers (the 1x1x1 form below)
+                        const float val = (float)wval(co, 4 * gq + (j & 3), Tap{0, 0, 0, 2, 0, 0});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        wr[((size_t)parts) * 512 + lane * 8 + j] = hi;
+                        if (parts == 2 && j < 4) wr[((size_t)parts + 1) * 512 + lane * 8 + j] = lo;
                     }
                 } else {
                     const float val = (float)wval(co, 4 * gq + (j & 3), Tap{0, 0, 0, 0, 0, 0});

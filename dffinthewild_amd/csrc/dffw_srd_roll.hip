@@ -214,6 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 
     int xslot = 0;
     f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v fop = {0u, 0u, 0u, 0u};
 #ifdef DFFW_TRACE_BUILD
     StepTrace trc(a.trace, wave, lane, NWAVES);
 #else
@@ -251,8 +253,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     if (ta_ok[j]) {
                         uint32_t h01, h23, l01, l23;
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                        Fmt<PREC>::split2(relu_lim_bits(acc[0], inside ? 0x7f800000 : 0), relu_lim_bits(acc[1], inside ? 0x7f800000 : 0), h01, l01);
+                        Fmt<PREC>::split2(relu_lim_bits(acc[2], inside ? 0x7f800000 : 0), relu_lim_bits(acc[3], inside ? 0x7f800000 : 0), h23, l23);
                         lds_store8(ta_st[j], h01, h23);
                         if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
                     }
@@ -284,46 +286,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
                     lds_store8(fslot_off + pb_f + (g & 1) * 8, fh01, fh23);
                     if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + (g & 1) * 8, fl01, fl23);
+                    fop = u32x4v{fh01, fh23, fl01, fl23};   // feat[s] of the lane's own 4 channels as [hi x4 | lo x4]: stage C's K octet for the slice behind z
                     vq1 = vq0;   // fp32 feat of this lane's pixel / channels, two steps deep: stage C adds it back
                     vq0 = v;
                 }
             } else {
                 vq1 = vq0;
-                lds_store8(fslot_off + pb_f + (g & 1) * 8, 0u, 0u);   // feat[N] = 0
-                if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + (g & 1) * 8, 0u, 0u);
+                fop = u32x4v{0u, 0u, 0u, 0u};   // feat[N] = 0
             }
             trc.stamp(4);
             // ---- stage C: attention for slice z = s-1 out of feat[z-1], feat[z], feat[z+1] = the slice stage B just wrote (or the zeros behind the
             // last one); wave w = pairs of rows 2w, 2w+1 = the pixels ITS stage B produced: feat never crosses waves, no barrier in between ----
             if (s >= 1 && !(ABL & 1)) {
                 const int z = s - 1;
-                const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
-                // chunk 0: K octet g = (pixel g >> 1 of the pair, slice z-1 + (g & 1)); chunk 1: (pixel g >> 1, slice z+1) for even g
-                const unsigned ad0 = lds0 + ((g & 1) ? sc : sm) + pb_f, ad1 = lds0 + sp + pb_f;
-                short8 fh0, fl0, fh1, fl1;
+                const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB;
+                // chunk 0: K octet g = (pixel g >> 1 of the pair, slice z-1 + (g & 1)) out of the ring; chunk 1: K octet g = the lane's own 4 channels of
+                // feat[z+1] as [hi x4 | lo x4], straight from stage B's registers (filter fragments [w_hi w_hi] and [w_lo 0] as for the 1x1x1 conv: two MFMAs)
+                const unsigned ad0 = lds0 + ((g & 1) ? sc : sm) + pb_f;
+                short8 fh0, fl0;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(fh0) : "v"(ad0));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fh1) : "v"(ad1));
                 if constexpr (PARTS == 2) {
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl0) : "v"(ad0), "n"(FPLANEB));
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl1) : "v"(ad1), "n"(FPLANEB));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1), "+v"(fl0), "+v"(fl1));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fl0));
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0));
                 }
+                const short8 f1op = __builtin_bit_cast(short8, fop);
                 f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (PARTS == 2) {
+                    at = mma<F16>(w3f[1][1], f1op, at);
                     at = mma<F16>(w3f[0][1], fh0, at);
                     at = mma<F16>(w3f[0][0], fl0, at);
-                    at = mma<F16>(w3f[1][1], fh1, at);
-                    at = mma<F16>(w3f[1][0], fl1, at);
                 }
+                at = mma<F16>(w3f[1][0], f1op, at);
                 at = mma<F16>(w3f[0][0], fh0, at);
-                at = mma<F16>(w3f[1][0], fh1, at);
                 // ReLU, split: {hi of the lane's 4 channels | lo of them} is the lane's K octet of the 1x1x1 conv
                 uint32_t ah01, ah23, al01, al23;
                 Fmt<PREC>::split2(relu_bits(at[0]), relu_bits(at[1]), ah01, al01);
                 Fmt<PREC>::split2(relu_bits(at[2]), relu_bits(at[3]), ah23, al23);
-                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
                 const u32x4v bq = {ah01, ah23, al01, al23};
                 const short8 b2op = __builtin_bit_cast(short8, bq);
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -342,10 +342,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     Fmt<PREC>::join2(h23, l23, m[2], m[3]);
                     uint32_t ph01, ph23, pl01, pl23;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[i]), __float_as_uint(m[i]), false, false);
-                        m[i] = fmaxf(m[i], __uint_as_float(lane < 32 ? sw[1] : sw[0]));
-                        m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m[i]), 0x128, 0xF, 0xF, true)));   // row_ror:8
+                    for (int i = 0; i < 4; ++i) {   // the values are sums of two ReLU results: non-negative, so the maxima are taken on the bit patterns (no canonicalising v_max_f32)
+                        uint32_t mu = __float_as_uint(m[i]);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                        mu = max(mu, lane < 32 ? sw[1] : sw[0]);
+                        mu = max(mu, (uint32_t)__builtin_amdgcn_mov_dpp((int)mu, 0x128, 0xF, 0xF, true));   // row_ror:8
+                        m[i] = __uint_as_float(mu);
                     }
                     Fmt<PREC>::split2(m[0], m[1], ph01, pl01);
                     Fmt<PREC>::split2(m[2], m[3], ph23, pl23);
@@ -565,8 +567,8 @@ __global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
                 const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (ta_ok[j]) {
                     uint32_t h01, h23, l01, l23;
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[0], inside ? 0x7f800000 : 0), relu_lim_bits(acc[1], inside ? 0x7f800000 : 0), h01, l01);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[2], inside ? 0x7f800000 : 0), relu_lim_bits(acc[3], inside ? 0x7f800000 : 0), h23, l23);
                     lds_store8(ta_st[j], h01, h23);
                     if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
                 }
@@ -746,8 +748,8 @@ __global__ __launch_bounds__(256) void of_first_kernel(const SrdArgs a) {
                 const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (ta_ok[j]) {
                     uint32_t h01, h23, l01, l23;
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[0], inside ? 0x7f800000 : 0), relu_lim_bits(acc[1], inside ? 0x7f800000 : 0), h01, l01);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[2], inside ? 0x7f800000 : 0), relu_lim_bits(acc[3], inside ? 0x7f800000 : 0), h23, l23);
                     *reinterpret_cast<uint2 *>(smem + ta_st[j]) = make_uint2(h01, h23);
                     if constexpr (PARTS == 2) *reinterpret_cast<uint2 *>(smem + ta_st[j] + TPLANEB) = make_uint2(l01, l23);
                 }
@@ -1023,6 +1025,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 
     int xslot = 0;
     f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v fop = {0u, 0u, 0u, 0u};
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         // a step as in srd_roll_kernel: stage A | barrier | stage B of slice s, then stage C of slice s-1 on the same wave (its own pixels: the feat
@@ -1057,8 +1061,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     if (ta_ok[j]) {
                         uint32_t h01, h23, l01, l23;
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                        Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                        Fmt<PREC>::split2(relu_lim_bits(acc[0], inside ? 0x7f800000 : 0), relu_lim_bits(acc[1], inside ? 0x7f800000 : 0), h01, l01);
+                        Fmt<PREC>::split2(relu_lim_bits(acc[2], inside ? 0x7f800000 : 0), relu_lim_bits(acc[3], inside ? 0x7f800000 : 0), h23, l23);
                         lds_store8(ta_st[j], h01, h23);
                         if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
                     }
@@ -1087,43 +1091,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
                     lds_store8(fslot_off + pb_f + g * 8, fh01, fh23);
                     if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + g * 8, fl01, fl23);
+                    fop = u32x4v{fh01, fh23, fl01, fl23};   // feat[s], channels 4g..4g+3 as [hi x4 | lo x4]: stage C's K octet for the slice behind z
                     vq1 = vq0;
                     vq0 = v;
                 }
             } else {
                 vq1 = vq0;
-                lds_store8(fslot_off + pb_f + g * 8, 0u, 0u);   // feat[N] = 0
-                if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + g * 8, 0u, 0u);
+                fop = u32x4v{0u, 0u, 0u, 0u};   // feat[N] = 0
             }
             // ---- stage C: attention for slice z = s-1 (feat[z+1] = what stage B just wrote, or the zeros behind the last slice) ----------------------------------------------------------------------
             if (s >= 1 && !(ABL & 1)) {
                 const int z = s - 1;
-                const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB, sp = F_OFF + ((z + 1) % 3) * FSLOTB;
-                // chunk 0: K octet g = (slice z-1 + (g >> 1), channel octet g & 1); chunk 1: (slice z+1, octet g & 1) for g < 2
-                const unsigned ad0 = lds0 + ((g >> 1) ? sc : sm) + pb_f + (g & 1) * 16, ad1 = lds0 + sp + pb_f + (g & 1) * 16;
-                short8 fh0, fl0, fh1, fl1;
+                const unsigned sm = F_OFF + ((z + 2) % 3) * FSLOTB, sc = F_OFF + (z % 3) * FSLOTB;
+                // chunk 0: K octet g = (slice z-1 + (g >> 1), channel octet g & 1) out of the ring; chunk 1: K octet g = channels 4g..4g+3 of feat[z+1] as
+                // [hi x4 | lo x4], straight from stage B's registers (fragments [w_hi w_hi] and [w_lo 0]: two MFMAs)
+                const unsigned ad0 = lds0 + ((g >> 1) ? sc : sm) + pb_f + (g & 1) * 16;
+                short8 fh0, fl0;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(fh0) : "v"(ad0));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fh1) : "v"(ad1));
                 if constexpr (PARTS == 2) {
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl0) : "v"(ad0), "n"(FPLANEB));
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl1) : "v"(ad1), "n"(FPLANEB));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1), "+v"(fl0), "+v"(fl1));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fl0));
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fh1));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0));
                 }
+                const short8 f1op = __builtin_bit_cast(short8, fop);
                 f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (PARTS == 2) {
+                    at = mma<F16>(w3f[1][1], f1op, at);
                     at = mma<F16>(w3f[0][1], fh0, at);
                     at = mma<F16>(w3f[0][0], fl0, at);
-                    at = mma<F16>(w3f[1][1], fh1, at);
-                    at = mma<F16>(w3f[1][0], fl1, at);
                 }
+                at = mma<F16>(w3f[1][0], f1op, at);
                 at = mma<F16>(w3f[0][0], fh0, at);
-                at = mma<F16>(w3f[1][0], fh1, at);
                 uint32_t ah01, ah23, al01, al23;
                 Fmt<PREC>::split2(relu_bits(at[0]), relu_bits(at[1]), ah01, al01);
                 Fmt<PREC>::split2(relu_bits(at[2]), relu_bits(at[3]), ah23, al23);
-                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
                 const u32x4v bq = {ah01, ah23, al01, al23};
                 const short8 b2op = __builtin_bit_cast(short8, bq);
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1142,9 +1144,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     Fmt<PREC>::join2(h23, l23, m[2], m[3]);
                     uint32_t ph01, ph23, pl01, pl23;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m[i]), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
-                        m[i] = fmaxf(m[i], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m[i]), 0x128, 0xF, 0xF, true)));   // row_ror:8
+                    for (int i = 0; i < 4; ++i) {   // non-negative values (sums of two ReLU results): maxima on the bit patterns
+                        uint32_t mu = __float_as_uint(m[i]);
+                        mu = max(mu, (uint32_t)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                        mu = max(mu, (uint32_t)__builtin_amdgcn_mov_dpp((int)mu, 0x128, 0xF, 0xF, true));   // row_ror:8
+                        m[i] = __uint_as_float(mu);
                     }
                     Fmt<PREC>::split2(m[0], m[1], ph01, pl01);
                     Fmt<PREC>::split2(m[2], m[3], ph23, pl23);
@@ -1380,8 +1384,8 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
                 const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (ta_ok[j]) {
                     uint32_t h01, h23, l01, l23;
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[0], inside ? 0x7f800000 : 0), relu_lim_bits(acc[1], inside ? 0x7f800000 : 0), h01, l01);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[2], inside ? 0x7f800000 : 0), relu_lim_bits(acc[3], inside ? 0x7f800000 : 0), h23, l23);
                     lds_store8(ta_st[j], h01, h23);
                     if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
                 }
@@ -1840,8 +1844,8 @@ __global__ __launch_bounds__(256) void of_s2_kernel(const SrdArgs a) {
                 const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (ta_ok[j]) {
                     uint32_t h01, h23, l01, l23;
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[0]) : 0.f, inside ? relu_bits(acc[1]) : 0.f, h01, l01);
-                    Fmt<PREC>::split2(inside ? relu_bits(acc[2]) : 0.f, inside ? relu_bits(acc[3]) : 0.f, h23, l23);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[0], inside ? 0x7f800000 : 0), relu_lim_bits(acc[1], inside ? 0x7f800000 : 0), h01, l01);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[2], inside ? 0x7f800000 : 0), relu_lim_bits(acc[3], inside ? 0x7f800000 : 0), h23, l23);
                     *reinterpret_cast<uint2 *>(smem + ta_st[j]) = make_uint2(h01, h23);
                     if constexpr (PARTS == 2) *reinterpret_cast<uint2 *>(smem + ta_st[j] + TPLANEB) = make_uint2(l01, l23);
                 }
