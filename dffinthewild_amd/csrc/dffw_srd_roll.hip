@@ -183,15 +183,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + (g & 1) * 4);
     // one operand tile: 3 chunks (filter rows) x hi/lo, read by inline asm (hipcc degrades every lgkmcnt wait to 0 and adds
     // vmcnt(0) in front of reads of DMA-filled slots while an LDS-DMA is outstanding) and contracted as they arrive
-    auto tile_mma = [&](unsigned base, int rowB, int loB, const short8 (&wf)[3][PARTS], f32x4 acc) {
+    auto tile_mma = [&](unsigned base, auto rowB_c, auto loB_c, const short8 (&wf)[3][PARTS], f32x4 acc) {
+        constexpr int rowB = decltype(rowB_c)::value, loB = decltype(loB_c)::value;   // immediates of the reads: no address arithmetic per chunk
         short8 xh[3], xl[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const unsigned ad = base + k * rowB;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
-            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
-            else xl[k] = xh[k];
-        }
+#define DFFW_SRD_READ(k)                                                                                                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xh[k]) : "v"(base), "n"(k * rowB));                                               \
+    if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(base), "n"(k * rowB + loB));               \
+    else xl[k] = xh[k];
+        DFFW_SRD_READ(0)
+        DFFW_SRD_READ(1)
+        DFFW_SRD_READ(2)
+#undef DFFW_SRD_READ
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (k == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xh[0]), "+v"(xl[0]) : "n"(2 * PARTS));
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 #pragma unroll
                 for (int j = 0; j < TA; ++j) {
                     if (j >= nA) break;
-                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], XX * PIXB, PLANEB, w0, b0);
+                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], std::integral_constant<int, XX * PIXB>{}, std::integral_constant<int, PLANEB>{}, w0, b0);
                     const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
                     const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     if (ta_ok[j]) {
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                 trc.stamp(3);
                 // ---- stage B: feat[s] = relu(conv.2(t) + shift + x) ----------------------------------------------------
                 if constexpr (!(ABL & 4)) {
-                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
+                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, std::integral_constant<int, TXT * PIXB>{}, std::integral_constant<int, TPLANEB>{}, w2, b2);
                     const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
                     u32x2 xh, xl = {0u, 0u};
                     asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
@@ -524,15 +526,17 @@ __global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
     const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + (g & 1) * 4);
     // one operand tile: 3 chunks (filter rows) x hi/lo, read by inline asm (hipcc degrades every lgkmcnt wait to 0 and adds
     // vmcnt(0) in front of reads of DMA-filled slots while an LDS-DMA is outstanding) and contracted as they arrive
-    auto tile_mma = [&](unsigned base, int rowB, int loB, const short8 (&wf)[3][PARTS], f32x4 acc) {
+    auto tile_mma = [&](unsigned base, auto rowB_c, auto loB_c, const short8 (&wf)[3][PARTS], f32x4 acc) {
+        constexpr int rowB = decltype(rowB_c)::value, loB = decltype(loB_c)::value;   // immediates of the reads: no address arithmetic per chunk
         short8 xh[3], xl[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const unsigned ad = base + k * rowB;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
-            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
-            else xl[k] = xh[k];
-        }
+#define DFFW_SRD_READ(k)                                                                                                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xh[k]) : "v"(base), "n"(k * rowB));                                               \
+    if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(base), "n"(k * rowB + loB));               \
+    else xl[k] = xh[k];
+        DFFW_SRD_READ(0)
+        DFFW_SRD_READ(1)
+        DFFW_SRD_READ(2)
+#undef DFFW_SRD_READ
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (k == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xh[0]), "+v"(xl[0]) : "n"(2 * PARTS));
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
 #pragma unroll
             for (int j = 0; j < TA; ++j) {
                 if (j >= nA) break;
-                const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], XX * PIXB, PLANEB, w0, b0);
+                const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], std::integral_constant<int, XX * PIXB>{}, std::integral_constant<int, PLANEB>{}, w0, b0);
                 const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
                 const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (ta_ok[j]) {
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // ---- stage B: out = relu(conv.2(t) + shift + shortcut(x)) -------------------------------------------------------------
             {
-                f32x4 acc = tile_mma(lds0 + T_OFF + pbo, TXT * PIXB, TPLANEB, w2, b2);
+                f32x4 acc = tile_mma(lds0 + T_OFF + pbo, std::integral_constant<int, TXT * PIXB>{}, std::integral_constant<int, TPLANEB>{}, w2, b2);
                 const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_sc;
                 short8 sh, sl;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(sh) : "v"(xp));
@@ -948,13 +952,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     for (int pt = 0; pt < PARTS; ++pt) w1f[pt] = reinterpret_cast<const short8 *>(a.w1f)[pt * 64 + lane];
     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);
     const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
-    auto tile_mma = [&](unsigned base, const int (&tapo)[NCH], int loB, const short8 (&wf)[NCH][PARTS], f32x4 acc) {
+    auto tile_mma = [&](unsigned base, const int (&tapo)[NCH], auto loB_c, const short8 (&wf)[NCH][PARTS], f32x4 acc) {
+        constexpr int loB = decltype(loB_c)::value;   // the lo plane as an immediate of the read
         short8 xh[NCH], xl[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const unsigned ad = base + tapo[k];
             asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
-            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(ad), "n"(loB));
             else xl[k] = xh[k];
         }
 #pragma unroll
@@ -978,16 +983,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 
     // two operand tiles side by side (stage A of the waves that own two): the reads of both run three chunks ahead of the MFMAs and the two
     // accumulator chains alternate, so one tile's LDS latency and MFMA dependency gaps are covered by the other's work
-    auto tile_mma2 = [&](unsigned base0, unsigned base1, const int (&tapo)[NCH], int loB, const short8 (&wf)[NCH][PARTS], f32x4 &acc0, f32x4 &acc1) {
+    auto tile_mma2 = [&](unsigned base0, unsigned base1, const int (&tapo)[NCH], auto loB_c, const short8 (&wf)[NCH][PARTS], f32x4 &acc0, f32x4 &acc1) {
         static_assert(PARTS == 2 || PARTS == 1, "");
         constexpr int NBUF = 3;
         short8 xh[NBUF][2], xl[NBUF][2];
         auto fetch = [&](int k) {
             const unsigned a0 = base0 + tapo[k], a1 = base1 + tapo[k];
             asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k % NBUF][0]) : "v"(a0));
-            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k % NBUF][0]) : "v"(a0 + loB));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k % NBUF][0]) : "v"(a0), "n"(decltype(loB_c)::value));
             asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k % NBUF][1]) : "v"(a1));
-            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k % NBUF][1]) : "v"(a1 + loB));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k % NBUF][1]) : "v"(a1), "n"(decltype(loB_c)::value));
         };
         fetch(0);
         fetch(1);
@@ -1048,9 +1053,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 if (nA == 2) {
                     accA[0] = b0;
                     accA[1] = b0;
-                    tile_mma2(lds0 + X_OFF + xslot * SLOTB + pa[0], lds0 + X_OFF + xslot * SLOTB + pa[1], tapA, PLANEB, w0, accA[0], accA[1]);
+                    tile_mma2(lds0 + X_OFF + xslot * SLOTB + pa[0], lds0 + X_OFF + xslot * SLOTB + pa[1], tapA, std::integral_constant<int, PLANEB>{}, w0, accA[0], accA[1]);
                 } else {
-                    accA[0] = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[0], tapA, PLANEB, w0, b0);
+                    accA[0] = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[0], tapA, std::integral_constant<int, PLANEB>{}, w0, b0);
                     accA[1] = b0;
                 }
 #pragma unroll
@@ -1072,7 +1077,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 // ---- stage B ---------------------------------------------------------------------------------------------------------
                 if constexpr (!(ABL & 4)) {
-                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, tapB, TPLANEB, w2, b2);
+                    const f32x4 acc = tile_mma(lds0 + T_OFF + pbo, tapB, std::integral_constant<int, TPLANEB>{}, w2, b2);
                     const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
                     u32x2 xh, xl = {0u, 0u};
                     asm volatile("ds_read_b64 %0, %1" : "=v"(xh) : "v"(xp));
