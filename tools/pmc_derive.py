@@ -1,7 +1,10 @@
 """Derived per-kernel figures from the two SQ PMC passes of tools/round_measurements.sh (appended to profiles/*_pmc_conv_kernels.txt).
 mfma_pipe = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles) with kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs;
 lds_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles); lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;
-waiting / stalled / issuing = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES; clock = kernel cycles / time."""
+waiting / stalled / issuing = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES; clock = kernel cycles / time.
+valu_issue / salu_issue = SQ_ACTIVE_INST_VALU / SQ_ACTIVE_INST_SCA x 4 cycles over (1024 SIMDs x kernel cycles) -- the share of a SIMD's time its vector
+(incl. the MFMAs' issue slots) / scalar issue port is taken (SQ_ACTIVE_* and SQ_WAVE_CYCLES count in units of 4 cycles: ~1.03 per VALU instruction);
+waves = SQ_WAVE_CYCLES x 4 / (1024 x kernel cycles), the average resident waves per SIMD."""
 import collections, csv, re, sys
 
 
@@ -32,4 +35,5 @@ for k in sorted(dur, key=lambda k: -dur[k])[:16]:
     lds_idx = cb.get("SQ_LDS_IDX_ACTIVE", 0)
     print(f"#   {k:58s} time {dur[k]:7.0f} us  clock {cyc / dur[k] / 1e3:4.2f} GHz  mfma_pipe {ca['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):4.2f}  "
           f"lds_busy {lds_idx / (256 * cyc):4.2f}  lds_conflict {(cb.get('SQ_LDS_BANK_CONFLICT', 0) / lds_idx) if lds_idx else 0:4.2f}  "
-          f"waiting {ca['SQ_WAIT_ANY'] / wc:4.2f}  stalled {ca['SQ_WAIT_INST_ANY'] / wc:4.2f}")
+          f"waiting {ca['SQ_WAIT_ANY'] / wc:4.2f}  stalled {ca['SQ_WAIT_INST_ANY'] / wc:4.2f}  valu_issue {cb.get('SQ_ACTIVE_INST_VALU', 0) * 4 / (1024 * cyc):4.2f}  "
+          f"salu_issue {cb.get('SQ_ACTIVE_INST_SCA', 0) * 4 / (1024 * cyc):4.2f}  waves {wc * 4 / (1024 * cyc):3.1f}")
