@@ -1959,11 +1959,30 @@ __global__ __launch_bounds__(256) void srd_attention_mfma(const uint16_t *__rest
             for (int pt = 0; pt < PARTS; ++pt) f[pt] = *reinterpret_cast<const short8 *>(p + pt * C);
         }
     };
-    short8 f[3][PARTS];
+    // feat[z] at the lane's RESULT channels nt*16 + 4g .. +3 (the residual; the operand octet holds other channels): requested one slice ahead
+    auto load_res = [&](int z, uint2 (&rh)[2], uint2 (&rl)[2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            rh[nt] = make_uint2(0, 0);
+            rl[nt] = make_uint2(0, 0);
+            if (z < N) {
+                const uint16_t *cp = feat + (pix0 + (int64_t)z * hw) * REC + nt * 16 + g * 4;
+                rh[nt] = *reinterpret_cast<const uint2 *>(cp);
+                if constexpr (PARTS == 2) rl[nt] = *reinterpret_cast<const uint2 *>(cp + C);
+            }
+        }
+    };
+    // The slice walk is a chain of dependent loads unless they run ahead: operand records two slices ahead, the residual one slice ahead (the
+    // kernel has only 8 waves of work per SIMD, 3 resident: with each slice's loads consumed in the iteration that issued them it ran at 3.1 TB/s)
+    short8 f[4][PARTS];
+    uint2 rh[2][2], rl[2][2];
     load(-1, f[0]);
     load(0, f[1]);
+    load(1, f[2]);
+    load_res(0, rh[0], rl[0]);
     for (int z = 0; z < N; ++z) {
-        load(z + 1, f[2]);
+        load(z + 2, f[3]);
+        load_res(z + 1, rh[1], rl[1]);
         f32x4 at[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -1996,14 +2015,9 @@ __global__ __launch_bounds__(256) void srd_attention_mfma(const uint16_t *__rest
                 if constexpr (PARTS == 2) o = mma<F16>(w1[c][1][nt], b2[c], o);
                 o = mma<F16>(w1[c][0][nt], b2[c], o);
             }
-            // + feat[z] at the lane's result channels nt*16 + 4g .. +3 (reloaded: the operand octet holds other channels)
-            const uint16_t *cp = feat + pix * REC + nt * 16 + g * 4;
-            const uint2 ch = *reinterpret_cast<const uint2 *>(cp);
-            uint2 cl = make_uint2(0, 0);
-            if constexpr (PARTS == 2) cl = *reinterpret_cast<const uint2 *>(cp + C);
             float c0, c1, c2, c3;
-            Fmt<PREC>::join2(ch.x, cl.x, c0, c1);
-            Fmt<PREC>::join2(ch.y, cl.y, c2, c3);
+            Fmt<PREC>::join2(rh[0][nt].x, rl[0][nt].x, c0, c1);
+            Fmt<PREC>::join2(rh[0][nt].y, rl[0][nt].y, c2, c3);
             uint32_t h01, h23, l01, l23;
             Fmt<PREC>::split2(c0 + relu_bits(o[0]), c1 + relu_bits(o[1]), h01, l01);
             Fmt<PREC>::split2(c2 + relu_bits(o[2]), c3 + relu_bits(o[3]), h23, l23);
@@ -2019,6 +2033,12 @@ __global__ __launch_bounds__(256) void srd_attention_mfma(const uint16_t *__rest
         for (int pt = 0; pt < PARTS; ++pt) {
             f[0][pt] = f[1][pt];
             f[1][pt] = f[2][pt];
+            f[2][pt] = f[3][pt];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            rh[0][nt] = rh[1][nt];
+            rl[0][nt] = rl[1][nt];
         }
     }
 }
