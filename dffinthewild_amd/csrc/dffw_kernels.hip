@@ -1173,30 +1173,21 @@ hipError_t launch_head_tail(int prec, const uint16_t *v, double *partial, const 
 // softplus (beta 1, threshold 20) = v > 20 ? v : log1p(exp(v)) on the hardware transcendentals instead of libm's
 // expf/log1pf (the regression kernels were bound by those two calls):
 //   e = exp(v) = exp2(v*log2e), the product carried in two floats so that the result keeps ~1 ulp for |v| up to 88;
-//   log1p(e)  = series for e < 0.1 (9 terms, truncation < 2e-10), else log(1+e) * e/((1+e)-1) (the classic
-//               correction for the rounding of 1+e) on v_log_f32.
+//   log1p(e)  = log(w) * e / (w - 1) with w = fl(1 + e) (the classic correction for the rounding of 1 + e: exact-rounded it is within 3.3e-7
+//               of log1p over v in [-30, 20]), e itself where w == 1; v_log_f32 and v_rcp_f32, no branch.  (Rounds 1-3 used a 9-term series below
+//               e = 0.1 and an IEEE division above it: ~55 vector instructions per value with both sides of the divergent branch executed, and
+//               the fused head kernel -- 40 values per pixel -- ran with its vector issue port 1.01 busy, profiles/r04_pmc_conv_kernels.txt.)
 // Measured against torch.nn.functional.softplus in tests/test_gpu_ops.py::test_regression_head (2e-6 rel-L2).
 __device__ __forceinline__ float softplus_fast(float v) {
-    if (v > 20.f) return v;
-    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500414e-08f;
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500414e-08f, LN2 = 0.693147182464599609375f;
     const float hi = v * L2E;
     const float lo = __builtin_fmaf(v, L2E, -hi) + v * L2E_LO;
     float e = __builtin_amdgcn_exp2f(hi);
-    e = __builtin_fmaf(e, lo * 0.693147182464599609375f, e);
-    if (e < 0.1f) {
-        float s = -1.f / 9.f;
-        s = __builtin_fmaf(s, e, 1.f / 8.f);
-        s = __builtin_fmaf(s, e, -1.f / 7.f);
-        s = __builtin_fmaf(s, e, 1.f / 6.f);
-        s = __builtin_fmaf(s, e, -1.f / 5.f);
-        s = __builtin_fmaf(s, e, 1.f / 4.f);
-        s = __builtin_fmaf(s, e, -1.f / 3.f);
-        s = __builtin_fmaf(s, e, 1.f / 2.f);
-        s = __builtin_fmaf(-s, e, 1.f);
-        return e * s;
-    }
-    const float w = 1.f + e;
-    return __builtin_amdgcn_logf(w) * 0.693147182464599609375f * (e / (w - 1.f));
+    e = __builtin_fmaf(e, lo * LN2, e);
+    const float w = 1.f + e, d = w - 1.f;
+    const float r = (__builtin_amdgcn_logf(w) * LN2) * (e * __builtin_amdgcn_rcpf(d));
+    const float sp = d == 0.f ? e : r;
+    return v > 20.f ? v : sp;
 }
 
 // Up to four regression heads in ONE launch (blockIdx.y = head): the heads at 1/8, 1/4 and 1/2 resolution are 30-us launches of a
@@ -1314,27 +1305,27 @@ __global__ __launch_bounds__(256) void regress_fused_kernel(const RegressHeads h
                 const float ly = sy - (float)y0, lx = sx - (float)x0;
                 const float hy = 1.f - ly, hx = 1.f - lx;
                 const int o00 = y0 * w + x0, o01 = y0 * w + x1, o10 = y1 * w + x0, o11 = y1 * w + x1;
-                for (int n0 = 0; n0 < N; n0 += 5) {
-                    float s00[5], s01[5], s10[5], s11[5];
+#pragma unroll   // blocks of 5 slices, fully unrolled: f[n0 + k] is a register, not a select chain over the NMAX candidates
+                for (int n0 = 0; n0 < NMAX; n0 += 5) {
+                    if (n0 < N) {
+                        float s00[5], s01[5], s10[5], s11[5];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        const int n = n0 + k < N ? n0 + k : N - 1;
-                        const float *pl = sp + (int64_t)n * h * w;
-                        s00[k] = pl[o00];
-                        s01[k] = pl[o01];
-                        s10[k] = pl[o10];
-                        s11[k] = pl[o11];
-                    }
+                        for (int k = 0; k < 5; ++k) {
+                            const int n = n0 + k < N ? n0 + k : N - 1;
+                            const float *pl = sp + (int64_t)n * h * w;
+                            s00[k] = pl[o00];
+                            s01[k] = pl[o01];
+                            s10[k] = pl[o10];
+                            s11[k] = pl[o11];
+                        }
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        if (n0 + k < N) {
-                            const float v = hy * (hx * s00[k] + lx * s01[k]) + ly * (hx * s10[k] + lx * s11[k]);
-                            const float p = softplus_fast(v) + 1e-6f;
-                            den += p;
-                            float fk = f[0];   // f[n0 + k] with a compile-time register index after unrolling over n0's possible values
-#pragma unroll
-                            for (int q = 1; q < NMAX; ++q) fk = (n0 + k == q) ? f[q] : fk;
-                            num += fk * p;
+                        for (int k = 0; k < 5; ++k) {
+                            if (n0 + k < N) {
+                                const float v = hy * (hx * s00[k] + lx * s01[k]) + ly * (hx * s10[k] + lx * s11[k]);
+                                const float p = softplus_fast(v) + 1e-6f;
+                                den += p;
+                                num += f[n0 + k < NMAX ? n0 + k : NMAX - 1] * p;
+                            }
                         }
                     }
                 }

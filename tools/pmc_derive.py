@@ -24,7 +24,7 @@ def load(path):
 a, dur = load(sys.argv[1])
 b, _ = load(sys.argv[2])
 print("\n# derived (batch 32; see tools/pmc_derive.py for the formulas)")
-for k in sorted(dur, key=lambda k: -dur[k])[:16]:
+for k in sorted(dur, key=lambda k: -dur[k])[:40]:
     if "dffw::" not in k:
         continue
     ca, cb = a[k], b[k]
