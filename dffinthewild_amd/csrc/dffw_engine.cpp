@@ -1157,7 +1157,7 @@ static bool getenv_flag(const char *name) {
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
+    X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(NO_ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
     X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
 enum SwitchId {
 #define X_ID(n) SW_##n,
@@ -1496,7 +1496,7 @@ struct Run {
         // rolling window with whole pixel records
         if (pc.wroll_s2 && !L.transposed && L.sh == 2 && (in0.C == 16 || in0.C == 32) && !o.in1 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre &&
             !o.cls && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_S2) && !(in0.C == 32 && sw.on(SW_NO_ROLL_S2K)) &&
-            (L.cout <= 32 || sw.on(SW_ROLL_S2_WIDE))) {   // 32 -> 64 as two launches measures level with conv_tile (r02): opt-in
+            (L.cout <= 32 || !sw.on(SW_NO_ROLL_S2_WIDE))) {   // 32 -> 64 as two launches: level with conv_tile in r02, 4-7 % faster since the r04 row-pitch fix of conv_roll_s2
             const int khn = in0.C / 16;
             const int ntk = (khn == 2 || L.cout >= 32) ? 2 : 1;     // output tiles per launch
             const int nlaunch = (L.cout / 16 + ntk - 1) / ntk;

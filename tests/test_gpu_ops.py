@@ -89,8 +89,6 @@ def test_conv_roll_strided_16_channels(eng, cin, cout, B, N, H, W, relu, wgs, pr
     contraction split between wave pairs (`dres3.conv3`: 32 -> 32; `dres2.conv1`, SPP `conv1`: 32 -> 64 as two launches over the output
     channel halves).  Slice counts 1, 2, 3, 10, non-square maps, one column per workgroup and long column streams, with and without
     the ReLU epilogue, three arithmetics; against F.conv3d and against conv_tile (DFFW_NO_ROLL_S2) on the same input."""
-    if cout == 64:
-        monkeypatch.setenv("DFFW_ROLL_S2_WIDE", "1")    # two launches over the output channel halves: off by default (no faster than conv_tile)
     x = rnd(B, cin, N, H, W, seed=51)
     w = rnd(cout, cin, 3, 3, 3, seed=52, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
     bn = bn_params(cout, 53)

@@ -19,14 +19,18 @@ for r in range(reps):
         rows = list(csv.reader(open(path), delimiter="\t"))[1:]
         os.unlink(path)
         tot[name].append(sum(float(row[4]) for row in rows))
-        for row in rows:
+        per = {}
+        for row in rows:   # a layer that runs as several launches ("... (lower output channels)") counts as their sum
             if any(k in row[1] for k in keys):
-                vals[name].setdefault(row[1], []).append(float(row[4]))
+                base = row[1].split(" (")[0]
+                per[base] = per.get(base, 0.0) + float(row[4])
+        for base, v in per.items():
+            vals[name].setdefault(base, []).append(v)
 def q(v, p):
     v = sorted(v)
     return v[min(len(v) - 1, int(p * len(v)))]
 print("layer".ljust(44) + "".join(f"{n + ' med':>12}{'min':>8}{'q25':>8}{'q75':>8}" for n, _ in variants))
 layers = list(vals[variants[0][0]].keys())
 for l in layers:
-    print(l[:43].ljust(44) + "".join(f"{statistics.median(vals[n][l]):12.4f}{min(vals[n][l]):8.4f}{q(vals[n][l], .25):8.4f}{q(vals[n][l], .75):8.4f}" for n, _ in variants))
+    print(l[:43].ljust(44) + "".join((f"{statistics.median(vals[n][l]):12.4f}{min(vals[n][l]):8.4f}{q(vals[n][l], .25):8.4f}{q(vals[n][l], .75):8.4f}" if l in vals[n] else " " * 36) for n, _ in variants))
 print("TOTAL (all layers)".ljust(44) + "".join(f"{statistics.median(tot[n]):12.3f}{min(tot[n]):8.3f}{q(tot[n], .25):8.3f}{q(tot[n], .75):8.3f}" for n, _ in variants))
