@@ -634,12 +634,12 @@ hipError_t launch_conv_rollx_pair(const ConvArgs &a, const RollArgs &t, hipStrea
     const int want = t.wgs > 0 ? t.wgs : 512;
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(rollx::NW * 64);
-    const char *az = getenv("DFFW_ROLLX_ABL");   // development: timing ablations (results are wrong with any bit set)
-    const int abl = az ? atoi(az) : 0;
     if (a.relu != 1) hipLaunchKernelGGL((conv_rollx_pair<false>), grid, block, 0, s, a, t);
-    else if (abl == 3) hipLaunchKernelGGL((conv_rollx_pair<true, 3>), grid, block, 0, s, a, t);
-    else if (abl == 12) hipLaunchKernelGGL((conv_rollx_pair<true, 12>), grid, block, 0, s, a, t);
+#ifdef DFFW_ABL_BUILD   // development (make ABL=1): timing ablations (DFFW_ROLLX_ABL; results are wrong with any bit set), non-temporal stores (DFFW_ROLLX_NTS)
+    else if (getenv("DFFW_ROLLX_ABL") && atoi(getenv("DFFW_ROLLX_ABL")) == 3) hipLaunchKernelGGL((conv_rollx_pair<true, 3>), grid, block, 0, s, a, t);
+    else if (getenv("DFFW_ROLLX_ABL") && atoi(getenv("DFFW_ROLLX_ABL")) == 12) hipLaunchKernelGGL((conv_rollx_pair<true, 12>), grid, block, 0, s, a, t);
     else if (getenv("DFFW_ROLLX_NTS")) hipLaunchKernelGGL((conv_rollx_pair<true, 0, true>), grid, block, 0, s, a, t);
+#endif
     else hipLaunchKernelGGL((conv_rollx_pair<true>), grid, block, 0, s, a, t);
     return hipGetLastError();
 }

@@ -2075,22 +2075,29 @@ hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s) {
     const int want = a.wgs > 0 ? a.wgs : 512;   // two resident workgroups per CU
     const int per_xcd = (a.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
-    const char *az = getenv("DFFW_SRD_ABL");   // development: timing ablations (wrong results with any bit set)
+#ifdef DFFW_ABL_BUILD   // development (make ABL=1): timing ablations, selected with DFFW_SRD_ABL (wrong results with any bit set)
+    const char *az = getenv("DFFW_SRD_ABL");
     const int abl = az ? atoi(az) : 0;
+#define DFFW_SRD16_ABL_CASES                                                                                      \
+    case 1: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 1>), grid, block, 0, s, a); break;              \
+    case 2: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 2>), grid, block, 0, s, a); break;              \
+    case 4: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 4>), grid, block, 0, s, a); break;              \
+    case 7: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 7>), grid, block, 0, s, a); break;              \
+    case 8: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 8>), grid, block, 0, s, a); break;              \
+    case 16: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 16>), grid, block, 0, s, a); break;            \
+    case 32: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 32>), grid, block, 0, s, a); break;            \
+    case 40: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 40>), grid, block, 0, s, a); break;            \
+    case 23: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 23>), grid, block, 0, s, a); break;            \
+    case 6: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 6>), grid, block, 0, s, a); break;
+#else
+    const int abl = 0;
+#define DFFW_SRD16_ABL_CASES
+#endif
 #define DFFW_SRD16_LAUNCH(P)                                                                \
     do {                                                                                    \
         if (a.pooled && P == P_BF16X3 && abl) {                                             \
             switch (abl) {                                                                  \
-                case 1: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 1>), grid, block, 0, s, a); break;   \
-                case 2: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 2>), grid, block, 0, s, a); break;   \
-                case 4: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 4>), grid, block, 0, s, a); break;   \
-                case 7: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 7>), grid, block, 0, s, a); break;   \
-                case 8: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 8>), grid, block, 0, s, a); break;   \
-                case 16: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 16>), grid, block, 0, s, a); break; \
-                case 32: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 32>), grid, block, 0, s, a); break; \
-                case 40: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 40>), grid, block, 0, s, a); break; \
-                case 23: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 23>), grid, block, 0, s, a); break; \
-                case 6: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true, 6>), grid, block, 0, s, a); break;   \
+                DFFW_SRD16_ABL_CASES                                                        \
                 default: hipLaunchKernelGGL((srd_roll16_kernel<P_BF16X3, true>), grid, block, 0, s, a);            \
             }                                                                               \
         } else if (a.pooled) hipLaunchKernelGGL((srd_roll16_kernel<P, true>), grid, block, 0, s, a);  \
@@ -2103,6 +2110,7 @@ hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_SRD16_LAUNCH
+#undef DFFW_SRD16_ABL_CASES
     return hipGetLastError();
 }
 
@@ -2151,22 +2159,30 @@ hipError_t launch_srd_roll(int prec, const SrdArgs &a, hipStream_t s) {
     const int want = a.wgs > 0 ? a.wgs : 768;   // three resident workgroups per CU
     const int per_xcd = (a.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
-    const char *az = getenv("DFFW_SRD_ABL");   // development: timing ablations (wrong results with any bit set)
+#ifdef DFFW_ABL_BUILD   // development (make ABL=1): timing ablations, selected with DFFW_SRD_ABL (wrong results with any bit set)
+    const char *az = getenv("DFFW_SRD_ABL");
     const int abl = az ? atoi(az) : 0;
+#define DFFW_SRD_ABL_CASES \
+    case 1: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 1>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 2: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 2>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 4: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 4>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 6: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 6>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 7: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 7>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 8: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 8>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 16: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 16>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 32: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 32>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 40: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 40>), grid, block, 0, s, a, a.w3, a.w1); break; \
+    case 23: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 23>), grid, block, 0, s, a, a.w3, a.w1); break; \
+
+#else
+    const int abl = 0;
+#define DFFW_SRD_ABL_CASES
+#endif
 #define DFFW_SRD_LAUNCH(P)                                                                    \
     do {                                                                                      \
         if (a.pooled && P == P_BF16X3 && abl) {                                               \
             switch (abl) {                                                                    \
-                case 1: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 1>), grid, block, 0, s, a, a.w3, a.w1); break;   \
-                case 2: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 2>), grid, block, 0, s, a, a.w3, a.w1); break;   \
-                case 4: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 4>), grid, block, 0, s, a, a.w3, a.w1); break;   \
-                case 6: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 6>), grid, block, 0, s, a, a.w3, a.w1); break;   \
-                case 7: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 7>), grid, block, 0, s, a, a.w3, a.w1); break;   \
-                case 8: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 8>), grid, block, 0, s, a, a.w3, a.w1); break;   \
-                case 16: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 16>), grid, block, 0, s, a, a.w3, a.w1); break; \
-                case 32: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 32>), grid, block, 0, s, a, a.w3, a.w1); break; \
-                case 40: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 40>), grid, block, 0, s, a, a.w3, a.w1); break; \
-                case 23: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true, 23>), grid, block, 0, s, a, a.w3, a.w1); break; \
+                DFFW_SRD_ABL_CASES                                                            \
                 default: hipLaunchKernelGGL((srd_roll_kernel<P_BF16X3, true>), grid, block, 0, s, a, a.w3, a.w1);            \
             }                                                                                 \
         } else if (a.pooled) hipLaunchKernelGGL((srd_roll_kernel<P, true>), grid, block, 0, s, a, a.w3, a.w1);   \
@@ -2179,6 +2195,7 @@ hipError_t launch_srd_roll(int prec, const SrdArgs &a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 #undef DFFW_SRD_LAUNCH
+#undef DFFW_SRD_ABL_CASES
     return hipGetLastError();
 }
 
