@@ -1339,14 +1339,14 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);
     const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
     // contraction of one operand tile: chunk k reads at base + tapo[k]; inline-asm LDS reads with counted waits (see srd_roll)
-    auto tile_mma5 = [&](unsigned base, const int *tapo, int loB, const short8 (*wf)[PARTS], f32x4 acc, auto nctag) {
-        constexpr int NC = decltype(nctag)::value;
+    auto tile_mma5 = [&](unsigned base, const int *tapo, auto loB_c, const short8 (*wf)[PARTS], f32x4 acc, auto nctag) {
+        constexpr int NC = decltype(nctag)::value, loB = decltype(loB_c)::value;   // the lo plane as an immediate of the read
         short8 xh[NC], xl[NC];
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const unsigned ad = base + tapo[k];
             asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
-            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(xl[k]) : "v"(ad + loB));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(ad), "n"(loB));
             else xl[k] = xh[k];
         }
 #pragma unroll
@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
             // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image (conv.2's padding) ------------
 #pragma unroll
             for (int j = 0; j < TA; ++j) {
-                const f32x4 acc = tile_mma5(xs + pa[j], tapA, PLANEB, w0, b0, std::integral_constant<int, NCHA>{});
+                const f32x4 acc = tile_mma5(xs + pa[j], tapA, std::integral_constant<int, PLANEB>{}, w0, b0, std::integral_constant<int, NCHA>{});
                 const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
                 const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (ta_ok[j]) {
@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
             f32x4 sum_t = {0.f, 0.f, 0.f, 0.f}, sum_c = sum_t;   // SUMS only
 #pragma unroll
             for (int j = 0; j < TB; ++j) {
-                f32x4 acc = tile_mma5(lds0 + T_OFF + pbo[j], tapB, TPLANEB, w2, b2, std::integral_constant<int, NCHB>{});
+                f32x4 acc = tile_mma5(lds0 + T_OFF + pbo[j], tapB, std::integral_constant<int, TPLANEB>{}, w2, b2, std::integral_constant<int, NCHB>{});
                 {   // the shortcut chunk: centre pixel of x, its channel octets as K octets (weights of absent octets are zeros)
                     short8 sh, sl;
                     asm volatile("ds_read_b128 %0, %1" : "=v"(sh) : "v"(xs + pbx[j]));
