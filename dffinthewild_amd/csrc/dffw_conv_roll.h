@@ -34,6 +34,17 @@ void conv_rollx_pair_kernel_name(const ConvArgs &a, char *buf, int n);
 bool rollx_k2_ok(int prec, const ConvArgs &a);
 hipError_t launch_conv_rollx_k2(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_rollx_k2_kernel_name(const ConvArgs &a, char *buf, int n);
+// conv_rollk (dffw_conv_rollk.hip, round 5): 3x3x3 stride 1 over 32 / 64 input channels, 32 output channels per launch (RollArgs::pair = first
+// 16-channel output tile of the launch), the contraction split over the workgroup's waves: wave w = (16-channel group w >> 1, tap half w & 1)
+// holds ROLLK_CHUNKS chunks of (2 taps x 16 channels) for two output tiles.  Filter packed as [32-channel output pair][wave][chunk][output
+// tile][part][64 lanes][8]; columns of 8 x 8 output pixels
+#define DFFW_ROLLK_TY 8
+#define DFFW_ROLLK_TX 8
+constexpr int ROLLK_CHUNKS = 7;
+void rollk_tile(int *ty, int *tx);
+int rollk_waves(int prec, const ConvArgs &a);   // waves per workgroup (= input channels / 8) when the kernel covers the launch, else 0
+hipError_t launch_conv_rollk(const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_rollk_kernel_name(const ConvArgs &a, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
 // transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one

@@ -310,6 +310,7 @@ struct PackedConv {
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_k2 = nullptr;  // device: a 3x3x3 stride-1 32 -> 16 filter in conv_rollx_k2's order: [input half][conv_roll's 15 chunks]
+    uint16_t *wrollk = nullptr;    // device: a 3x3x3 stride-1 32 / 64 -> 32 / 64 filter in conv_rollk's order: [32-channel output pair][wave][7 chunks][output tile]
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
     uint16_t *wroll_s2 = nullptr;  // device: a 3x3x3 stride-(1,2,2) 16 -> 16 / 32 filter in conv_roll_s2's order (15 chunks per 16-channel output tile)
@@ -348,6 +349,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll_t = nullptr;
     if (pc.wroll_k2) (void)hipFree(pc.wroll_k2);
     pc.wroll_k2 = nullptr;
+    if (pc.wrollk) (void)hipFree(pc.wrollk);
+    pc.wrollk = nullptr;
     if (pc.wroll8) (void)hipFree(pc.wroll8);
     pc.wroll8 = nullptr;
     if (pc.wroll_t32) (void)hipFree(pc.wroll_t32);
@@ -677,6 +680,35 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                     }
         HIPCHK(hipMalloc((void **)&pc.wroll_k2, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll_k2, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- conv_rollk (dffw_conv_rollk.hip): 3x3x3 stride 1, 32 / 64 -> 32 / 64 channels, the contraction split over the workgroup's waves: wave w =
+    // (16-channel group w >> 1, tap half w & 1); tap slot s of a half = filter tap 14 * (w & 1) + s in [dz][ky][kx] order (tap 27: zero weights);
+    // chunk c = slots 2c, 2c + 1; K octet g = (slot 2c + (g >> 1), channel octet g & 1 of the group)
+    if (geo == G3S1 && (cin_pad == 32 || cin_pad == 64) && L.cin == cin_pad && L.cout % 32 == 0 && L.cout <= 64 && !stem && !shortcut_w && prec == P_BF16X3) {
+        const int nw = cin_pad / 8, npair = L.cout / 32;
+        std::vector<uint16_t> wr((size_t)npair * nw * ROLLK_CHUNKS * 2 * parts * 512, 0);
+        for (int op = 0; op < npair; ++op)
+            for (int wv = 0; wv < nw; ++wv)
+                for (int c = 0; c < ROLLK_CHUNKS; ++c)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int row = lane & 15, gq = lane >> 4;
+                                const int tap = (wv & 1) * 2 * ROLLK_CHUNKS + 2 * c + (gq >> 1);
+                                const int cin = (wv >> 1) * 16 + (gq & 1) * 8 + j;
+                                float val = 0.f;
+                                if (tap < 27) {
+                                    const int dz = tap / 9, ky = (tap % 9) / 3, kx = tap % 3;
+                                    val = (float)wval((op * 2 + nt) * 16 + row, cin, Tap{dz - 1, ky - 1, kx - 1, dz, ky, kx});
+                                }
+                                uint16_t hi, lo;
+                                host_split(prec, val, hi, lo);
+                                const size_t base = (((((size_t)op * nw + wv) * ROLLK_CHUNKS + c) * 2 + nt) * parts) * 512 + (size_t)lane * 8 + j;
+                                wr[base] = hi;
+                                wr[base + 512] = lo;
+                            }
+        HIPCHK(hipMalloc((void **)&pc.wrollk, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wrollk, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- srd_roll stage C: the attention convs of the 8-channel SRD block (DEN.py:322-323) in pixel-pair form.  Result row
     // m = (pixel m >> 3 of the pair, channel m & 7).  3x1x1: chunk 0 K octet g = (pixel g >> 1, slice g & 1), chunk 1 = slice 2 in the
@@ -1158,7 +1190,7 @@ static bool getenv_flag(const char *name) {
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
     X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(NO_ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_ROLLK) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1205,7 +1237,8 @@ struct Switches {
 };
 
 inline int Switches::path_bits() const {
-    return (f[SW_NO_LEAN_TILE] ? DFFW_ARGS_NO_LEAN_TILE : 0) | (f[SW_NO_LEAN_ROLL] ? DFFW_ARGS_NO_LEAN_ROLL : 0) | (f[SW_NO_ROLLX] ? DFFW_ARGS_NO_ROLLX : 0);
+    return (f[SW_NO_LEAN_TILE] ? DFFW_ARGS_NO_LEAN_TILE : 0) | (f[SW_NO_LEAN_ROLL] ? DFFW_ARGS_NO_LEAN_ROLL : 0) | (f[SW_NO_ROLLX] ? DFFW_ARGS_NO_ROLLX : 0) |
+           (f[SW_NO_ROLLK] ? DFFW_ARGS_NO_ROLLK : 0);
 }
 
 struct ConvOpt {
@@ -1251,7 +1284,11 @@ struct Run {
     const Switches sw;   // the DFFW_* switches as they were when this forward started
 
     Run(dffw_engine *e_, hipStream_t s_, bool dry_, char *ws_, int64_t cap)
-        : e(e_), s(s_), arena(cap), dry(dry_), ws(ws_), main_s(s_), sw(Switches::read()) {}
+        : e(e_), s(s_), arena(cap), dry(dry_), ws(ws_), main_s(s_), sw(Switches::read()) {
+        // DFFW_DEBUG_FLAGS bit 0 ("no footprint fill") is withdrawn: kernels then contract uninitialised LDS and the run ended in an abort of the
+        // whole process (profiles/r04_ablation_conv_tile_phases.txt) -- an error code instead; bits 1 (no MFMA loop) and 2 (no stores) remain
+        if (sw.debug_flags & 1) err = fail(DFFW_EINVAL, "DFFW_DEBUG_FLAGS bit 0 (skip the footprint fill) is not supported; use 2 (no MFMA loop), 4 (no stores) or 6");
+    }
 
     bool ok() const { return err == DFFW_OK; }
 
@@ -1449,7 +1486,7 @@ struct Run {
         a.relu = o.relu;
         if (!dry && e->ensure_zero_page() != DFFW_OK) { err = DFFW_EHIP; return out; }
         a.zero = e->zero_page;
-        a.dbg = (sw.debug_flags & 7) | sw.path_bits();   // ablation switches (1 no fill, 2 no MFMA loop, 4 no stores) + the launchers' path switches
+        a.dbg = (sw.debug_flags & 6) | sw.path_bits();   // ablation switches (2 no MFMA loop, 4 no stores) + the launchers' path switches
         if (o.raw) a.dbg |= DFFW_ARGS_RAW;   // fs32 then points to the RawStack descriptor in device memory
         if (o.sums) {
             if (!sums_conv_ok(name, in0.B, in0.N, in0.H, in0.W) || o.relu != 1 || o.res0 || o.res1 || o.cls || o.out_pre || o.in1) {
@@ -1465,7 +1502,7 @@ struct Run {
             if (dry) return out;
             a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
             a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
-            a.dbg &= 6;
+            a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK);   // (the ablation bits these kernels know + the launchers' path switches)
             for (int py = 0; py < 2; ++py) {
                 int rty, rtx;
                 roll_t32_tile(py, &rty, &rtx);
@@ -1507,7 +1544,7 @@ struct Run {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
-                a.dbg &= 6;
+                a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK);   // (the ablation bits these kernels know + the launchers' path switches)
                 for (int li = 0; li < nlaunch; ++li) {
                     RollArgs t;
                     memset(&t, 0, sizeof t);
@@ -1543,7 +1580,7 @@ struct Run {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
-                a.dbg &= 6;
+                a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK);   // (the ablation bits these kernels know + the launchers' path switches)
                 RollArgs t;
                 memset(&t, 0, sizeof t);
                 t.wroll = pc.wroll8;
@@ -1608,7 +1645,10 @@ struct Run {
         if (stem_pair) a.bias = pc.bias_pair;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
         // grids at most 8 x 8 (the 1/32-resolution pyramid layers at 256 x 256) with enough samples to fill the chip: the 5 x 8 x 8 block
-        const bool narrow = !stem_pair && pc.tile_narrow.cfg && gW <= 8 && gH <= 8 && !sw.on(SW_NO_NARROW) &&
+        // (its packs of layers with more than 4 output tiles split the output channels over grid.y: not with a fused classifier, whose partial
+        // dot spans all of a pixel's channels, nor under DFFW_NO_SPLIT)
+        const bool narrow_splits = pc.tile_narrow.cfg && pc.nt > pc.tile_narrow.cfg->nt;
+        const bool narrow = !stem_pair && pc.tile_narrow.cfg && gW <= 8 && gH <= 8 && !sw.on(SW_NO_NARROW) && !(narrow_splits && (o.cls || sw.on(SW_NO_SPLIT))) &&
                             (int64_t)in0.B * (((L.transposed ? in0.N : No) + 4) / 5) * pc.nt >= 256;
         const TilePack &tp = stem_pair ? pc.tile_pair : (narrow ? pc.tile_narrow : pc.tile);
         // 32 -> 16 channels on whole 8 x 16 columns: the pipelined rolling window with the contraction split over the two input halves
@@ -1642,6 +1682,44 @@ struct Run {
                     prof_end();
                     return out;
                 }
+            }
+        }
+        // 32 / 64 -> 32 / 64 channels on whole 8 x 8 columns: the K-split rolling window (one launch per 32 output channels)
+        if (pc.wrollk && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLLK)) {
+            int kty, ktx;
+            rollk_tile(&kty, &ktx);
+            const int cols = (Ho / kty) * (Wo / ktx);
+            ConvArgs ak = a;
+            ak.Ng = No; ak.Hg = Ho; ak.Wg = Wo;
+            ak.M = (int64_t)ak.B * No * Ho * Wo;
+            if (Ho % kty == 0 && Wo % ktx == 0 && (int64_t)in0.B * cols >= sw.roll_min_units && rollk_waves(e->prec, ak) == cin_pad / 8) {
+                if (dry) return out;
+                const int npair = L.cout / 32;
+                for (int op = 0; op < npair; ++op) {
+                    RollArgs t;
+                    memset(&t, 0, sizeof t);
+                    t.wroll = pc.wrollk + (size_t)op * (cin_pad / 8) * ROLLK_CHUNKS * 2 * prec_parts(e->prec) * 512;
+                    t.tiles_y = Ho / kty;
+                    t.tiles_x = Wo / ktx;
+                    t.zsplit = ((int64_t)in0.B * cols < 512 && No >= 8) ? 2 : 1;
+                    if (sw.roll_zsplit >= 1 && sw.roll_zsplit <= No) t.zsplit = sw.roll_zsplit;
+                    t.total_tiles = in0.B * t.zsplit * cols;
+                    t.wgs = sw.roll_wgs;
+                    t.pair = op * 2;     // first 16-channel output tile of this launch
+                    char kn[96];
+                    conv_rollk_kernel_name(ak, kn, sizeof kn);
+                    g_last_kernel = kn;
+                    if (e->profiling) {
+                        const double opx = (double)out.B * No * Ho * Wo;
+                        const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout / npair * elem_bytes() * (1 + (o.res0 ? 1 : 0)) +
+                                             27.0 * L.cin * L.cout / npair * elem_bytes();
+                        prof_begin(kn, npair > 1 ? name + (op ? " (upper output channels)" : " (lower output channels)") : name,
+                                   2.0 * opx * 27.0 * L.cin * L.cout / npair, bytes);
+                    }
+                    check(launch_conv_rollk(ak, t, s), name.c_str());
+                    prof_end();
+                }
+                return out;
             }
         }
         // rolling-window kernel: 16-channel 3x3x3 stride-1 layers whose grid is whole columns and fills the chip
@@ -1764,7 +1842,8 @@ struct Run {
                 return out;
             }
             // the pixel-pair stem on whole tiles from the fp32 stack: the persistent pipelined kernel (dffw_stem.hip)
-            const bool stem_pipe_run = stem_pair && !sw.on(SW_NO_STEM_PIPE) && stem_pipe_ok(e->prec, cfg, a, t);
+            const bool tracing = sw.trace_layer && sw.trace_out && name == sw.trace_layer;   // stem_pipe has no tile timeline: a traced stem runs on conv_tile
+            const bool stem_pipe_run = stem_pair && !sw.on(SW_NO_STEM_PIPE) && !tracing && stem_pipe_ok(e->prec, cfg, a, t);
             auto kernel_name = [&](char *kn, int n) {
                 if (stem_pipe_run) return stem_pipe_kernel_name(a, kn, n);
                 conv_tile_kernel_name(e->prec, cfg, t.ksplit > 1 || (a.dbg & (DFFW_ARGS_RAW | DFFW_ARGS_SUMS)), tile_lean(e->prec, cfg, a, t), kn, n);

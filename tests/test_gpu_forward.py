@@ -13,8 +13,13 @@ from oracle import cpu_ref
 
 pytestmark = pytest.mark.gpu
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "den_*.npz")))
-OUT_TOL = {"bf16x3": 1e-3}          # the north-star gate; measured ~1e-5
+OUT_TOL = {"bf16x3": 1e-3}          # the north-star gate (BASELINE.json); measured 1e-5 ... 5e-5
 TAP_TOL = {"bf16x3": 2e-4}
+# drift guards: the north-star gate is 20-100x looser than what the split-bf16 path delivers, so a kernel change that costs an
+# order of magnitude of accuracy would pass it.  These sit ~4x above the measured errors: pred3 of every reference golden, and the three feature
+# volumes V1 / V2 / V3 (measured <= 1.5e-5).
+DRIFT_OUT = 2e-4
+DRIFT_TAP = {"V1": 5e-5, "V2": 5e-5, "V3": 5e-5}
 
 
 def case(path):
@@ -55,6 +60,8 @@ def test_forward_matches_reference_goldens(lib_built, path):
         if name in g.files:
             err = cpu_ref.rel_l2(o.cpu(), g[name])
             assert err <= OUT_TOL["bf16x3"], (name, err)
+            if name == "pred3":
+                assert err <= DRIFT_OUT, ("drift guard", name, err)
 
 
 def test_intermediate_volumes_match_goldens(lib_built):
@@ -67,6 +74,50 @@ def test_intermediate_volumes_match_goldens(lib_built):
     for nm in names:
         err = cpu_ref.rel_l2(taps[nm].cpu(), g["tap_" + nm])
         assert err <= TAP_TOL["bf16x3"], (nm, err)
+        if nm in DRIFT_TAP:
+            assert err <= DRIFT_TAP[nm], ("drift guard", nm, err)
+
+
+def test_debug_flag_without_fill_is_an_error_not_an_abort(lib_built, monkeypatch):
+    """DFFW_DEBUG_FLAGS bit 0 (skip the footprint fill) used to end in an abort of the process (profiles/r04_ablation_conv_tile_phases.txt);
+    it now comes back as an error code through the C ABI -> RuntimeError / ValueError in the binding, and the engine works afterwards."""
+    path = [p for p in GOLDEN if "tiny_taps" in p][0]
+    g, meta, FS, fd, sd = case(path)
+    model = model_for(sd, (meta["wseed"], meta["profile"]))
+    for flags in ("1", "3"):
+        monkeypatch.setenv("DFFW_DEBUG_FLAGS", flags)
+        with pytest.raises((RuntimeError, ValueError)):
+            with torch.no_grad():
+                model(FS.cuda(), fd.cuda())
+    monkeypatch.delenv("DFFW_DEBUG_FLAGS")
+    with torch.no_grad():
+        outs = model(FS.cuda(), fd.cuda())
+    assert cpu_ref.rel_l2(outs[3].cpu(), g["pred3"]) <= DRIFT_OUT
+
+
+@pytest.mark.parametrize("which", ["tiny_taps", "batch2_bcast", "he_n10_64"])
+def test_streaming_kernels_at_golden_sizes(lib_built, which, monkeypatch):
+    """The persistent rolling-window kernels only take a layer from 192 columns up, which the small goldens never reach.  With
+    DFFW_ROLL_MIN_UNITS=1 every layer that has one runs on it at the goldens' sizes -- one or two columns per sample, dres2.conv0's virtual
+    concat through conv_rollk's two-source fill, 64-output layers as two launches -- and must still give the reference's answer (and, on
+    the case that stores them, its intermediate volumes)."""
+    path = [p for p in GOLDEN if which in p][0]
+    g, meta, FS, fd, sd = case(path)
+    model = model_for(sd, (meta["wseed"], meta["profile"]))
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    names = [k[4:] for k in g.files if k.startswith("tap_")]
+    taps = {}
+    with torch.no_grad():
+        if names:
+            outs, taps = model.forward_with_taps(FS.cuda(), fd.cuda(), names)
+        else:
+            outs = model(FS.cuda(), fd.cuda())
+    torch.cuda.synchronize()
+    for name, o in zip(("mid_out", "pred1", "pred2", "pred3"), outs):
+        if name in g.files:
+            assert cpu_ref.rel_l2(o.cpu(), g[name]) <= OUT_TOL["bf16x3"], (name, cpu_ref.rel_l2(o.cpu(), g[name]))
+    for nm in names:
+        assert cpu_ref.rel_l2(taps[nm].cpu(), g["tap_" + nm]) <= TAP_TOL["bf16x3"], (nm, cpu_ref.rel_l2(taps[nm].cpu(), g["tap_" + nm]))
 
 
 @pytest.mark.parametrize("prec,tol", [("fp16", 2e-2), ("bf16", 1e-1)])
@@ -283,7 +334,7 @@ def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monk
 
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK", "DFFW_NO_SMALL", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
                                  "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR",
-                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_REGRESS_MERGE", "DFFW_NO_ROLLX", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE"])
+                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_REGRESS_MERGE", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback

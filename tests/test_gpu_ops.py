@@ -222,6 +222,41 @@ def test_conv_rollx_k2(eng, N, H, W, zsplit, wgs, relu, monkeypatch):
     assert rel(got, alt) <= 2e-5, rel(got, alt)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64)])
+@pytest.mark.parametrize("N,H,W,zsplit,wgs,relu,residual", [(10, 64, 64, 1, 0, 1, False), (1, 32, 64, 1, 8, 1, True), (7, 64, 32, 3, 24, 0, True), (2, 40, 24, 2, 16, 1, False),
+                                                            (3, 64, 64, 3, 8, 0, False), (5, 8, 8, 1, 0, 1, True)])
+def test_conv_rollk(eng, cin, cout, N, H, W, zsplit, wgs, relu, residual, monkeypatch):
+    """conv_rollk (dffw_conv_rollk.hip): 3x3x3 stride 1, 32 / 64 -> 32 / 64 channels (`dres2.conv0`, `dres0.*`, `dres2.conv2`, `dres3.conv2/4`, the
+    pyramid's `dres8_*`, `confidence.0`; DEN.py:33-40,155-192,243-258) as a rolling window over 8 x 8 columns with the contraction split over
+    the workgroup's waves (filter resident in registers, partial sums exchanged through LDS per half-step; 64 outputs = two launches): every
+    slice count incl. 1 and 2, split slice ranges, one column per workgroup and long streams, a single 8 x 8 column per sample, ReLU and
+    residual on and off; against F.conv3d and against conv_tile on the same input (DFFW_NO_ROLLK)."""
+    B = 3
+    x = rnd(B, cin, N, H, W, seed=61)
+    w = rnd(cout, cin, 3, 3, 3, seed=62, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 63)
+    res = rnd(B, cout, N, H, W, seed=64) if residual else None
+    ref = ref_bn(F.conv3d(x, w, None, 1, 1), bn)
+    if residual:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    monkeypatch.setenv("DFFW_ROLL_ZSPLIT", str(zsplit))
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    kw = dict(pad=1, bn=bn, relu=relu, residual=res.cuda() if residual else None, precision="bf16x3")
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_rollk<%d," % (cin // 8)), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL["bf16x3"], rel(got, ref)
+    again = eng.op_conv3d(x.cuda(), w, **kw)
+    assert torch.equal(got, again)                      # the partial sums are added in a fixed order
+    monkeypatch.setenv("DFFW_NO_ROLLK", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    assert not eng.last_conv_kernel().startswith("dffw::conv_rollk<"), eng.last_conv_kernel()
+    assert rel(got, alt) <= 2e-5, rel(got, alt)
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("N,H,W,zsplit,residual,wgs", [(10, 64, 256, 1, True, 0), (5, 128, 128, 1, False, 16), (1, 64, 256, 1, True, 8),
                                                         (7, 64, 256, 3, False, 24), (2, 128, 128, 2, True, 0)])
@@ -248,6 +283,29 @@ def test_conv_roll_transposed(eng, N, H, W, zsplit, residual, wgs, prec, monkeyp
     alt = eng.op_conv3d(x.cuda(), w, **kw)
     assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
     assert rel(alt, ref) <= TOL[prec]
+
+
+def test_no_lean_roll_switch_reaches_every_rolling_kernel(eng, monkeypatch):
+    """DFFW_NO_LEAN_ROLL must select the generic-epilogue instantiation of conv_roll_t32 and conv_roll_s2 as well (the switch travels in
+    ConvArgs::dbg and those launch paths masked it off, so the lean-vs-generic parity cases compared the lean kernel with itself)."""
+    B, N = 2, 3
+    x = rnd(B, 32, N, 64, 256, seed=71)
+    w = rnd(32, 16, 3, 3, 3, seed=72, scale=0.1)
+    bn = bn_params(16, 73)
+    kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, relu=1, precision="bf16x3")
+    a = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_t32<") and eng.last_conv_kernel().endswith("true>"), eng.last_conv_kernel()
+    x2 = rnd(B, 16, N, 128, 256, seed=74)
+    w2 = rnd(16, 16, 3, 3, 3, seed=75, scale=0.1)
+    kw2 = dict(stride=(1, 2, 2), pad=1, bn=bn, relu=1, precision="bf16x3")
+    a2 = eng.op_conv3d(x2.cuda(), w2, **kw2)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_s2<") and eng.last_conv_kernel().endswith("true>"), eng.last_conv_kernel()
+    monkeypatch.setenv("DFFW_NO_LEAN_ROLL", "1")
+    b = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_t32<") and eng.last_conv_kernel().endswith("false>"), eng.last_conv_kernel()
+    b2 = eng.op_conv3d(x2.cuda(), w2, **kw2)
+    assert eng.last_conv_kernel().startswith("dffw::conv_roll_s2<") and eng.last_conv_kernel().endswith("false>"), eng.last_conv_kernel()
+    assert torch.equal(a, b) and torch.equal(a2, b2)     # same arithmetic, same order
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
@@ -328,6 +386,33 @@ def test_pools(eng, prec):
     assert rel(eng.op_pool(x.cuda(), 2, "max", prec), F.max_pool3d(x, (1, 2, 2), (1, 2, 2))) <= TOL[prec]
     for k in (2, 4, 8):
         assert rel(eng.op_pool(x.cuda(), k, "avg", prec), F.avg_pool3d(x, (1, k, k), (1, k, k))) <= TOL[prec]
+
+
+def test_softplus_pointwise_sweep(eng):
+    """softplus_fast (dffw_kernels.hip: log2 / rcp on the hardware transcendentals, no series, no IEEE divide) point by point instead of through a
+    whole-map norm: a two-slice head with focus distances (0, 1) returns p1 / (p0 + p1), p = softplus(v) + 1e-6 (DEN.py:88-90), i.e. the RATIO of two
+    softplus values -- dense sweep of v over [-30, 25] against (a) the neighbour v + 0.5 (both values small in the tail: relative accuracy there) and
+    (b) the anchor v = 0; covers e^v below fp32 resolution (w == 1 select), the 1e-6 floor and the linear branch above the threshold 20.
+    Reference in float64 with torch's own threshold rule."""
+    v = torch.arange(-30.0, 25.0, 1.0 / 64).float()
+    n = v.numel()
+    w = 64
+    hgt = (n + w - 1) // w
+    pad = hgt * w - n
+    vv = torch.cat([v, v[-1:].repeat(pad)]).reshape(1, 1, hgt, w)
+    fd = torch.tensor([0.0, 1.0]).reshape(1, 2, 1, 1)
+
+    def sp64(x):
+        x = x.double()
+        return torch.where(x > 20.0, x, torch.log1p(torch.exp(x))) + 1e-6
+
+    for other in (vv + 0.5, torch.zeros_like(vv)):
+        score = torch.cat([vv, other], 1).contiguous()
+        got = eng.op_regress(score.cuda(), fd.cuda(), hgt, w).cpu().double().reshape(-1)
+        p0, p1 = sp64(score[0, 0].float()).reshape(-1), sp64(score[0, 1].float()).reshape(-1)
+        ref = p1 / (p0 + p1)
+        err = ((got - ref).abs() / ref).max()
+        assert float(err) <= 1.5e-6, float(err)
 
 
 @pytest.mark.parametrize("N,h,w,scale", [(10, 8, 8, 8), (5, 8, 12, 4), (15, 16, 16, 2), (4, 32, 32, 1), (1, 8, 8, 8)])
