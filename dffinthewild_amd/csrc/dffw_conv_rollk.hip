@@ -128,8 +128,10 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     int fu = ufirst, fq = 0, fslices = 0, fz = 0;      // fill cursor: unit, slice inside it, its slice count, input slice index
     auto setup_fill = [&]() {
         const Unit c = decode(fu);
-        fslices = c.nz + 2;
-        fz = c.zbeg - 1;
+        // the unit's input slices: its output range and one halo slice on either side where the volume has one (no zero slices in the ring:
+        // the windows at the volume's ends skip the taps that would read them)
+        fz = c.zbeg > 0 ? c.zbeg - 1 : 0;
+        fslices = (c.zbeg + c.nz < a.Ni ? c.zbeg + c.nz : a.Ni - 1) - fz + 1;
         const int64_t o = ((int64_t)c.b * a.Ni * a.Hi * a.Wi + (int64_t)(c.gy0 - 1) * a.Wi + (c.gx0 - 1)) * recb;
         fb0 = tb0 + o;
         fb1 = tb1 + o;
@@ -154,7 +156,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         constexpr int k = decltype(K)::value;
         const int p = k * NW + wave;
         if (p >= L::NPIECE) return;                    // (wave-uniform)
-        const bool zin = (unsigned)fz < (unsigned)a.Ni && fu < uend;           // slices above / below the volume and past the stream: zeros
+        const bool zin = fu < uend;                    // past the end of the stream: zeros (the slot is never read)
         const int nrec = zin ? (int)0x80000000 : 0, so = zin ? fz * slice_bytes : 0;
         auto dst = (__attribute__((address_space(3))) void *)(smem + fslotb + p * 1024);
         // One descriptor per piece, chosen with SCALAR selects (written as a lane-dependent choice hipcc turns every piece into a waterfall
@@ -191,7 +193,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         }
     };
 #pragma unroll
-    for (int q = 0; q < RING - 1; ++q) {
+    for (int q = 0; q < 2; ++q) {                   // the fill runs two slices ahead of the window's centre
         static_for<L::PPW>([&](auto K) { issue_piece(K); });
         advance_fill();
     }
@@ -236,7 +238,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): prologue slices, filter, bias (compiler-visible, so that no later wait is invented)
     asm volatile("s_barrier" ::: "memory");
 
-    int sidx = 0;                         // ring slot of the window's first slice
+    int sidx = RING - 1;                  // ring slot of the window's first slice = global step - 1 (the stream's slices sit in consecutive slots)
     f32x4 mine0 = {0.f, 0.f, 0.f, 0.f}, mine1 = {0.f, 0.f, 0.f, 0.f};   // this wave's own partial of the unit it owns in half-step 0 / 1
     char *pptr = nullptr;                 // where the previous step's output slice starts (wave-uniform)
     const char *rptr = nullptr;           // ... and its residual slice
@@ -268,9 +270,12 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     };
 
     // One half-step.  LIVE: contract this window's operand tiles 2h, 2h + 1 (PRE: its chunk 0 was requested by the previous half-step).
-    // FIN: this wave finishes the unit it owns in the PREVIOUS half-step (partials in exchange buffer h ^ 1, its own in `mine`), output slice
-    // at optr_f / residual slice at rptr_f.  LAST: the step ends with this half-step.
-    auto half = [&](auto H_, auto LIVE_, auto FIN_, auto LAST_, auto PRE_, const f32x4 &mine, char *optr_f, const char *rptr_f, int vob_f, f32x4 &mine_out) {
+    // `nofront` / `noback` (wave-uniform): the window's centre is the volume's first / last slice -- the ring holds real slices only, so the taps
+    // of the missing slice (TH = 0: chunks 0-3 and the first tap of chunk 4; TH = 1: chunks 2-6) contract zeroed operands instead of whatever
+    // the ring slot holds.  FIN: this wave finishes the unit it owns in the PREVIOUS half-step (partials in exchange buffer h ^ 1, its own in
+    // `mine`), output slice at optr_f / residual slice at rptr_f.  LAST: the step ends with this half-step.
+    auto half = [&](auto H_, auto LIVE_, auto FIN_, auto LAST_, auto PRE_, const bool nofront, const bool noback, const f32x4 &mine, char *optr_f,
+                    const char *rptr_f, int vob_f, f32x4 &mine_out) {
         constexpr int h = decltype(H_)::value;
         constexpr bool LIVE = decltype(LIVE_)::value, FIN = decltype(FIN_)::value, LAST = decltype(LAST_)::value, PRE = decltype(PRE_)::value;
         // the partials of my unit come in two batches (at most 4 + 3: 16 registers instead of 28), each requested behind a chunk's operands
@@ -343,6 +348,29 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
                     if constexpr (c == 1) fin_read(std::integral_constant<int, 0>{});
                     if constexpr (c == 3) fin_read(std::integral_constant<int, 1>{});
                     asm volatile("" : "+v"(x[cur][0][0]), "+v"(x[cur][0][1]), "+v"(x[cur][1][0]), "+v"(x[cur][1][1]));
+                }
+                // taps in a slice the volume does not have: zero operands (a uniform branch, taken by two steps per unit)
+                if constexpr (TH == 0 && c <= 4) {
+                    if (nofront) {
+                        const unsigned keep = c == 4 ? gmask : 0u;   // chunk 4 = taps 8 | 9: only its first tap (lanes g < 2) lies in the missing slice
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int pt = 0; pt < 2; ++pt) {
+                                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                                u32x4v q = __builtin_bit_cast(u32x4v, x[cur][j][pt]);
+                                q &= keep;
+                                x[cur][j][pt] = __builtin_bit_cast(short8, q);
+                            }
+                    }
+                }
+                if constexpr (TH == 1 && c >= 2) {
+                    if (noback) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int pt = 0; pt < 2; ++pt) x[cur][j][pt] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
                 }
                 if constexpr (!(ABL & 2)) {
                     // product-major over the four accumulators: consecutive MFMAs never share one
@@ -423,8 +451,9 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         }
     };
 
-    // One step of the stream.  LIVE: this window produces an output slice; PEND: the previous one did (its second half-step's units are finished now).
-    auto step = [&](auto LIVE_, auto PEND_, char *optr, const char *rp) {
+    // One step of the stream.  LIVE: this window produces an output slice (nofront / noback: see half); PEND: the previous one did (its second
+    // half-step's units are finished now).
+    auto step = [&](auto LIVE_, auto PEND_, const bool nofront, const bool noback, char *optr, const char *rp) {
         constexpr bool LIVE = decltype(LIVE_)::value, PEND = decltype(PEND_)::value;
         using T = std::true_type;
         using F = std::false_type;
@@ -433,15 +462,26 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         f32x4 dummy;
         if constexpr (LIVE) {
             // (a live step behind a live step finds its chunk 0 requested by that step's second half-step)
-            half(I0{}, T{}, std::integral_constant<bool, PEND && OWN1>{}, F{}, std::integral_constant<bool, PEND>{}, mine1, pptr, rptr, vob1, OWN0 ? mine0 : dummy);
-            half(I1{}, T{}, std::integral_constant<bool, OWN0>{}, T{}, T{}, mine0, optr, rp, vob0, OWN1 ? mine1 : dummy);
+            half(I0{}, T{}, std::integral_constant<bool, PEND && OWN1>{}, F{}, std::integral_constant<bool, PEND>{}, nofront, noback, mine1, pptr, rptr, vob1, OWN0 ? mine0 : dummy);
+            half(I1{}, T{}, std::integral_constant<bool, OWN0>{}, T{}, T{}, nofront, noback, mine0, optr, rp, vob0, OWN1 ? mine1 : dummy);
         } else {
-            half(I0{}, F{}, std::integral_constant<bool, PEND && OWN1>{}, T{}, F{}, mine1, pptr, rptr, vob1, dummy);
+            half(I0{}, F{}, std::integral_constant<bool, PEND && OWN1>{}, T{}, F{}, false, false, mine1, pptr, rptr, vob1, dummy);
         }
         sidx = (sidx + 1) & (RING - 1);
         advance_fill();
         pptr = optr;
         rptr = rp;
+    };
+    auto dispatch = [&](bool live, bool pend, bool nofront, bool noback, char *optr, const char *rp) {
+        using T = std::true_type;
+        using F = std::false_type;
+        if (live) {
+            if (pend) step(T{}, T{}, nofront, noback, optr, rp);
+            else step(T{}, F{}, nofront, noback, optr, rp);
+        } else {
+            if (pend) step(F{}, T{}, false, false, optr, rp);
+            else step(F{}, F{}, false, false, optr, rp);
+        }
     };
 
     bool prev_live = false;
@@ -449,26 +489,24 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         const int64_t o0 = ((((int64_t)U.b * a.No + U.zbeg) * a.Ho + U.gy0) * a.Wo + U.gx0) * a.Cout * 4;
-        char *optr = reinterpret_cast<char *>(a.out) + o0;
-        const char *rp = RES ? reinterpret_cast<const char *>(a.res0) + o0 : nullptr;
-        for (int st = 0; st < U.nz + 2; ++st) {
-            const bool live = st < U.nz;   // windows starting on the unit's last two slices straddle two units: no output
-            using T = std::true_type;
-            using F = std::false_type;
-            if (live) {
-                if (prev_live) step(T{}, T{}, optr, rp);
-                else step(T{}, F{}, optr, rp);
-            } else {
-                if (prev_live) step(F{}, T{}, optr, rp);
-                else step(F{}, F{}, optr, rp);
-            }
+        // Step st of the unit's ns input slices contracts the window centred on its slice st = output slice st - h0 (h0: the unit has a halo slice
+        // in front, i.e. its range starts inside the volume): a range that starts / ends inside the volume costs a dead step there, one that
+        // reaches the volume's end none -- a unit that covers all slices is ns live steps.
+        const int zlo = U.zbeg > 0 ? U.zbeg - 1 : 0, h0 = U.zbeg - zlo;
+        const int ns = (U.zbeg + U.nz < a.Ni ? U.zbeg + U.nz : a.Ni - 1) - zlo + 1;
+        char *optr = reinterpret_cast<char *>(a.out) + o0 - (int64_t)h0 * ostride;
+        const char *rp = RES ? reinterpret_cast<const char *>(a.res0) + o0 - (int64_t)h0 * ostride : nullptr;
+        for (int st = 0; st < ns; ++st) {
+            const bool live = st >= h0 && st - h0 < U.nz;
+            dispatch(live, prev_live, st == 0, st == ns - 1, optr, rp);
             prev_live = live;
             optr += ostride;
             if (RES) rp += ostride;
         }
     }
-    // a unit ends with two dead steps, which have finished the last live step's units -- and the slices queued past the end of the
-    // stream are still in flight: a wave must not retire before its LDS-DMA has landed
+    // the last live step's second half-step is finished by the step behind it: past the end of the stream, one more (dead) step
+    if (prev_live) dispatch(false, true, false, false, nullptr, nullptr);
+    // ... and the slices queued past the end of the stream are still in flight: a wave must not retire before its LDS-DMA has landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
