@@ -45,6 +45,15 @@ void rollk_tile(int *ty, int *tx);
 int rollk_waves(int prec, const ConvArgs &a);   // waves per workgroup (= input channels / 8) when the kernel covers the launch, else 0
 hipError_t launch_conv_rollk(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_rollk_kernel_name(const ConvArgs &a, char *buf, int n);
+// conv_slice32 (dffw_conv_slice.hip, round 5): per-slice 1x3x3, 32 -> 32 channels, every wave holds the whole filter: SLICE32_CHUNKS chunks of (one tap x
+// 32 channels) for two output tiles, packed as [chunk][output tile][part][64 lanes][8]; columns of 8 x 16 output pixels, all slices of a sample
+#define DFFW_SLICE_TY 8
+#define DFFW_SLICE_TX 16
+constexpr int SLICE32_CHUNKS = 9;
+void slice32_tile(int *ty, int *tx);
+bool slice32_ok(int prec, const ConvArgs &a);
+hipError_t launch_conv_slice32(const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_slice32_kernel_name(const ConvArgs &a, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
 // transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one

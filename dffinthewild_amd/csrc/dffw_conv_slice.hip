@@ -1,0 +1,297 @@
+// conv_slice32: the per-slice 1x3x3 convolution with 32 input and 32 output channels as a persistent streaming kernel (round 5), gfx950 / MI355X.
+// `FM_conv2.1.Focus_Measure.conv.{0,2}` (DEN.py:295-304: the two convs of the 32-channel SRD block's resnet_block_2d) and the 32 -> 32 convs of
+// the alignment heads of End_to_End (E2E.py:33-61: `optical_flow_aggregation.conv2.{2,4}.0`).
+//
+// On conv_tile these layers spend half their time staging footprints (profiles/r05_ablation_conv_tile_phases.txt: fill alone 0.063 of 0.120 ms):
+// a 5 x 4 x 16 block of a per-slice conv has no reuse along the slices, so every block pays a full (y, x) halo for 64-byte half-line requests,
+// and fill -> barrier -> contract -> store run one after the other.  Here
+//   * the 9 x 32 x 32 split-bf16 filter (37 KB) is small enough for EVERY wave to hold all of it: 9 chunks (one tap x 32 channels) x 2 output
+//     tiles x (hi, lo) = 144 VGPRs -- no weight stream and no split of the contraction, hence no exchange of partial sums;
+//   * a workgroup of 4 waves walks the slices of 8 x 16 columns (a slice is an independent 2-D convolution; walking them gives the stream its
+//     length): slice images go through a ring of 3 LDS slots by buffer-addressed LDS-DMA two slices ahead of the one being contracted, one
+//     barrier per slice; wave w contracts rows 2w, 2w + 1 of the column (two operand tiles of 16 pixels) and runs their epilogue itself;
+//   * LDS slice image [16-channel group][part][row][pixel][octet] in 16-byte entries (conv_rollk's): lane rows g, g + 1 of an operand read take
+//     the two octets of the same tap of 16 consecutive pixels -- 16 distinct 16-byte bank groups per ds_read_b128 service group, no padding;
+//   * the operand fragments of chunk c + 1 are requested in front of chunk c's MFMAs, chunk 0 of the NEXT slice (already resident) in front of the
+//     last chunk's, so the matrix pipe restarts right behind the barrier; two workgroups per CU run out of phase.
+// Epilogue: out = [relu](acc + BatchNorm shift [+ residual]) in split-bf16 storage (epilogue_lean: the arithmetic and order of conv_tile's LEAN
+// epilogue; the contraction order differs from conv_tile's stage walk only in the position of the channel halves inside a chunk).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+
+#include "dffw_conv_roll.h"
+#include "dffw_device.h"
+
+namespace dffw {
+
+namespace slice32 {
+constexpr int TY = DFFW_SLICE_TY, TX = DFFW_SLICE_TX, FY = TY + 2, FX = TX + 2, NW = 4, RING = 3, NCH = SLICE32_CHUNKS;
+static_assert(TY == 2 * NW && TX == 16, "a wave contracts two 16-pixel rows of the column");
+constexpr int PARTE = FY * FX * 2;        // entries of one part of a 16-channel group: [row][pixel][octet]
+constexpr int CQE = 2 * PARTE;            // ... of a group: [part][row][pixel][octet]
+constexpr int SLOTE = 2 * CQE;
+constexpr int NPIECE = (SLOTE + 63) / 64;
+constexpr int SLOTB = NPIECE * 1024;
+constexpr int PPW = (NPIECE + NW - 1) / NW;
+constexpr int LDSB = RING * SLOTB;
+static_assert(CQE % 16 == 0 && SLOTB % 256 == 0 && 2 * LDSB <= 160 * 1024, "LDS layout (two workgroups per CU)");
+}   // namespace slice32
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice32(const ConvArgs a, const RollArgs t) {
+    using namespace slice32;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+
+    // ---- this workgroup's units (8 x 16 columns of one sample): XCD x owns a contiguous range, as conv_roll -------------
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % t.tiles_x;
+        const int tt = u / t.tiles_x;
+        c.gx0 = txi * TX;
+        c.gy0 = (tt % t.tiles_y) * TY;
+        c.b = tt / t.tiles_y;
+        return c;
+    };
+
+    // ---- fill: pieces of 64 consecutive 16-byte entries of the slot; per lane the byte offset from the unit's footprint origin (out-of-image
+    // and padding lanes pushed out of range: the buffer range check writes their zeros = the conv's padding) ---------------------------------
+    constexpr int recb = 128, partb = 64;              // a pixel record of the 32-channel source: [hi 32][lo 32]
+    const char *tb = reinterpret_cast<const char *>(a.in0);
+    const int slice_bytes = a.Hi * a.Wi * recb;
+    int fvo[PPW];
+    const char *fb = tb;
+    int fu = ufirst, fz = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+        fz = 0;
+        fb = tb + ((int64_t)c.b * a.Ni * a.Hi * a.Wi + (int64_t)(c.gy0 - 1) * a.Wi + (c.gx0 - 1)) * recb;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                       // (opaque: hipcc would hoist the decode below out of the unit loop and keep its results in registers)
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int e = (k * NW + wave) * 64 + ln;       // entry inside the slot: [group][part][row][pixel][octet]
+            const int cq = e / CQE, e2 = e - cq * CQE;
+            const int part = e2 / PARTE, e3 = e2 - part * PARTE;
+            const int fy = e3 / (2 * FX), e4 = e3 - fy * (2 * FX);
+            const int fx = e4 >> 1, oct = e4 & 1;
+            const int iy = c.gy0 - 1 + fy, ix = c.gx0 - 1 + fx;
+            fvo[k] = (e < SLOTE && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) ? (fy * a.Wi + fx) * recb + part * partb + (cq * 2 + oct) * 16
+                                                                                                 : (int)0x80000000;
+        }
+    };
+    setup_fill();
+    int fslotb = 0;
+    auto issue_piece = [&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
+        const int p = k * NW + wave;
+        if (p >= NPIECE) return;                           // (wave-uniform)
+        const bool zin = fu < uend;                        // past the end of the stream: zeros (the slot is never read)
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fb), 0, zin ? (int)0x80000000 : 0, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + fslotb + p * 1024), 16, fvo[k], zin ? fz * slice_bytes : 0, 0, 0);
+    };
+    auto advance_fill = [&]() {
+        fslotb = (fslotb + SLOTB == RING * SLOTB) ? 0 : fslotb + SLOTB;
+        if (++fz == a.Ni && fu < uend) {
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                          // the fill runs two slices ahead
+        static_for<PPW>([&](auto K) { issue_piece(K); });
+        advance_fill();
+    }
+
+    // ---- operand addressing: K octet g of a chunk = input channels 8g .. 8g + 7 = (group g >> 1, octet g & 1) of the chunk's tap; lane r of
+    // operand tile j = pixel (row 2 * wave + j, column r): tap, tile and part are instruction immediates
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const unsigned abase = lds0 + (unsigned)(((g >> 1) * CQE + (2 * wave) * 2 * FX + r * 2 + (g & 1)) * 16);
+    // output: the lane's 16-byte piece (part g & 1 of channel octet nt * 2 + (g >> 1)) of pixel (row 2 * wave + j, column r)
+    int vob[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) vob[j][nt] = ((2 * wave + j) * a.Wo + r) * 64 + (g & 1) * 32 + (nt * 2 + (g >> 1)) * 8;
+
+    // ---- the whole filter: 9 chunks x 2 output tiles x (hi, lo), resident for the whole walk ----
+    short8 w[NCH][2][2];
+    {
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                w[c][nt][0] = wp[((c * 2 + nt) * 2 + 0) * 64];
+                w[c][nt][1] = wp[((c * 2 + nt) * 2 + 1) * 64];
+            }
+    }
+    f32x4 bias4[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bias4[nt] = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): prologue slices, filter, bias (compiler-visible, so that no later wait is invented)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) asm volatile("" : "+v"(w[c][nt][0]), "+v"(w[c][nt][1]));   // (pinned: never re-loaded in front of an MFMA)
+    asm volatile("s_barrier" ::: "memory");
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // operand fragments of one chunk: [operand tile][part]; two buffers in rotation over the chunk sequence, which runs on across slices (9 chunks
+    // per slice: chunk c of a slice of parity PAR sits in buffer (PAR + c) & 1)
+    short8 x[2][2][2];
+    auto fetch = [](auto BUF, auto C, short8 (&xx)[2][2][2], const unsigned ad) __attribute__((always_inline)) {
+        constexpr int b = decltype(BUF)::value, c = decltype(C)::value;
+        constexpr int tapo = ((c / 3) * 2 * FX + (c % 3) * 2) * 16, row1 = 2 * FX * 16, pb = PARTE * 16;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][0]) : "v"(ad), "n"(tapo));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][1]) : "v"(ad), "n"(tapo + pb));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][0]) : "v"(ad), "n"(tapo + row1));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][1]) : "v"(ad), "n"(tapo + row1 + pb));
+    };
+
+    int sidxb = 0;                        // byte offset of the ring slot of the slice being contracted
+    // One slice.  PAR: parity of the stream position (selects the fragment buffers); PRE: its chunk 0 was requested by the slice in front.
+    auto step = [&](auto PAR_, auto PRE_, char *optr, const char *rptr) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value;
+        constexpr bool PRE = decltype(PRE_)::value;
+        // the slice two ahead goes into the slot the previous step left
+        static_for<PPW>([&](auto K) { issue_piece(K); });
+        // residual pieces of this slice's outputs: requested behind chunk 1's MFMAs (at the top of the step they cost spills; later their latency shows: 16 registers live over most of the
+        // contraction), waited for -- together with the DMA pieces in front of them -- before the epilogue
+        u32x4 rq[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) rq[j][nt] = u32x4{0, 0, 0, 0};
+        const unsigned cur0 = abase + (unsigned)sidxb;
+        const unsigned nxtb = abase + (unsigned)(sidxb + SLOTB == RING * SLOTB ? 0 : sidxb + SLOTB);
+        if constexpr (!PRE) fetch(std::integral_constant<int, PAR & 1>{}, std::integral_constant<int, 0>{}, x, cur0);
+        f32x4 n[4];   // [operand tile][output tile]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) n[u] = bias4[u & 1];
+        static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+            constexpr int c = decltype(C)::value;
+            constexpr int cur = (PAR + c) & 1, nxt = cur ^ 1;
+            if constexpr (c + 1 < NCH) fetch(std::integral_constant<int, nxt>{}, std::integral_constant<int, (c + 1 < NCH ? c + 1 : 0)>{}, x, cur0);
+            else fetch(std::integral_constant<int, nxt>{}, std::integral_constant<int, 0>{}, x, nxtb);   // the next slice's chunk 0: resident since the last barrier
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[cur][0][0]), "+v"(x[cur][0][1]), "+v"(x[cur][1][0]), "+v"(x[cur][1][1]));
+            // product-major over the four accumulators: consecutive MFMAs never share one
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) n[j * 2 + nt] = mma<false>(w[c][nt][1], x[cur][j][0], n[j * 2 + nt]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) n[j * 2 + nt] = mma<false>(w[c][nt][0], x[cur][j][1], n[j * 2 + nt]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) n[j * 2 + nt] = mma<false>(w[c][nt][0], x[cur][j][0], n[j * 2 + nt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RES && c == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        // (wave-uniform base in SGPRs + the lane's 32-bit byte offset: no 64-bit address per lane and piece)
+                        const unsigned ro = (unsigned)(vob[j][nt] * 2);
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rq[j][nt]) : "v"(ro), "s"(rptr) : "memory");
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        // epilogue of the wave's four result tiles
+        if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const uint4 q4 = make_uint4(rq[j][nt][0], rq[j][nt][1], rq[j][nt][2], rq[j][nt][3]);
+                (void)epilogue_lean<P_BF16X3, RES, false>(reinterpret_cast<uint16_t *>(optr), nullptr, vob[j][nt], n[j * 2 + nt], q4, RELU, zero4);
+                __builtin_amdgcn_sched_barrier(0);   // (one tile's epilogue at a time: interleaved, the four need their temporaries at once)
+            }
+        // the slice queued in this step (and everything older) has landed; this step's four stores may stay in flight across the barrier.  All
+        // waves are done reading this slice's slot: the step after the next one refills it.
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            constexpr int nb = (PAR + NCH) & 1;
+            asm volatile("" : "+v"(x[nb][0][0]), "+v"(x[nb][0][1]), "+v"(x[nb][1][0]), "+v"(x[nb][1][1]));
+        }
+        sidxb = (sidxb + SLOTB == RING * SLOTB) ? 0 : sidxb + SLOTB;
+        advance_fill();
+    };
+
+    const int64_t ostride = (int64_t)a.Ho * a.Wo * 128;   // bytes per output slice (32 channels, hi + lo)
+    int par = 0;
+    bool first = true;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        const int64_t o0 = (((int64_t)U.b * a.No * a.Ho + U.gy0) * a.Wo + U.gx0) * 128;
+        char *optr = reinterpret_cast<char *>(a.out) + o0;
+        const char *rp = RES ? reinterpret_cast<const char *>(a.res0) + o0 : nullptr;
+        for (int z = 0; z < a.No; ++z) {
+            using T = std::true_type;
+            using F = std::false_type;
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            if (first) step(I0{}, F{}, optr, rp);
+            else if (par) step(I1{}, T{}, optr, rp);
+            else step(I0{}, T{}, optr, rp);
+            first = false;
+            par ^= 1;
+            optr += ostride;
+            if (RES) rp += ostride;
+        }
+    }
+    // the slices queued past the end of the stream are still in flight: a wave must not retire before its LDS-DMA has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+void slice32_tile(int *ty, int *tx) {
+    *ty = slice32::TY;
+    *tx = slice32::TX;
+}
+
+bool slice32_ok(int prec, const ConvArgs &a) {
+    if (prec != P_BF16X3 || (a.dbg & DFFW_ARGS_NO_SLICE32)) return false;
+    if (!a.out || a.out_pre || a.outf || a.res1 || a.res_bcast || a.cls_w || a.relu == 2 || a.Cout != 32 || a.C0 != 32 || a.C1 != 0) return false;
+    if (a.Ho % slice32::TY || a.Wo % slice32::TX || a.Ho != a.Hi || a.Wo != a.Wi || a.No != a.Ni) return false;
+    // 32-bit buffer offsets: a sample's input volume (+ one footprint) stays below 2^31 bytes
+    return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * 128 < (1ll << 31);
+}
+
+hipError_t launch_conv_slice32(const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    const int want = t.wgs > 0 ? t.wgs : 512;   // two 4-wave workgroups per CU
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(slice32::NW * 64);
+    const bool relu = a.relu == 1, res = a.res0 != nullptr;
+    if (relu && res) hipLaunchKernelGGL((conv_slice32<true, true>), grid, block, 0, s, a, t);
+    else if (relu) hipLaunchKernelGGL((conv_slice32<true, false>), grid, block, 0, s, a, t);
+    else if (res) hipLaunchKernelGGL((conv_slice32<false, true>), grid, block, 0, s, a, t);
+    else hipLaunchKernelGGL((conv_slice32<false, false>), grid, block, 0, s, a, t);
+    return hipGetLastError();
+}
+
+void conv_slice32_kernel_name(const ConvArgs &a, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_slice32<%s, %s>", a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false");
+}
+
+}  // namespace dffw

@@ -310,6 +310,7 @@ struct PackedConv {
     uint16_t *wroll = nullptr;  // device: the filter in conv_roll's fragment order (3x3x3 stride 1, 16 input channels, <= 16 outputs)
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_k2 = nullptr;  // device: a 3x3x3 stride-1 32 -> 16 filter in conv_rollx_k2's order: [input half][conv_roll's 15 chunks]
+    uint16_t *wslice32 = nullptr;  // device: a 1x3x3 32 -> 32 filter in conv_slice32's order: [9 taps][output tile][part]
     uint16_t *wrollk = nullptr;    // device: a 3x3x3 stride-1 32 / 64 -> 32 / 64 filter in conv_rollk's order: [32-channel output pair][wave][7 chunks][output tile]
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
@@ -351,6 +352,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll_k2 = nullptr;
     if (pc.wrollk) (void)hipFree(pc.wrollk);
     pc.wrollk = nullptr;
+    if (pc.wslice32) (void)hipFree(pc.wslice32);
+    pc.wslice32 = nullptr;
     if (pc.wroll8) (void)hipFree(pc.wroll8);
     pc.wroll8 = nullptr;
     if (pc.wroll_t32) (void)hipFree(pc.wroll_t32);
@@ -533,16 +536,18 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         int cg = (geo == G3S2 || geo == G2S2) ? 8 : (cin_t % 16 == 0 ? 16 : 8);
         // transposed conv: its 4 sub-pixel passes share one LDS image only when the whole contraction depth is
         // staged at once, so 32-channel groups (one fill instead of 4 x 2) where an instantiation exists
-        if (geo == G3T && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;
+        if (geo == G3T && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32)) cg = 32;
         // stride-(1,2,2) 3x3x3 over 64 channels (dres2.conv3): 16-channel stages on a 4 x 4 x 8 tile instead of eight 8-channel
         // stages on 5 x 4 x 16 (every stage re-fetches the 128-byte lines it takes a piece of): -18 %.  Measured on the 16- and
         // 32-channel stride-2 layers too: +25 % / +9 % SLOWER (smaller tile, more halo, 4-slice tiles on 10 slices) -- not used there.
-        if (geo == G3S2 && cin_t % 64 == 0 && tile_cfg_find(geo, pc.nt, 16) && !getenv("DFFW_NO_S2_CG16")) cg = 16;
+        if (geo == G3S2 && cin_t % 64 == 0 && tile_cfg_find(geo, pc.nt, 16)) cg = 16;
         // per-slice 1x3x3 over 32 channels: ONE 32-channel stage per tile (each 128-byte pixel line is fetched once instead of
         // half of it per 16-channel stage -- the memory side moves whole 128-byte lines, profiles/r02_fetch_size_calibration.txt)
-        if (geo == G2S1 && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32) && !getenv("DFFW_NO_CG32")) cg = 32;   // +4..14 % on those layers
+        if (geo == G2S1 && cin_t % 32 == 0 && tile_cfg_find(geo, pc.nt, 32)) cg = 32;   // +4..14 % on those layers
         // wide (8-wave, 640-point) tile wherever an instantiation exists (dffw_conv_tile.hip lists what was measured)
-        const bool wide = !getenv("DFFW_NO_WIDE");
+        // (the pack-time switches DFFW_NO_WIDE / DFFW_NO_CG32 / DFFW_NO_S2_CG16 / DFFW_STEM_NARROW / DFFW_NO_ROLL_PAIR / DFFW_NO_ROLL_T were retired in round 5: their
+        // alternatives lost every A/B of rounds 1-4, profiles/r04_ab_forward_switches.txt and the rounds before)
+        const bool wide = true;
         // pair: the stem's pixel-pair form (G2P) -- result rows 8-15 carry the filter as pixel x+2 sees the same records, and the
         // LDS image keeps only the footprint columns = 0,1 mod 4 (tap offsets in packed columns)
         auto pack_tile = [&](TilePack &tp, const TileCfg *cfg, int cg, bool pair) -> int {
@@ -612,7 +617,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                 if (rc != DFFW_OK) return rc;
             }
         }
-        const TileCfg *pcfg = (stem && L.cout == 8 && !getenv("DFFW_NO_STEM_PAIR")) ? tile_cfg_find(G2P, 1, 8, wide && !getenv("DFFW_STEM_NARROW")) : nullptr;
+        const TileCfg *pcfg = (stem && L.cout == 8 && !getenv("DFFW_NO_STEM_PAIR")) ? tile_cfg_find(G2P, 1, 8, wide) : nullptr;
         if (pcfg) {
             const int rc = pack_tile(pc.tile_pair, pcfg, 8, true);
             if (rc != DFFW_OK) return rc;
@@ -622,7 +627,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // K order [dz][k5][32]: chunk k5 of a slice = in-slice taps 2*k5 and 2*k5+1 (tap 9 does not exist: zero weights),
     // lane group g -> tap 2*k5 + (g >> 1), channel octet g & 1
     if (geo == G3S1 && cin_pad == 16 && pc.nt == 1 && !stem) {
-        pc.roll_pair = L.cout == 8 && !getenv("DFFW_NO_ROLL_PAIR");
+        pc.roll_pair = L.cout == 8;
         const int nch = pc.roll_pair ? ROLL_CHUNKS_PAIR : ROLL_CHUNKS;
         std::vector<uint16_t> wr((size_t)nch * parts * 512, 0);
         for (int c = 0; c < nch; ++c)
@@ -680,6 +685,24 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                     }
         HIPCHK(hipMalloc((void **)&pc.wroll_k2, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wroll_k2, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- conv_slice32 (dffw_conv_slice.hip): per-slice 1x3x3, 32 -> 32 channels: chunk c = filter tap c ([ky][kx] order) x 32 channels (K octet g = channels 8g ..)
+    if (geo == G2S1 && cin_pad == 32 && L.cin == 32 && L.cout == 32 && !shortcut_w && prec == P_BF16X3) {
+        std::vector<uint16_t> wr((size_t)SLICE32_CHUNKS * 2 * parts * 512, 0);
+        for (int c = 0; c < SLICE32_CHUNKS; ++c)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = lane & 15, gq = lane >> 4, ky = c / 3, kx = c % 3;
+                        const float val = (float)wval(nt * 16 + row, gq * 8 + j, Tap{0, ky - 1, kx - 1, 0, ky, kx});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)c * 2 + nt) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wslice32, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wslice32, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- conv_rollk (dffw_conv_rollk.hip): 3x3x3 stride 1, 32 / 64 -> 32 / 64 channels, the contraction split over the workgroup's waves: wave w =
     // (16-channel group w >> 1, tap half w & 1); tap slot s of a half = filter tap 14 * (w & 1) + s in [dz][ky][kx] order (tap 27: zero weights);
@@ -1019,7 +1042,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // tap x 32 channels (K octet g = channel octet g).  Enumeration (must match the kernel): x phase 0 first: (window slice d,
     // row tap rt) with filter column 1 at input column x; then x phase 1: (d, rt, ct): ct = 0 -> filter column 2 at x, ct = 1 ->
     // filter column 0 at x+1.  Row taps: py = 0: filter row 1 at input row y; py = 1: rt = 0 -> filter row 2 at y, rt = 1 -> row 0 at y+1.
-    if (geo == G3T && (cin_pad == 32 || cin_pad == 16) && L.cout == 16 && !getenv("DFFW_NO_ROLL_T")) {   // (16 input channels: octets 2, 3 get zero weights)
+    if (geo == G3T && (cin_pad == 32 || cin_pad == 16) && L.cout == 16) {   // (16 input channels: octets 2, 3 get zero weights)
         std::vector<uint16_t> wr((size_t)(ROLL_CHUNKS_T32_0 + ROLL_CHUNKS_T32_1) * parts * 512, 0);
         size_t chunk0 = 0;
         for (int py = 0; py < 2; ++py) {
@@ -1052,7 +1075,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // slice (c-3)/2, filter row 2 at input row y ((c-3) even) or filter row 0 at input row y+1 (odd).  Lane group g
     // contracts input column x + (g >> 1), channel octet g & 1: pixel 2x sees only column x (filter column 1), pixel 2x+1
     // sees column x (filter column 2) and column x+1 (filter column 0).  Window slice d is input slice oz-1+d = filter slice 2-d.
-    if (geo == G3T && cin_pad == 16 && L.cout == 8 && !getenv("DFFW_NO_ROLL_T")) {
+    if (geo == G3T && cin_pad == 16 && L.cout == 8) {
         std::vector<uint16_t> wr((size_t)ROLL_CHUNKS_T * parts * 512, 0);
         for (int c = 0; c < ROLL_CHUNKS_T; ++c)
             for (int lane = 0; lane < 64; ++lane)
@@ -1188,9 +1211,9 @@ static bool getenv_flag(const char *name) {
 // graph code below never calls getenv itself, so a forward sees one consistent set and pays for one scan of environ.
 #define DFFW_SWITCHES(X)                                                                                                 \
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
-    X(NO_FUSED_SRD16) X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_ROLL_T32) X(NO_SPLIT) X(NO_SPLITK)  \
-    X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2K) X(NO_ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_ROLLK) X(NO_REGRESS_MERGE) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
+    X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_SPLIT) X(NO_SPLITK)  \
+    X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_ROLLK) X(NO_SLICE32) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1238,7 +1261,7 @@ struct Switches {
 
 inline int Switches::path_bits() const {
     return (f[SW_NO_LEAN_TILE] ? DFFW_ARGS_NO_LEAN_TILE : 0) | (f[SW_NO_LEAN_ROLL] ? DFFW_ARGS_NO_LEAN_ROLL : 0) | (f[SW_NO_ROLLX] ? DFFW_ARGS_NO_ROLLX : 0) |
-           (f[SW_NO_ROLLK] ? DFFW_ARGS_NO_ROLLK : 0);
+           (f[SW_NO_ROLLK] ? DFFW_ARGS_NO_ROLLK : 0) | (f[SW_NO_SLICE32] ? DFFW_ARGS_NO_SLICE32 : 0);
 }
 
 struct ConvOpt {
@@ -1498,11 +1521,11 @@ struct Run {
         }
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
-            (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= sw.roll_min_units && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_T32)) {
+            (int64_t)in0.B * (in0.H / 8) * (in0.W / 16) >= sw.roll_min_units && !sw.on(SW_NO_ROLL)) {
             if (dry) return out;
             a.Ng = in0.N; a.Hg = in0.H; a.Wg = in0.W;
             a.M = (int64_t)a.B * in0.N * in0.H * in0.W;
-            a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK);   // (the ablation bits these kernels know + the launchers' path switches)
+            a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK | DFFW_ARGS_NO_SLICE32);   // (the ablation bits these kernels know + the launchers' path switches)
             for (int py = 0; py < 2; ++py) {
                 int rty, rtx;
                 roll_t32_tile(py, &rty, &rtx);
@@ -1532,7 +1555,7 @@ struct Run {
         // strided 3x3x3 over 16 / 32 channels (FM_conv2.0.stride_conv, dres3.conv1, dres4.conv3; dres3.conv3, dres2.conv1, SPP conv1):
         // rolling window with whole pixel records
         if (pc.wroll_s2 && !L.transposed && L.sh == 2 && (in0.C == 16 || in0.C == 32) && !o.in1 && !o.res1 && !o.res_bcast && !o.outf && !o.out_pre &&
-            !o.cls && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_S2) && !(in0.C == 32 && sw.on(SW_NO_ROLL_S2K)) &&
+            !o.cls && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLL_S2) &&
             (L.cout <= 32 || !sw.on(SW_NO_ROLL_S2_WIDE))) {   // 32 -> 64 as two launches: level with conv_tile in r02, 4-7 % faster since the r04 row-pitch fix of conv_roll_s2
             const int khn = in0.C / 16;
             const int ntk = (khn == 2 || L.cout >= 32) ? 2 : 1;     // output tiles per launch
@@ -1544,7 +1567,7 @@ struct Run {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
-                a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK);   // (the ablation bits these kernels know + the launchers' path switches)
+                a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK | DFFW_ARGS_NO_SLICE32);   // (the ablation bits these kernels know + the launchers' path switches)
                 for (int li = 0; li < nlaunch; ++li) {
                     RollArgs t;
                     memset(&t, 0, sizeof t);
@@ -1580,7 +1603,7 @@ struct Run {
                 if (dry) return out;
                 a.Ng = No; a.Hg = Ho; a.Wg = Wo;
                 a.M = (int64_t)a.B * No * Ho * Wo;
-                a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK);   // (the ablation bits these kernels know + the launchers' path switches)
+                a.dbg &= (6 | DFFW_ARGS_NO_LEAN_TILE | DFFW_ARGS_NO_LEAN_ROLL | DFFW_ARGS_NO_ROLLX | DFFW_ARGS_NO_ROLLK | DFFW_ARGS_NO_SLICE32);   // (the ablation bits these kernels know + the launchers' path switches)
                 RollArgs t;
                 memset(&t, 0, sizeof t);
                 t.wroll = pc.wroll8;
@@ -1682,6 +1705,37 @@ struct Run {
                     prof_end();
                     return out;
                 }
+            }
+        }
+        // per-slice 1x3x3, 32 -> 32 channels on whole 8 x 16 columns: the streaming kernel with the filter resident in every wave
+        if (pc.wslice32 && !o.in1 && !o.sums && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_SLICE32)) {
+            int sty, stx;
+            slice32_tile(&sty, &stx);
+            const int cols = (Ho / sty) * (Wo / stx);
+            ConvArgs ak = a;
+            ak.Ng = No; ak.Hg = Ho; ak.Wg = Wo;
+            ak.M = (int64_t)ak.B * No * Ho * Wo;
+            if (Ho % sty == 0 && Wo % stx == 0 && (int64_t)in0.B * cols >= sw.roll_min_units && slice32_ok(e->prec, ak)) {
+                if (dry) return out;
+                RollArgs t;
+                memset(&t, 0, sizeof t);
+                t.wroll = pc.wslice32;
+                t.tiles_y = Ho / sty;
+                t.tiles_x = Wo / stx;
+                t.zsplit = 1;
+                t.total_tiles = in0.B * cols;
+                t.wgs = sw.roll_wgs;
+                char kn[96];
+                conv_slice32_kernel_name(ak, kn, sizeof kn);
+                g_last_kernel = kn;
+                if (e->profiling) {
+                    const double opx = (double)out.B * No * Ho * Wo;
+                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout * elem_bytes() * (1 + (o.res0 ? 1 : 0)) + 9.0 * L.cin * L.cout * elem_bytes();
+                    prof_begin(kn, name, 2.0 * opx * 9.0 * L.cin * L.cout, bytes);
+                }
+                check(launch_conv_slice32(ak, t, s), name.c_str());
+                prof_end();
+                return out;
             }
         }
         // 32 / 64 -> 32 / 64 channels on whole 8 x 8 columns: the K-split rolling window (one launch per 32 output channels)
@@ -1983,7 +2037,7 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
         if (x.C == 16) srd_roll16_tile(&sty, &stx);
         else srd_roll_tile(&sty, &stx);
         const auto end = r.e->convs.end();
-        if ((x.C == 8 || (x.C == 16 && !r.sw.on(SW_NO_FUSED_SRD16))) && c0 != end && c2 != end && a3 != end && a1 != end &&
+        if ((x.C == 8 || x.C == 16) && c0 != end && c2 != end && a3 != end && a1 != end &&
             c0->second.wsrd && c2->second.wsrd && a3->second.w32 &&
             a1->second.w32 && a3->second.watt && a1->second.watt && a3->second.def.kd == 3 && a1->second.def.kd == 1 &&
             x.H % sty == 0 && x.W % stx == 0 && x.H % 2 == 0 && (int64_t)x.B * (x.H / sty) * (x.W / stx) >= r.sw.roll_min_units &&
@@ -2362,7 +2416,7 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     // (on side stream 0 next to dres0 / deconv_1 below 16M stack pixels: two 1/8-resolution convs and a regression head that
     // nothing else waits for -- measured +2.7 % at batch 1, +2.3 % at batch 8, -0.3 % at batch 32 where dres0 fills the chip)
     RegressQueue rq;
-    const bool merge_heads = !r.sw.on(SW_NO_REGRESS_MERGE);
+    const bool merge_heads = true;   // (DFFW_NO_REGRESS_MERGE retired in round 5: one launch per head lost the A/B of rounds 3 and 4)
     const int h8 = H / 8, w8 = W / 8;
     float *conf = (float *)r.raw((int64_t)B * N * h8 * w8 * sizeof(float));
     const bool conf_side = r.concurrent && (int64_t)B * N * H * W < (16 << 20) && !r.sw.on(SW_NO_CONF_FORK);

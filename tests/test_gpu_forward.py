@@ -323,7 +323,7 @@ def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monk
     model = model_for(sd, (meta["wseed"], meta["profile"]))
     with torch.no_grad():
         base = [o.clone() for o in model(FS.cuda(), fd.cuda())]
-        for env, val in (("DFFW_NO_LEAN_TILE", "1"), ("DFFW_NO_LEAN_ROLL", "1"), ("DFFW_NO_REGRESS_MERGE", "1"), ("DFFW_NO_REGRESS_FUSED", "1"), ("DFFW_NO_STEM_PIPE", "1"), ("DFFW_NO_POOL3", "1"), ("DFFW_WARM_MAX_WGS", "0")):
+        for env, val in (("DFFW_NO_LEAN_TILE", "1"), ("DFFW_NO_LEAN_ROLL", "1"), ("DFFW_NO_REGRESS_FUSED", "1"), ("DFFW_NO_STEM_PIPE", "1"), ("DFFW_NO_POOL3", "1"), ("DFFW_WARM_MAX_WGS", "0")):
             monkeypatch.setenv(env, val)
             alt = model(FS.cuda(), fd.cuda())
             torch.cuda.synchronize()
@@ -333,19 +333,20 @@ def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monk
 
 
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK", "DFFW_NO_SMALL", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
-                                 "DFFW_NO_CG32", "DFFW_NO_WIDE", "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR",
-                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_REGRESS_MERGE", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE"])
+                                 "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR",
+                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_SLICE32", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback
     (conv_igemm, DFFW_NO_TILE), the un-split
-    few-tile launches, the unfused attention convs / pooling, the narrow (4-wave, 16-channel-stage) tile variants, conv_tile on its
-    generic epilogue (DFFW_NO_LEAN_TILE) and one regression launch per head (DFFW_NO_REGRESS_MERGE)."""
+    few-tile launches, the unfused attention convs / pooling, conv_tile on its generic epilogue (DFFW_NO_LEAN_TILE), conv_tile instead of
+    the K-split rolling window (DFFW_NO_ROLLK).  (Round 5 retired the switches whose alternative had lost every A/B for two rounds or more:
+    DFFW_NO_CG32, DFFW_NO_WIDE, DFFW_NO_REGRESS_MERGE and the untested pack-time ones.)"""
     path = [p for p in GOLDEN if which in p][0]
     g, meta, FS, fd, sd = case(path)
     model = model_for(sd, (meta["wseed"], meta["profile"]))
     monkeypatch.setenv(env, "1")
-    model.invalidate()                 # DFFW_NO_CG32 / DFFW_NO_WIDE pick the kernel variant when the weights are packed
+    model.invalidate()                 # (DFFW_NO_STEM_PAIR is read when the weights are packed)
     with torch.no_grad():
         outs = model(FS.cuda(), fd.cuda())
     torch.cuda.synchronize()
