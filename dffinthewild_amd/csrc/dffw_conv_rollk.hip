@@ -240,6 +240,10 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
 
     int sidx = RING - 1;                  // ring slot of the window's first slice = global step - 1 (the stream's slices sit in consecutive slots)
     f32x4 mine0 = {0.f, 0.f, 0.f, 0.f}, mine1 = {0.f, 0.f, 0.f, 0.f};   // this wave's own partial of the unit it owns in half-step 0 / 1
+    // partial columns at the volume's bottom / right edge (H or W not a multiple of 8: the 1/8-resolution volumes of 480 x 640 stacks): the fill's
+    // range check zero-pads them, the epilogue's store (and residual read) is predicated on the lane's pixel lying inside: pv0 / pv1 for the unit
+    // this wave owns in half-step 0 / 1 of the current column, ppv1 = pv1 of the step before (another column at a column change)
+    int pv0 = 1, pv1 = 1, ppv1 = 1;
     char *pptr = nullptr;                 // where the previous step's output slice starts (wave-uniform)
     const char *rptr = nullptr;           // ... and its residual slice
 
@@ -275,7 +279,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     // the ring slot holds.  FIN: this wave finishes the unit it owns in the PREVIOUS half-step (partials in exchange buffer h ^ 1, its own in
     // `mine`), output slice at optr_f / residual slice at rptr_f.  LAST: the step ends with this half-step.
     auto half = [&](auto H_, auto LIVE_, auto FIN_, auto LAST_, auto PRE_, const bool nofront, const bool noback, const f32x4 &mine, char *optr_f,
-                    const char *rptr_f, int vob_f, f32x4 &mine_out) {
+                    const char *rptr_f, int vob_f, int pv_f, f32x4 &mine_out) {
         constexpr int h = decltype(H_)::value;
         constexpr bool LIVE = decltype(LIVE_)::value, FIN = decltype(FIN_)::value, LAST = decltype(LAST_)::value, PRE = decltype(PRE_)::value;
         // the partials of my unit come in two batches (at most 4 + 3: 16 registers instead of 28), each requested behind a chunk's operands
@@ -284,7 +288,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         f32x4 part[NPA ? NPA : 1];
         u32x4 rq = {0, 0, 0, 0};
         if constexpr (FIN && RES) {
-            const char *rp = rptr_f + (uint32_t)(vob_f * 2);
+            const char *rp = rptr_f + (uint32_t)(pv_f ? vob_f * 2 : 0);   // (a lane outside the volume reads the column's first pixel instead: always inside)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq) : "v"(rp) : "memory");
         }
         f32x4 v = zero4;
@@ -316,7 +320,9 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
             if constexpr (FIN) {
                 if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq)::"memory");
                 uint4 rq4 = make_uint4(rq[0], rq[1], rq[2], rq[3]);
-                if constexpr (!(ABL & 32)) (void)epilogue_lean<P_BF16X3, RES, false>(reinterpret_cast<uint16_t *>(optr_f), nullptr, vob_f, v, rq4, RELU, zero4);
+                float cls = 0.f;
+                if constexpr (!(ABL & 32))
+                    epilogue_lean_t<P_BF16X3>(reinterpret_cast<uint16_t *>(optr_f), nullptr, vob_f, v[0], v[1], v[2], v[3], RES, rq4, RELU, false, zero4, cls, pv_f != 0);
                 else asm volatile("" ::"v"(v), "v"(rq4.x));
             }
         };
@@ -462,15 +468,16 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         f32x4 dummy;
         if constexpr (LIVE) {
             // (a live step behind a live step finds its chunk 0 requested by that step's second half-step)
-            half(I0{}, T{}, std::integral_constant<bool, PEND && OWN1>{}, F{}, std::integral_constant<bool, PEND>{}, nofront, noback, mine1, pptr, rptr, vob1, OWN0 ? mine0 : dummy);
-            half(I1{}, T{}, std::integral_constant<bool, OWN0>{}, T{}, T{}, nofront, noback, mine0, optr, rp, vob0, OWN1 ? mine1 : dummy);
+            half(I0{}, T{}, std::integral_constant<bool, PEND && OWN1>{}, F{}, std::integral_constant<bool, PEND>{}, nofront, noback, mine1, pptr, rptr, vob1, ppv1, OWN0 ? mine0 : dummy);
+            half(I1{}, T{}, std::integral_constant<bool, OWN0>{}, T{}, T{}, nofront, noback, mine0, optr, rp, vob0, pv0, OWN1 ? mine1 : dummy);
         } else {
-            half(I0{}, F{}, std::integral_constant<bool, PEND && OWN1>{}, T{}, F{}, false, false, mine1, pptr, rptr, vob1, dummy);
+            half(I0{}, F{}, std::integral_constant<bool, PEND && OWN1>{}, T{}, F{}, false, false, mine1, pptr, rptr, vob1, ppv1, dummy);
         }
         sidx = (sidx + 1) & (RING - 1);
         advance_fill();
         pptr = optr;
         rptr = rp;
+        ppv1 = pv1;
     };
     auto dispatch = [&](bool live, bool pend, bool nofront, bool noback, char *optr, const char *rp) {
         using T = std::true_type;
@@ -492,6 +499,11 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         // Step st of the unit's ns input slices contracts the window centred on its slice st = output slice st - h0 (h0: the unit has a halo slice
         // in front, i.e. its range starts inside the volume): a range that starts / ends inside the volume costs a dead step there, one that
         // reaches the volume's end none -- a unit that covers all slices is ns live steps.
+        {
+            const int col = U.gx0 + (r & 7), row = U.gy0 + (myu >> 1) + 4 * (r >> 3);
+            pv0 = (col < a.Wo && row < a.Ho) ? 1 : 0;
+            pv1 = (col < a.Wo && row + 2 < a.Ho) ? 1 : 0;
+        }
         const int zlo = U.zbeg > 0 ? U.zbeg - 1 : 0, h0 = U.zbeg - zlo;
         const int ns = (U.zbeg + U.nz < a.Ni ? U.zbeg + U.nz : a.Ni - 1) - zlo + 1;
         char *optr = reinterpret_cast<char *>(a.out) + o0 - (int64_t)h0 * ostride;
@@ -542,7 +554,6 @@ int rollk_waves(int prec, const ConvArgs &a) {
     const int cin = a.C0 + a.C1;
     if (cin != 32 && cin != 64) return 0;
     if (a.C1 && a.C1 != a.C0) return 0;
-    if (a.Ho % rollk::TY || a.Wo % rollk::TX) return 0;
     // 32-bit buffer offsets: a sample's input volume (+ one footprint) stays below 2^31 bytes
     const int64_t recb = (int64_t)a.C0 * 4;
     if ((int64_t)(a.Ni + 1) * a.Hi * a.Wi * recb >= (1ll << 31)) return 0;

@@ -39,8 +39,12 @@ constexpr int LDSB = RING * SLOTB;
 static_assert(CQE % 16 == 0 && SLOTB % 256 == 0 && 2 * LDSB <= 160 * 1024, "LDS layout (two workgroups per CU)");
 }   // namespace slice32
 
-template <bool RELU, bool RES>
+// SUMS: the row-sums variant (third conv of an alignment head, End_to_End.py:41-46, whose ReLU'd result only feeds the head's last conv + plane mean
+// = plane sums): nothing is stored but, per output row segment of 16 pixels, its sum and its first and last pixel -- conv_tile's row-sums epilogue,
+// same layout: a.outf[((plane * Ho + y) * tiles_x + tile column) * 3 + {sum, first, last}][32] fp32 (an operand tile here is such a row segment)
+template <bool RELU, bool RES, bool SUMS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice32(const ConvArgs a, const RollArgs t) {
+    static_assert(!SUMS || (RELU && !RES), "row sums: relu(acc), no residual");
     using namespace slice32;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
     const int lane = threadIdx.x & 63;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int sidxb = 0;                        // byte offset of the ring slot of the slice being contracted
     // One slice.  PAR: parity of the stream position (selects the fragment buffers); PRE: its chunk 0 was requested by the slice in front.
-    auto step = [&](auto PAR_, auto PRE_, char *optr, const char *rptr) __attribute__((always_inline)) {
+    auto step = [&](auto PAR_, auto PRE_, char *optr, const char *rptr, float *srow) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PAR_)::value;
         constexpr bool PRE = decltype(PRE_)::value;
         // the slice two ahead goes into the slot the previous step left
@@ -220,17 +224,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         });
         // epilogue of the wave's four result tiles
         if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
+        if constexpr (!SUMS) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const uint4 q4 = make_uint4(rq[j][nt][0], rq[j][nt][1], rq[j][nt][2], rq[j][nt][3]);
-                (void)epilogue_lean<P_BF16X3, RES, false>(reinterpret_cast<uint16_t *>(optr), nullptr, vob[j][nt], n[j * 2 + nt], q4, RELU, zero4);
-                __builtin_amdgcn_sched_barrier(0);   // (one tile's epilogue at a time: interleaved, the four need their temporaries at once)
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint4 q4 = make_uint4(rq[j][nt][0], rq[j][nt][1], rq[j][nt][2], rq[j][nt][3]);
+                    (void)epilogue_lean<P_BF16X3, RES, false>(reinterpret_cast<uint16_t *>(optr), nullptr, vob[j][nt], n[j * 2 + nt], q4, RELU, zero4);
+                    __builtin_amdgcn_sched_barrier(0);   // (one tile's epilogue at a time: interleaved, the four need their temporaries at once)
+                }
+        } else {
+            // lane (g, r) holds channels 4g .. 4g + 3 of pixel r of its row segment: sums over the 16 lanes of a row by DPP (quad xor 1, xor 2,
+            // half-row mirror, row mirror); lanes r = 0 / r = 15 are the segment's first / last pixel
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float *rp = srow + ((int64_t)(2 * wave + j) * t.tiles_x * 3) * 32 + g * 4;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 v, rs;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = relu_bits(n[j * 2 + nt][i]);
+                        float q = v[i];
+                        q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                        q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                        q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                        q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x140, 0xF, 0xF, true));   // row_mirror
+                        rs[i] = q;
+                    }
+                    if (r == 0) {
+                        *reinterpret_cast<f32x4 *>(rp + nt * 16) = rs;
+                        *reinterpret_cast<f32x4 *>(rp + 32 + nt * 16) = v;
+                    }
+                    if (r == 15) *reinterpret_cast<f32x4 *>(rp + 64 + nt * 16) = v;
+                }
             }
+        }
         // the slice queued in this step (and everything older) has landed; this step's four stores may stay in flight across the barrier.  All
         // waves are done reading this slice's slot: the step after the next one refills it.
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SUMS ? 0 : 4) : "memory");   // (row sums: masked stores whose count the compiler owns -- wait for them too)
         {
             constexpr int nb = (PAR + NCH) & 1;
             asm volatile("" : "+v"(x[nb][0][0]), "+v"(x[nb][0][1]), "+v"(x[nb][1][0]), "+v"(x[nb][1][1]));
@@ -240,25 +272,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     const int64_t ostride = (int64_t)a.Ho * a.Wo * 128;   // bytes per output slice (32 channels, hi + lo)
+    const int64_t sstride = (int64_t)a.Ho * t.tiles_x * 3 * 32;   // row-sum floats per slice
     int par = 0;
     bool first = true;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         const int64_t o0 = (((int64_t)U.b * a.No * a.Ho + U.gy0) * a.Wo + U.gx0) * 128;
-        char *optr = reinterpret_cast<char *>(a.out) + o0;
+        char *optr = SUMS ? nullptr : reinterpret_cast<char *>(a.out) + o0;
         const char *rp = RES ? reinterpret_cast<const char *>(a.res0) + o0 : nullptr;
+        float *sp = SUMS ? a.outf + (((int64_t)U.b * a.No * a.Ho + U.gy0) * t.tiles_x + U.gx0 / TX) * 3 * 32 : nullptr;
         for (int z = 0; z < a.No; ++z) {
             using T = std::true_type;
             using F = std::false_type;
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
-            if (first) step(I0{}, F{}, optr, rp);
-            else if (par) step(I1{}, T{}, optr, rp);
-            else step(I0{}, T{}, optr, rp);
+            if (first) step(I0{}, F{}, optr, rp, sp);
+            else if (par) step(I1{}, T{}, optr, rp, sp);
+            else step(I0{}, T{}, optr, rp, sp);
             first = false;
             par ^= 1;
-            optr += ostride;
+            if (!SUMS) optr += ostride;
             if (RES) rp += ostride;
+            if (SUMS) sp += sstride;
         }
     }
     // the slices queued past the end of the stream are still in flight: a wave must not retire before its LDS-DMA has landed
@@ -272,7 +307,10 @@ void slice32_tile(int *ty, int *tx) {
 
 bool slice32_ok(int prec, const ConvArgs &a) {
     if (prec != P_BF16X3 || (a.dbg & DFFW_ARGS_NO_SLICE32)) return false;
-    if (!a.out || a.out_pre || a.outf || a.res1 || a.res_bcast || a.cls_w || a.relu == 2 || a.Cout != 32 || a.C0 != 32 || a.C1 != 0) return false;
+    if (a.dbg & DFFW_ARGS_SUMS) {   // row-sums variant: nothing stored, a.outf receives the row vectors
+        if (!a.outf || a.relu != 1 || a.res0) return false;
+    } else if (!a.out || a.outf) return false;
+    if (a.out_pre || a.res1 || a.res_bcast || a.cls_w || a.relu == 2 || a.Cout != 32 || a.C0 != 32 || a.C1 != 0) return false;
     if (a.Ho % slice32::TY || a.Wo % slice32::TX || a.Ho != a.Hi || a.Wo != a.Wi || a.No != a.Ni) return false;
     // 32-bit buffer offsets: a sample's input volume (+ one footprint) stays below 2^31 bytes
     return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * 128 < (1ll << 31);
@@ -283,7 +321,8 @@ hipError_t launch_conv_slice32(const ConvArgs &a, const RollArgs &t, hipStream_t
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(slice32::NW * 64);
     const bool relu = a.relu == 1, res = a.res0 != nullptr;
-    if (relu && res) hipLaunchKernelGGL((conv_slice32<true, true>), grid, block, 0, s, a, t);
+    if (a.dbg & DFFW_ARGS_SUMS) hipLaunchKernelGGL((conv_slice32<true, false, true>), grid, block, 0, s, a, t);
+    else if (relu && res) hipLaunchKernelGGL((conv_slice32<true, true>), grid, block, 0, s, a, t);
     else if (relu) hipLaunchKernelGGL((conv_slice32<true, false>), grid, block, 0, s, a, t);
     else if (res) hipLaunchKernelGGL((conv_slice32<false, true>), grid, block, 0, s, a, t);
     else hipLaunchKernelGGL((conv_slice32<false, false>), grid, block, 0, s, a, t);
@@ -291,7 +330,8 @@ hipError_t launch_conv_slice32(const ConvArgs &a, const RollArgs &t, hipStream_t
 }
 
 void conv_slice32_kernel_name(const ConvArgs &a, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_slice32<%s, %s>", a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false");
+    if (a.dbg & DFFW_ARGS_SUMS) snprintf(buf, n, "dffw::conv_slice32<true, false, true>");
+    else snprintf(buf, n, "dffw::conv_slice32<%s, %s>", a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false");
 }
 
 }  // namespace dffw

@@ -1708,7 +1708,7 @@ struct Run {
             }
         }
         // per-slice 1x3x3, 32 -> 32 channels on whole 8 x 16 columns: the streaming kernel with the filter resident in every wave
-        if (pc.wslice32 && !o.in1 && !o.sums && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_SLICE32)) {
+        if (pc.wslice32 && !o.in1 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_SLICE32)) {
             int sty, stx;
             slice32_tile(&sty, &stx);
             const int cols = (Ho / sty) * (Wo / stx);
@@ -1730,7 +1730,8 @@ struct Run {
                 g_last_kernel = kn;
                 if (e->profiling) {
                     const double opx = (double)out.B * No * Ho * Wo;
-                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout * elem_bytes() * (1 + (o.res0 ? 1 : 0)) + 9.0 * L.cin * L.cout * elem_bytes();
+                    const double obytes = o.sums ? opx / 16.0 * 3.0 * L.cout * 4.0 : opx * L.cout * elem_bytes() * (1 + (o.res0 ? 1 : 0));
+                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + obytes + 9.0 * L.cin * L.cout * elem_bytes();
                     prof_begin(kn, name, 2.0 * opx * 9.0 * L.cin * L.cout, bytes);
                 }
                 check(launch_conv_slice32(ak, t, s), name.c_str());
@@ -1742,19 +1743,19 @@ struct Run {
         if (pc.wrollk && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLLK)) {
             int kty, ktx;
             rollk_tile(&kty, &ktx);
-            const int cols = (Ho / kty) * (Wo / ktx);
+            const int cols = ((Ho + kty - 1) / kty) * ((Wo + ktx - 1) / ktx);   // (partial columns at the bottom / right edge are predicated in the kernel)
             ConvArgs ak = a;
             ak.Ng = No; ak.Hg = Ho; ak.Wg = Wo;
             ak.M = (int64_t)ak.B * No * Ho * Wo;
-            if (Ho % kty == 0 && Wo % ktx == 0 && (int64_t)in0.B * cols >= sw.roll_min_units && rollk_waves(e->prec, ak) == cin_pad / 8) {
+            if ((int64_t)in0.B * cols >= sw.roll_min_units && rollk_waves(e->prec, ak) == cin_pad / 8) {
                 if (dry) return out;
                 const int npair = L.cout / 32;
                 for (int op = 0; op < npair; ++op) {
                     RollArgs t;
                     memset(&t, 0, sizeof t);
                     t.wroll = pc.wrollk + (size_t)op * (cin_pad / 8) * ROLLK_CHUNKS * 2 * prec_parts(e->prec) * 512;
-                    t.tiles_y = Ho / kty;
-                    t.tiles_x = Wo / ktx;
+                    t.tiles_y = (Ho + kty - 1) / kty;
+                    t.tiles_x = (Wo + ktx - 1) / ktx;
                     t.zsplit = ((int64_t)in0.B * cols < 512 && No >= 8) ? 2 : 1;
                     if (sw.roll_zsplit >= 1 && sw.roll_zsplit <= No) t.zsplit = sw.roll_zsplit;
                     t.total_tiles = in0.B * t.zsplit * cols;

@@ -288,8 +288,14 @@ def test_hip_e2e_head_tail_as_plane_sums(lib_built, monkeypatch, B, H, W, precis
             h, w = H // div, W // div
             want = w % 16 == 0 and B * 2 * ((h + 3) // 4) * (w // 16) >= 256
             got = [k for k, layer in prof if layer.endswith(lvl + ".4.0")]
-            # conv_tile<prec, geo, NT, TZ, TY, TX, CG, pipe, waves, SPLITK (= row-sums variant for this geometry), LEAN>
-            assert len(got) == 1 and (got[0].rstrip(">").split(", ")[9] == "true") == want, (lvl, got, want)
+            # conv_tile<prec, geo, NT, TZ, TY, TX, CG, pipe, waves, SPLITK (= row-sums variant for this geometry), LEAN>, or -- the 32-channel level-2
+            # head on whole 8 x 16 columns -- conv_slice32<RELU, RES, SUMS>
+            assert len(got) == 1, (lvl, got)
+            if got[0].startswith("dffw::conv_slice32<"):
+                is_sums = got[0].endswith(", true>") and got[0].count(",") == 2
+            else:
+                is_sums = got[0].rstrip(">").split(", ")[9] == "true"
+            assert is_sums == want, (lvl, got, want)
         monkeypatch.setenv("DFFW_NO_HEAD_SUMS_FUSED", "1")
         with torch.no_grad():
             outs3, taps3 = _model(sd, precision).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)

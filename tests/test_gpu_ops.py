@@ -254,13 +254,14 @@ def test_conv_slice32(eng, B, N, H, W, wgs, relu, residual, monkeypatch):
 
 @pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64)])
 @pytest.mark.parametrize("N,H,W,zsplit,wgs,relu,residual", [(10, 64, 64, 1, 0, 1, False), (1, 32, 64, 1, 8, 1, True), (7, 64, 32, 3, 24, 0, True), (2, 40, 24, 2, 16, 1, False),
-                                                            (3, 64, 64, 3, 8, 0, False), (5, 8, 8, 1, 0, 1, True)])
+                                                            (3, 64, 64, 3, 8, 0, False), (5, 8, 8, 1, 0, 1, True), (3, 60, 80, 1, 0, 1, True), (4, 28, 36, 2, 8, 1, False)])
 def test_conv_rollk(eng, cin, cout, N, H, W, zsplit, wgs, relu, residual, monkeypatch):
     """conv_rollk (dffw_conv_rollk.hip): 3x3x3 stride 1, 32 / 64 -> 32 / 64 channels (`dres2.conv0`, `dres0.*`, `dres2.conv2`, `dres3.conv2/4`, the
     pyramid's `dres8_*`, `confidence.0`; DEN.py:33-40,155-192,243-258) as a rolling window over 8 x 8 columns with the contraction split over
     the workgroup's waves (filter resident in registers, partial sums exchanged through LDS per half-step; 64 outputs = two launches): every
-    slice count incl. 1 and 2, split slice ranges, one column per workgroup and long streams, a single 8 x 8 column per sample, ReLU and
-    residual on and off; against F.conv3d and against conv_tile on the same input (DFFW_NO_ROLLK)."""
+    slice count incl. 1 and 2, split slice ranges, one column per workgroup and long streams, a single 8 x 8 column per sample, partial columns at
+    the bottom / right edge (60 x 80: the 1/8-resolution volume of a 480 x 640 stack; 28 x 36), ReLU and residual on and off; against F.conv3d and
+    against conv_tile on the same input (DFFW_NO_ROLLK)."""
     B = 3
     x = rnd(B, cin, N, H, W, seed=61)
     w = rnd(cout, cin, 3, 3, 3, seed=62, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
