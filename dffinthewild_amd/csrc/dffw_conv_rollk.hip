@@ -607,7 +607,8 @@ hipError_t launch_conv_rollk(const ConvArgs &a, const RollArgs &t, hipStream_t s
 }
 
 void conv_rollk_kernel_name(const ConvArgs &a, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_rollk<%d, %s, %s>", (a.C0 + a.C1) / 8, a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false");
+    // (rocprofv3's spelling, defaulted template arguments included: tools/hbm_traffic.py and the PMC summaries match kernels by name)
+    snprintf(buf, n, "dffw::conv_rollk<%d, %s, %s, 0, %d>", (a.C0 + a.C1) / 8, a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false", DFFW_ROLLK_SKEW);
 }
 
 }  // namespace dffw

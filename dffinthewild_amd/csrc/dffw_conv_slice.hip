@@ -331,7 +331,7 @@ hipError_t launch_conv_slice32(const ConvArgs &a, const RollArgs &t, hipStream_t
 
 void conv_slice32_kernel_name(const ConvArgs &a, char *buf, int n) {
     if (a.dbg & DFFW_ARGS_SUMS) snprintf(buf, n, "dffw::conv_slice32<true, false, true>");
-    else snprintf(buf, n, "dffw::conv_slice32<%s, %s>", a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false");
+    else snprintf(buf, n, "dffw::conv_slice32<%s, %s, false>", a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false");   // (rocprofv3's spelling)
 }
 
 }  // namespace dffw

@@ -292,7 +292,7 @@ def test_hip_e2e_head_tail_as_plane_sums(lib_built, monkeypatch, B, H, W, precis
             # head on whole 8 x 16 columns -- conv_slice32<RELU, RES, SUMS>
             assert len(got) == 1, (lvl, got)
             if got[0].startswith("dffw::conv_slice32<"):
-                is_sums = got[0].endswith(", true>") and got[0].count(",") == 2
+                is_sums = got[0].endswith(", true>")          # conv_slice32<RELU, RES, SUMS>
             else:
                 is_sums = got[0].rstrip(">").split(", ")[9] == "true"
             assert is_sums == want, (lvl, got, want)
