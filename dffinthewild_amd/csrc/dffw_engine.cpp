@@ -1222,7 +1222,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, warm_max_wgs = 1024;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1244,6 +1244,7 @@ struct Switches {
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
+        s.narrow_max = geti("DFFW_NARROW_MAX", 1, 40);   // widest grid that may take the 5 x 8 x 8 block when its own block leaves the chip short of workgroups (8 = round 4)
         // conv_tile launches of at most this many (tile, channel-split) workgroups touch the weight lines of their whole contraction walk first
         // (TileArgs::warm; 0: never).  Measured r03 on 10x256x256 stacks, ms per forward at 0 / 256 / 1024 / always: batch 2 1.29 / 1.17 / 1.17 /
         // 1.17, batch 8 2.74 / 2.65 / 2.63 / 2.63, batch 16 4.71 / 4.66 / 4.62 / 4.66, batch 32 8.58 / 8.57 / 8.57 / 8.70
@@ -1667,12 +1668,20 @@ struct Run {
                                !sw.on(SW_NO_STEM_PAIR);
         if (stem_pair) a.bias = pc.bias_pair;
         const int gW = L.transposed ? in0.W : Wo, gH = L.transposed ? in0.H : Ho;
-        // grids at most 8 x 8 (the 1/32-resolution pyramid layers at 256 x 256) with enough samples to fill the chip: the 5 x 8 x 8 block
-        // (its packs of layers with more than 4 output tiles split the output channels over grid.y: not with a fused classifier, whose partial
-        // dot spans all of a pixel's channels, nor under DFFW_NO_SPLIT)
+        // the 5 x 8 x 8 block (its packs of layers with more than 4 output tiles split the output channels over grid.y: not with a fused classifier,
+        // whose partial dot spans all of a pixel's channels, nor under DFFW_NO_SPLIT), with enough samples / tiles to fill the chip:
+        // (a) grids at most 8 x 8 (the 1/32-resolution pyramid layers at 256 x 256, round 4);  (b) round 5: stride-1 layers with 128 output channels on grids up to
+        // DFFW_NARROW_MAX (40) wide whose launch on the layer's own block would be fewer than 256 workgroups -- End_to_End's 15 x 20 and
+        // 30 x 40 pyramid levels at batch 8: `combine2` ran as 96 workgroups of 128 output channels each (0.24 -> 0.13 ms, `conv4` 0.16 -> 0.09; the 64-output layers of those levels gain 2-8 % on it at that shape and lose as much at others: left alone)
         const bool narrow_splits = pc.tile_narrow.cfg && pc.nt > pc.tile_narrow.cfg->nt;
-        const bool narrow = !stem_pair && pc.tile_narrow.cfg && gW <= 8 && gH <= 8 && !sw.on(SW_NO_NARROW) && !(narrow_splits && (o.cls || sw.on(SW_NO_SPLIT))) &&
-                            (int64_t)in0.B * (((L.transposed ? in0.N : No) + 4) / 5) * pc.nt >= 256;
+        const int gN = L.transposed ? in0.N : No;
+        bool narrow = !stem_pair && pc.tile_narrow.cfg && !sw.on(SW_NO_NARROW) && !(narrow_splits && (o.cls || sw.on(SW_NO_SPLIT))) &&
+                      (int64_t)in0.B * ((gN + 4) / 5) * ((gH + 7) / 8) * ((gW + 7) / 8) * pc.nt >= 256;
+        if (narrow && !(gW <= 8 && gH <= 8)) {
+            const TileCfg *mc = pc.tile.cfg;
+            const int64_t main_wgs = mc ? (int64_t)in0.B * ((gN + mc->tz - 1) / mc->tz) * ((gH + mc->ty - 1) / mc->ty) * ((gW + mc->tx - 1) / mc->tx) : 0;
+            narrow = !L.transposed && pc.nt >= 8 && gW <= sw.narrow_max && gH <= sw.narrow_max && mc && main_wgs < 256;
+        }
         const TilePack &tp = stem_pair ? pc.tile_pair : (narrow ? pc.tile_narrow : pc.tile);
         // 32 -> 16 channels on whole 8 x 16 columns: the pipelined rolling window with the contraction split over the two input halves
         {
