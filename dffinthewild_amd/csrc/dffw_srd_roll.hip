@@ -1185,6 +1185,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// one operand fragment (hi [+ lo] plane) of an of_roll tile, and the counted wait that releases it (DS operations retire in order: `left` =
+// operations requested after it that may still be in flight; the "+v" ties keep the MFMAs behind the wait)
+template <int PARTS, int LOB>
+__device__ __forceinline__ void of_read(unsigned ad, short8 &h, short8 &l) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(h) : "v"(ad));
+    if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(l) : "v"(ad), "n"(LOB));
+}
+template <int PARTS>
+__device__ __forceinline__ void of_wait(int left, short8 &h, short8 &l) {
+    if constexpr (PARTS == 1) {
+        (void)l;
+        if (left >= 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(h));
+        else if (left >= 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(h));
+        else if (left >= 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(h));
+        else if (left >= 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(h));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h));
+        return;
+    }
+    if (left >= 10) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(h), "+v"(l));
+    else if (left >= 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(h), "+v"(l));
+    else if (left >= 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(h), "+v"(l));
+    else if (left >= 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(h), "+v"(l));
+    else if (left >= 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(h), "+v"(l));
+    else if (left >= 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(h), "+v"(l));
+    else if (left >= 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(h), "+v"(l));
+    else if (left >= 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(h), "+v"(l));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h), "+v"(l));
+}
+
 // ---- of_roll: a stride-1 residual block of the alignment network (End_to_End.py:135-145, `OF_feature.0`, `OF_feature.1`) -------
 //     out = relu( conv1x1x1(x) + BN(conv1x3x3(relu(BN(conv1x3x3(x))))) ),   8 (3 real) or 16 -> 16 channels, full resolution
 // As two launches t = relu(BN(conv(x))) went through HBM and the second conv re-read x for the folded shortcut (two 16-channel
@@ -1338,36 +1367,6 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
         for (int pt = 0; pt < PARTS; ++pt) w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
     const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);
     const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
-    // contraction of one operand tile: chunk k reads at base + tapo[k]; inline-asm LDS reads with counted waits (see srd_roll)
-    auto tile_mma5 = [&](unsigned base, const int *tapo, auto loB_c, const short8 (*wf)[PARTS], f32x4 acc, auto nctag) {
-        constexpr int NC = decltype(nctag)::value, loB = decltype(loB_c)::value;   // the lo plane as an immediate of the read
-        short8 xh[NC], xl[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const unsigned ad = base + tapo[k];
-            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
-            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(ad), "n"(loB));
-            else xl[k] = xh[k];
-        }
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const int left = (NC - 1 - k) * PARTS;
-            if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xh[k]), "+v"(xl[k]));
-            else if (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xh[k]), "+v"(xl[k]));
-            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xh[k]), "+v"(xl[k]));
-            else if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xh[k]), "+v"(xl[k]));
-            else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xh[k]), "+v"(xl[k]));
-            else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xh[k]), "+v"(xl[k]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[k]), "+v"(xl[k]));
-            if constexpr (PARTS == 2) {
-                acc = mma<F16>(wf[k][1], xh[k], acc);
-                acc = mma<F16>(wf[k][0], xl[k], acc);
-            }
-            acc = mma<F16>(wf[k][0], xh[k], acc);
-        }
-        return acc;
-    };
-
     constexpr int INFLIGHT = (RX - 2) * PPW;
 #pragma unroll
     for (int q = 0; q < RX - 1; ++q) issue_next();
@@ -1382,9 +1381,26 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(INFLIGHT) : "memory");
             const unsigned xs = lds0 + X_OFF + xslot * SLOTB;
             // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image (conv.2's padding) ------------
+            // operand reads run one tile ahead: chunk k of tile j+1 is requested as soon as chunk k of tile j has been contracted (into the same
+            // registers), so only the stage's first tile waits for the LDS.  DS operations retire in order: behind the reads of (j, k) there are
+            // the 2 (NC-1-k) reads of the tile's later chunks, the 2k already requested for tile j+1 and at most the 2 stores of tile j-1's
+            // epilogue -- lgkmcnt(2 (NC-1)) covers (j, k) whether or not the stores were issued.
+            short8 fxh[NCHB + 1], fxl[NCHB + 1];
+#pragma unroll
+            for (int k = 0; k < NCHA; ++k) of_read<PARTS, PLANEB>(xs + pa[0] + tapA[k], fxh[k], fxl[k]);
 #pragma unroll
             for (int j = 0; j < TA; ++j) {
-                const f32x4 acc = tile_mma5(xs + pa[j], tapA, std::integral_constant<int, PLANEB>{}, w0, b0, std::integral_constant<int, NCHA>{});
+                f32x4 acc = b0;
+#pragma unroll
+                for (int k = 0; k < NCHA; ++k) {
+                    of_wait<PARTS>(j + 1 < TA ? (NCHA - 1) * PARTS : (NCHA - 1 - k) * PARTS, fxh[k], fxl[k]);
+                    if constexpr (PARTS == 2) {
+                        acc = mma<F16>(w0[k][1], fxh[k], acc);
+                        acc = mma<F16>(w0[k][0], fxl[k], acc);
+                    }
+                    acc = mma<F16>(w0[k][0], fxh[k], acc);
+                    if (j + 1 < TA) of_read<PARTS, PLANEB>(xs + pa[j + 1] + tapA[k], fxh[k], fxl[k]);
+                }
                 const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
                 const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (ta_ok[j]) {
@@ -1398,21 +1414,26 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // ---- stage B: out = relu(conv.2(t) + shift + shortcut(x)) -----------------------------------------------------------
             f32x4 sum_t = {0.f, 0.f, 0.f, 0.f}, sum_c = sum_t;   // SUMS only
+            // (chunk NCHB = the shortcut chunk: centre pixel of x, its channel octets as K octets -- weights of absent octets are zeros; reads one
+            // tile ahead as in stage A: 2 NCHB operations behind the reads of (j, k), no DS stores in this stage)
+#pragma unroll
+            for (int k = 0; k < NCHB; ++k) of_read<PARTS, TPLANEB>(lds0 + T_OFF + pbo[0] + tapB[k], fxh[k], fxl[k]);
+            of_read<PARTS, PLANEB>(xs + pbx[0], fxh[NCHB], fxl[NCHB]);
 #pragma unroll
             for (int j = 0; j < TB; ++j) {
-                f32x4 acc = tile_mma5(lds0 + T_OFF + pbo[j], tapB, std::integral_constant<int, TPLANEB>{}, w2, b2, std::integral_constant<int, NCHB>{});
-                {   // the shortcut chunk: centre pixel of x, its channel octets as K octets (weights of absent octets are zeros)
-                    short8 sh, sl;
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(sh) : "v"(xs + pbx[j]));
+                f32x4 acc = b2;
+#pragma unroll
+                for (int k = 0; k <= NCHB; ++k) {
+                    of_wait<PARTS>(j + 1 < TB ? NCHB * PARTS : (NCHB - k) * PARTS, fxh[k], fxl[k]);
                     if constexpr (PARTS == 2) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sl) : "v"(xs + pbx[j]), "n"(PLANEB));
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh), "+v"(sl));
-                        acc = mma<F16>(w2[NCHB][1], sh, acc);
-                        acc = mma<F16>(w2[NCHB][0], sl, acc);
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh));
+                        acc = mma<F16>(w2[k][1], fxh[k], acc);
+                        acc = mma<F16>(w2[k][0], fxl[k], acc);
                     }
-                    acc = mma<F16>(w2[NCHB][0], sh, acc);
+                    acc = mma<F16>(w2[k][0], fxh[k], acc);
+                    if (j + 1 < TB) {
+                        if (k < NCHB) of_read<PARTS, TPLANEB>(lds0 + T_OFF + pbo[j + 1] + tapB[k], fxh[k], fxl[k]);
+                        else of_read<PARTS, PLANEB>(xs + pbx[j + 1], fxh[k], fxl[k]);
+                    }
                 }
                 if constexpr (SUMS) {
                     // this lane: channels 4g..4g+3 of pixel (row 2*wave + j, column r).  Row sums over the 16 lanes of the row group by

@@ -1,5 +1,6 @@
 """A/B of selected layers on one box with run-to-run statistics: REPS profiled forwards per variant in ABBA order, per layer the median, minimum and
-the quartiles of the per-run times.  usage: ab_layers_stat.py REPS 'substr1,substr2' name=ENV=V,... name2=...   (empty env list = the default library)"""
+the quartiles of the per-run times.  usage: ab_layers_stat.py REPS 'substr1,substr2' name=ENV=V,... name2=...   (empty env list = the default library; extra bench.py
+arguments, e.g. "--workload e2e", through the environment variable AB_BENCH_ARGS)"""
 import csv, os, statistics, subprocess, sys, tempfile
 reps = int(sys.argv[1])
 keys = [k for k in sys.argv[2].split(",") if k]
@@ -15,7 +16,7 @@ for r in range(reps):
         with tempfile.NamedTemporaryFile(suffix=".tsv", delete=False) as f:
             path = f.name
         subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-other-configs", "--sustain-seconds", "0", "--steps", "3", "--warmup", "2",
-                        "--dump-layers", path], env=dict(os.environ, **env), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+                        "--dump-layers", path] + os.environ.get("AB_BENCH_ARGS", "").split(), env=dict(os.environ, **env), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         rows = list(csv.reader(open(path), delimiter="\t"))[1:]
         os.unlink(path)
         tot[name].append(sum(float(row[4]) for row in rows))
