@@ -247,10 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
             }
             // ---- stage A: t = relu(conv.0(x) + shift) on the 10 x 18 region, zero outside the image ---------------------
             if (produce && !(ABL & 2)) {
-#pragma unroll
-                for (int j = 0; j < TA; ++j) {
-                    if (j >= nA) break;
-                    const f32x4 acc = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[j], std::integral_constant<int, XX * PIXB>{}, std::integral_constant<int, PLANEB>{}, w0, b0);
+                auto store_t = [&](int j, const f32x4 acc) {
                     const int iy = U.gy0 - 1 + ta_y[j], ix = U.gx0 - 1 + ta_x[j];
                     const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     if (ta_ok[j]) {
@@ -260,6 +257,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                         lds_store8(ta_st[j], h01, h23);
                         if constexpr (PARTS == 2) lds_store8(ta_st[j] + TPLANEB, l01, l23);
                     }
+                };
+                if (nA == 2) {
+                    // two operand tiles: chunk k of the second one is requested as soon as chunk k of the first has been contracted (same registers), so its
+                    // reads travel under the first tile's MFMAs and epilogue (DS operations retire in order: 2 chunks' reads behind the one waited for)
+                    const unsigned ab0 = lds0 + X_OFF + xslot * SLOTB + pa[0], ab1 = lds0 + X_OFF + xslot * SLOTB + pa[1];
+                    short8 ah[3], al[3];
+#define DFFW_SRD_RDA(base, k)                                                                                                             \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[k]) : "v"(base), "n"(k * XX * PIXB));                                           \
+    if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[k]) : "v"(base), "n"(k * XX * PIXB + PLANEB));
+#define DFFW_SRD_MMA(k, W)                                 \
+    if constexpr (PARTS == 2) {                            \
+        acc = mma<F16>(w0[k][1], ah[k], acc);              \
+        acc = mma<F16>(w0[k][0], al[k], acc);              \
+    }                                                      \
+    acc = mma<F16>(w0[k][0], ah[k], acc);
+                    DFFW_SRD_RDA(ab0, 0)
+                    DFFW_SRD_RDA(ab0, 1)
+                    DFFW_SRD_RDA(ab0, 2)
+                    f32x4 acc = b0;
+                    if constexpr (PARTS == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[0]), "+v"(al[0])); else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[0]));
+                    DFFW_SRD_MMA(0, w0)
+                    DFFW_SRD_RDA(ab1, 0)
+                    if constexpr (PARTS == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[1]), "+v"(al[1])); else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[1]));
+                    DFFW_SRD_MMA(1, w0)
+                    DFFW_SRD_RDA(ab1, 1)
+                    if constexpr (PARTS == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[2]), "+v"(al[2])); else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[2]));
+                    DFFW_SRD_MMA(2, w0)
+                    DFFW_SRD_RDA(ab1, 2)
+                    store_t(0, acc);
+                    acc = b0;
+                    // (behind the second tile's reads: at most its later chunks -- the first tile's stores come after them and only make the wait longer)
+                    if constexpr (PARTS == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[0]), "+v"(al[0])); else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[0]));
+                    DFFW_SRD_MMA(0, w0)
+                    if constexpr (PARTS == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[1]), "+v"(al[1])); else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[1]));
+                    DFFW_SRD_MMA(1, w0)
+                    if constexpr (PARTS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[2]), "+v"(al[2])); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[2]));
+                    DFFW_SRD_MMA(2, w0)
+#undef DFFW_SRD_RDA
+#undef DFFW_SRD_MMA
+                    store_t(1, acc);
+                } else {
+                    store_t(0, tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[0], std::integral_constant<int, XX * PIXB>{}, std::integral_constant<int, PLANEB>{}, w0, b0));
                 }
             }
             trc.stamp(2);
