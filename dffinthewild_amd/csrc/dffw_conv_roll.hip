@@ -209,6 +209,57 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     int sidx = 0;   // ring slot of the window's first slice
+    // Software pipeline over the 15 chunks, operand fragments DEPTH chunks ahead of the MFMAs.  The LDS reads and
+    // their waits are inline asm: while an LDS-DMA is outstanding hipcc degrades every lgkmcnt wait to
+    // lgkmcnt(0) (it models global_load_lds as a FLAT access that may also return through LGKM), which would
+    // serialise read -> wait -> MFMA.  DS operations retire in order, so "at most (chunks still ahead) * RPC
+    // reads outstanding" is exactly "chunk c has arrived"; the wait is tied to the fragment registers so the
+    // MFMAs stay behind it.  The first DEPTH chunks of a window lie in its first slice, resident since two steps: they are
+    // requested right behind the previous step's barrier and travel under its epilogue (round 5).
+    constexpr int RPC = MTW * PARTS;   // ds_read_b128 per chunk
+    constexpr int DEPTH = PAIR ? 2 : 1;
+    short8 x[DEPTH + 1][MTW][PARTS];
+    int sb[3];   // slot byte offsets of the three slices the window at sidx reads
+    auto set_window = [&]() {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            int sl = sidx + dz;
+            if (sl >= RING) sl -= RING;
+            sb[dz] = sl * SLOTB;
+        }
+    };
+    auto fetch = [&](int c, short8 (&dst)[MTW][PARTS]) {
+        if constexpr (PAIR) {
+            // chunk c = (slice c/6, filter row (c%6)/2, half c%2): a compile-time offset from the lane's base
+            const unsigned ad = lds0 + sb[c / 6] + pofs[0];
+            const int imm = (((c % 6) / 2) * FX + (c % 2)) * PIXB;
+            switch (imm) {   // the offset must be an immediate: one case per (filter row, half)
+#define DFFW_PAIR_RD(I)                                                                                                  \
+    case I:                                                                                                              \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0][0]) : "v"(ad), "n"(I));                              \
+        if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0][1]) : "v"(ad), "n"(I + PLANEB)); \
+        break;
+                DFFW_PAIR_RD(0)
+                DFFW_PAIR_RD(PIXB)
+                DFFW_PAIR_RD(FX * PIXB)
+                DFFW_PAIR_RD(FX * PIXB + PIXB)
+                DFFW_PAIR_RD(2 * FX * PIXB)
+                DFFW_PAIR_RD(2 * FX * PIXB + PIXB)
+#undef DFFW_PAIR_RD
+            }
+        } else {
+            const unsigned ko = lds0 + sb[c / 5] + inoff[c % 5];
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) {
+                const unsigned ad = ko + pofs[j];
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst[j][0]) : "v"(ad));
+                if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(PLANEB));
+            }
+        }
+    };
+    set_window();
+#pragma unroll
+    for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);   // (the prologue's slices have landed: barrier above)
     StepTrace trc(a.trace, wave, lane, NWAVES);
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
@@ -243,54 +294,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
 #pragma unroll
             for (int j = 0; j < MTW; ++j) acc[j] = bias4;
             if (live && !(a.dbg & 2)) {
-                // slot byte offsets of the three slices this window reads
-                int sb[3];
-#pragma unroll
-                for (int dz = 0; dz < 3; ++dz) {
-                    int sl = sidx + dz;
-                    if (sl >= RING) sl -= RING;
-                    sb[dz] = sl * SLOTB;
-                }
-                // Software pipeline over the 15 chunks, operand fragments two chunks ahead of the MFMAs.  The LDS reads and
-                // their waits are inline asm: while an LDS-DMA is outstanding hipcc degrades every lgkmcnt wait to
-                // lgkmcnt(0) (it models global_load_lds as a FLAT access that may also return through LGKM), which would
-                // serialise read -> wait -> MFMA.  DS operations retire in order, so "at most (chunks still ahead) * RPC
-                // reads outstanding" is exactly "chunk c has arrived"; the wait is tied to the fragment registers so the
-                // MFMAs stay behind it.
-                constexpr int RPC = MTW * PARTS;   // ds_read_b128 per chunk
-                constexpr int DEPTH = PAIR ? 2 : 1;
-                short8 x[DEPTH + 1][MTW][PARTS];
-                auto fetch = [&](int c, short8 (&dst)[MTW][PARTS]) {
-                    if constexpr (PAIR) {
-                        // chunk c = (slice c/6, filter row (c%6)/2, half c%2): a compile-time offset from the lane's base
-                        const unsigned ad = lds0 + sb[c / 6] + pofs[0];
-                        const int imm = (((c % 6) / 2) * FX + (c % 2)) * PIXB;
-                        switch (imm) {   // the offset must be an immediate: one case per (filter row, half)
-#define DFFW_PAIR_RD(I)                                                                                                  \
-    case I:                                                                                                              \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0][0]) : "v"(ad), "n"(I));                              \
-        if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0][1]) : "v"(ad), "n"(I + PLANEB)); \
-        break;
-                            DFFW_PAIR_RD(0)
-                            DFFW_PAIR_RD(PIXB)
-                            DFFW_PAIR_RD(FX * PIXB)
-                            DFFW_PAIR_RD(FX * PIXB + PIXB)
-                            DFFW_PAIR_RD(2 * FX * PIXB)
-                            DFFW_PAIR_RD(2 * FX * PIXB + PIXB)
-#undef DFFW_PAIR_RD
-                        }
-                    } else {
-                        const unsigned ko = lds0 + sb[c / 5] + inoff[c % 5];
-#pragma unroll
-                        for (int j = 0; j < MTW; ++j) {
-                            const unsigned ad = ko + pofs[j];
-                            asm volatile("ds_read_b128 %0, %1" : "=v"(dst[j][0]) : "v"(ad));
-                            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[j][1]) : "v"(ad), "n"(PLANEB));
-                        }
-                    }
-                };
-#pragma unroll
-                for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     if (c + DEPTH < NCH) fetch(c + DEPTH, x[(c + DEPTH) % (DEPTH + 1)]);
@@ -339,6 +342,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
                 for (int j = 0; j < MTW; ++j) asm volatile("" : "+v"(rq[j]));
             }
             sidx = (sidx + 1 == RING) ? 0 : sidx + 1;
+            set_window();
+#pragma unroll
+            for (int c = 0; c < DEPTH; ++c) fetch(c, x[c]);   // the next window's first chunks (also behind the last step: the slots exist)
             trc.stamp(3);
             if (!live) {
                 trc.next();
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_roll(const ConvArgs a, const
     }
     // the slices queued past the end of the stream are still in flight: a wave must not retire before its LDS-DMA has
     // landed, or the pieces arrive in the LDS of whichever workgroup is given these bytes next
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
