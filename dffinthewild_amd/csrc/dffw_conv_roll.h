@@ -54,6 +54,12 @@ void slice32_tile(int *ty, int *tx);
 bool slice32_ok(int prec, const ConvArgs &a);
 hipError_t launch_conv_slice32(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_slice32_kernel_name(const ConvArgs &a, char *buf, int n);
+// conv_slice64: the same for 64 -> 64 channels, a wave holds ONE 16-channel output tile's filter: SLICE64_CHUNKS chunks of (one tap x 32 channels); weights
+// [output tile 4][chunk = tap * 2 + channel half][part][64 lanes][8]
+constexpr int SLICE64_CHUNKS = 18;
+bool slice64_ok(int prec, const ConvArgs &a);
+hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_slice64_kernel_name(const ConvArgs &a, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
 // transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one

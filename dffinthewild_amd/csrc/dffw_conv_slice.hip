@@ -300,6 +300,237 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- conv_slice64: the same per-slice convolution with 64 input and 64 output channels (End_to_End's level-3 alignment head, E2E.py:33-46:
+// `optical_flow_aggregation.conv1.{2,4}.0` at quarter resolution) ------------------------------------------------------------------------------
+// The 9 x 64 x 64 split-bf16 filter is 147 KB: a wave holds the share of ONE 16-channel output tile (18 chunks of (one tap x 32 channels) x (hi, lo)
+// = 144 VGPRs) and contracts it against all of its pixels' K -- the split is over the outputs, so there are no partial sums to exchange.  Eight waves
+// per workgroup walk the slices of an 8 x 16 column: wave (nt, rh) = output tile nt of rows 4 rh .. 4 rh + 3, two rows (operand tiles) at a time, so a
+// slice is two passes of 18 chunks over the resident filter; an operand fragment feeds 3 MFMAs (conv_slice32: 6) -- every output tile's wave reads the
+// image itself: ~0.4 of the LDS's read rate at the matrix pipe's sustained rate.  Slice image [group 4][part][row][pixel][octet] (45 KB), ring of 3 slots
+// two slices ahead (135 KB: one workgroup per CU, two waves per SIMD), one barrier per slice; the fragments of the next chunk -- of the next pass, of
+// the next slice's first chunk -- are requested in front of every chunk's MFMAs, as in conv_slice32.
+namespace slice64 {
+constexpr int TY = DFFW_SLICE_TY, TX = DFFW_SLICE_TX, FY = TY + 2, FX = TX + 2, NW = 8, RING = 3, NCH = SLICE64_CHUNKS, NG = 4;
+static_assert(TY == 8 && TX == 16 && NCH % 2 == 0, "wave (nt, rh): rows 4 rh .. 4 rh + 3; an even chunk count keeps the fragment buffers' parity");
+constexpr int PARTE = FY * FX * 2;        // entries of one part of a 16-channel group: [row][pixel][octet]
+constexpr int CQE = 2 * PARTE;            // ... of a group: [part][row][pixel][octet]
+constexpr int SLOTE = NG * CQE;
+constexpr int NPIECE = (SLOTE + 63) / 64;
+constexpr int SLOTB = NPIECE * 1024;
+constexpr int PPW = (NPIECE + NW - 1) / NW;
+constexpr int LDSB = RING * SLOTB;
+static_assert(CQE % 16 == 0 && SLOTB % 256 == 0 && LDSB <= 160 * 1024, "LDS layout (one workgroup per CU)");
+}   // namespace slice64
+
+template <bool RELU, bool SUMS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice64(const ConvArgs a, const RollArgs t) {
+    static_assert(!SUMS || RELU, "row sums: relu(acc)");
+    using namespace slice64;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int nt = wave & 3, rh = wave >> 2;
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = t.total_tiles >> 3, rem = t.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % t.tiles_x;
+        const int tt = u / t.tiles_x;
+        c.gx0 = txi * TX;
+        c.gy0 = (tt % t.tiles_y) * TY;
+        c.b = tt / t.tiles_y;
+        return c;
+    };
+
+    // ---- fill (as conv_slice32; a pixel record of the 64-channel source is [hi 64][lo 64]) ----
+    constexpr int recb = 256, partb = 128;
+    const char *tb = reinterpret_cast<const char *>(a.in0);
+    const int slice_bytes = a.Hi * a.Wi * recb;
+    int fvo[PPW];
+    const char *fb = tb;
+    int fu = ufirst, fz = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+        fz = 0;
+        fb = tb + ((int64_t)c.b * a.Ni * a.Hi * a.Wi + (int64_t)(c.gy0 - 1) * a.Wi + (c.gx0 - 1)) * recb;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                       // (opaque: no hoisting of the decode out of the unit loop)
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int e = (k * NW + wave) * 64 + ln;       // entry inside the slot: [group][part][row][pixel][octet]
+            const int cq = e / CQE, e2 = e - cq * CQE;
+            const int part = e2 / PARTE, e3 = e2 - part * PARTE;
+            const int fy = e3 / (2 * FX), e4 = e3 - fy * (2 * FX);
+            const int fx = e4 >> 1, oct = e4 & 1;
+            const int iy = c.gy0 - 1 + fy, ix = c.gx0 - 1 + fx;
+            fvo[k] = (e < SLOTE && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) ? (fy * a.Wi + fx) * recb + part * partb + (cq * 2 + oct) * 16
+                                                                                                 : (int)0x80000000;
+        }
+    };
+    setup_fill();
+    int fslotb = 0;
+    auto issue_piece = [&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
+        const int p = k * NW + wave;
+        if (p >= NPIECE) return;                           // (wave-uniform)
+        const bool zin = fu < uend;                        // past the end of the stream: zeros (the slot is never read)
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fb), 0, zin ? (int)0x80000000 : 0, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + fslotb + p * 1024), 16, fvo[k], zin ? fz * slice_bytes : 0, 0, 0);
+    };
+    auto advance_fill = [&]() {
+        fslotb = (fslotb + SLOTB == RING * SLOTB) ? 0 : fslotb + SLOTB;
+        if (++fz == a.Ni && fu < uend) {
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                          // the fill runs two slices ahead
+        static_for<PPW>([&](auto K) { issue_piece(K); });
+        advance_fill();
+    }
+
+    // ---- operand addressing: chunk c = (tap c / 2, channel half c % 2); K octet g of a chunk = channels 32 (c % 2) + 8g .. = (group 2 (c % 2) + (g >> 1),
+    // octet g & 1) of the tap; lane r of operand tile j of pass p = pixel (row 4 rh + 2 p + j, column r): tap, half, pass, tile and part are immediates
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const unsigned abase = lds0 + (unsigned)(((g >> 1) * CQE + (4 * rh) * 2 * FX + r * 2 + (g & 1)) * 16);
+    // output: the lane's 16-byte piece (part g & 1 of channel octet nt * 2 + (g >> 1)) of pixel (row 4 rh + 2 p + j, column r)
+    int vob[2][2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vob[ps][j] = ((4 * rh + 2 * ps + j) * a.Wo + r) * 128 + (g & 1) * 64 + (nt * 2 + (g >> 1)) * 8;
+
+    // ---- this output tile's filter: 18 chunks x (hi, lo), resident for the whole walk ----
+    short8 w[NCH][2];
+    {
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + (size_t)nt * NCH * 2 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            w[c][0] = wp[(c * 2 + 0) * 64];
+            w[c][1] = wp[(c * 2 + 1) * 64];
+        }
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4 *>(a.bias + nt * 16 + g * 4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): prologue slices, filter, bias
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(w[c][0]), "+v"(w[c][1]));   // (pinned: never re-loaded in front of an MFMA)
+    asm volatile("s_barrier" ::: "memory");
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // operand fragments of one chunk: [operand tile][part]; chunk c of any pass sits in buffer c & 1 (18 chunks per pass)
+    short8 x[2][2][2];
+    auto fetch = [](auto BUF, auto C, auto PS, short8 (&xx)[2][2][2], const unsigned ad) __attribute__((always_inline)) {
+        constexpr int b = decltype(BUF)::value, c = decltype(C)::value, ps = decltype(PS)::value;
+        constexpr int tap = c / 2, hf = c % 2;
+        constexpr int tapo = ((tap / 3 + 2 * ps) * 2 * FX + (tap % 3) * 2 + hf * 2 * CQE) * 16, row1 = 2 * FX * 16, pb = PARTE * 16;
+        static_assert(tapo + row1 + pb < 65536, "ds_read immediate");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][0]) : "v"(ad), "n"(tapo));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][1]) : "v"(ad), "n"(tapo + pb));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][0]) : "v"(ad), "n"(tapo + row1));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][1]) : "v"(ad), "n"(tapo + row1 + pb));
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    int sidxb = 0;                        // byte offset of the ring slot of the slice being contracted
+    // One pass = two rows of the wave's four.  PRE: its chunk 0 was requested by the pass in front (all but the kernel's first).
+    auto pass = [&](auto PS_, auto PRE_, const unsigned cur0, const unsigned nxtb, char *optr, float *srow) __attribute__((always_inline)) {
+        constexpr int ps = decltype(PS_)::value;
+        constexpr bool PRE = decltype(PRE_)::value;
+        if constexpr (!PRE) fetch(I0{}, I0{}, std::integral_constant<int, ps>{}, x, cur0);
+        f32x4 n[2] = {bias4, bias4};   // [operand tile]
+        static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+            constexpr int c = decltype(C)::value;
+            constexpr int cur = c & 1, nxt = cur ^ 1;
+            if constexpr (c + 1 < NCH) fetch(std::integral_constant<int, nxt>{}, std::integral_constant<int, (c + 1 < NCH ? c + 1 : 0)>{}, std::integral_constant<int, ps>{}, x, cur0);
+            else if constexpr (ps == 0) fetch(std::integral_constant<int, nxt>{}, I0{}, I1{}, x, cur0);   // the second pass's chunk 0
+            else fetch(std::integral_constant<int, nxt>{}, I0{}, I0{}, x, nxtb);                          // the next slice's: resident since the last barrier
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[cur][0][0]), "+v"(x[cur][0][1]), "+v"(x[cur][1][0]), "+v"(x[cur][1][1]));
+            // product-major over the two accumulators
+            n[0] = mma<false>(w[c][1], x[cur][0][0], n[0]);
+            n[1] = mma<false>(w[c][1], x[cur][1][0], n[1]);
+            n[0] = mma<false>(w[c][0], x[cur][0][1], n[0]);
+            n[1] = mma<false>(w[c][0], x[cur][1][1], n[1]);
+            n[0] = mma<false>(w[c][0], x[cur][0][0], n[0]);
+            n[1] = mma<false>(w[c][0], x[cur][1][0], n[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (!SUMS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                (void)epilogue_lean<P_BF16X3, false, false>(reinterpret_cast<uint16_t *>(optr), nullptr, vob[ps][j], n[j], uint4{}, RELU, zero4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // lane (g, r) holds channels 16 nt + 4g .. + 3 of pixel r of its row segment: sums over the 16 lanes of a row by DPP; lanes r = 0 / r = 15 are
+            // the segment's first / last pixel (conv_tile's row-sums layout: [(row * tiles_x + tile column) * 3 + {sum, first, last}][64])
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float *rp = srow + ((int64_t)(4 * rh + 2 * ps + j) * t.tiles_x * 3) * 64 + nt * 16 + g * 4;
+                f32x4 v, rs;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = relu_bits(n[j][i]);
+                    float q = v[i];
+                    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                    q += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(q), 0x140, 0xF, 0xF, true));   // row_mirror
+                    rs[i] = q;
+                }
+                if (r == 0) {
+                    *reinterpret_cast<f32x4 *>(rp) = rs;
+                    *reinterpret_cast<f32x4 *>(rp + 64) = v;
+                }
+                if (r == 15) *reinterpret_cast<f32x4 *>(rp + 128) = v;
+            }
+        }
+    };
+    auto step = [&](auto PRE_, char *optr, float *srow) __attribute__((always_inline)) {
+        static_for<PPW>([&](auto K) { issue_piece(K); });   // the slice two ahead goes into the slot the previous step left
+        const unsigned cur0 = abase + (unsigned)sidxb;
+        const unsigned nxtb = abase + (unsigned)(sidxb + SLOTB == RING * SLOTB ? 0 : sidxb + SLOTB);
+        pass(I0{}, PRE_, cur0, nxtb, optr, srow);
+        pass(I1{}, std::true_type{}, cur0, nxtb, optr, srow);
+        // the slice queued in this step (and everything older) has landed; this step's four stores may stay in flight across the barrier
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SUMS ? 0 : 4) : "memory");
+        asm volatile("" : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][1][0]), "+v"(x[0][1][1]));
+        sidxb = (sidxb + SLOTB == RING * SLOTB) ? 0 : sidxb + SLOTB;
+        advance_fill();
+    };
+
+    const int64_t ostride = (int64_t)a.Ho * a.Wo * 256;   // bytes per output slice (64 channels, hi + lo)
+    const int64_t sstride = (int64_t)a.Ho * t.tiles_x * 3 * 64;   // row-sum floats per slice
+    bool first = true;
+    for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
+        const Unit U = decode(cu);
+        const int64_t o0 = (((int64_t)U.b * a.No * a.Ho + U.gy0) * a.Wo + U.gx0) * 256;
+        char *optr = SUMS ? nullptr : reinterpret_cast<char *>(a.out) + o0;
+        float *sp = SUMS ? a.outf + (((int64_t)U.b * a.No * a.Ho + U.gy0) * t.tiles_x + U.gx0 / TX) * 3 * 64 : nullptr;
+        for (int z = 0; z < a.No; ++z) {
+            if (first) step(std::false_type{}, optr, sp);
+            else step(std::true_type{}, optr, sp);
+            first = false;
+            if (!SUMS) optr += ostride;
+            if (SUMS) sp += sstride;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
+}
+
 void slice32_tile(int *ty, int *tx) {
     *ty = slice32::TY;
     *tx = slice32::TX;
@@ -332,6 +563,31 @@ hipError_t launch_conv_slice32(const ConvArgs &a, const RollArgs &t, hipStream_t
 void conv_slice32_kernel_name(const ConvArgs &a, char *buf, int n) {
     if (a.dbg & DFFW_ARGS_SUMS) snprintf(buf, n, "dffw::conv_slice32<true, false, true>");
     else snprintf(buf, n, "dffw::conv_slice32<%s, %s, false>", a.relu == 1 ? "true" : "false", a.res0 ? "true" : "false");   // (rocprofv3's spelling)
+}
+
+bool slice64_ok(int prec, const ConvArgs &a) {
+    if (prec != P_BF16X3 || (a.dbg & DFFW_ARGS_NO_SLICE32)) return false;
+    if (a.dbg & DFFW_ARGS_SUMS) {   // row-sums variant: nothing stored, a.outf receives the row vectors
+        if (!a.outf || a.relu != 1) return false;
+    } else if (!a.out || a.outf) return false;
+    if (a.res0 || a.out_pre || a.res1 || a.res_bcast || a.cls_w || a.relu == 2 || a.Cout != 64 || a.C0 != 64 || a.C1 != 0) return false;
+    if (a.Ho % slice64::TY || a.Wo % slice64::TX || a.Ho != a.Hi || a.Wo != a.Wi || a.No != a.Ni) return false;
+    // 32-bit buffer offsets: a sample's input volume (+ one footprint) stays below 2^31 bytes
+    return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * 256 < (1ll << 31);
+}
+
+hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t s) {
+    const int want = t.wgs > 0 ? t.wgs : 256;   // one 8-wave workgroup per CU
+    const int per_xcd = (t.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(slice64::NW * 64);
+    if (a.dbg & DFFW_ARGS_SUMS) hipLaunchKernelGGL((conv_slice64<true, true>), grid, block, 0, s, a, t);
+    else if (a.relu == 1) hipLaunchKernelGGL((conv_slice64<true, false>), grid, block, 0, s, a, t);
+    else hipLaunchKernelGGL((conv_slice64<false, false>), grid, block, 0, s, a, t);
+    return hipGetLastError();
+}
+
+void conv_slice64_kernel_name(const ConvArgs &a, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_slice64<%s, %s>", (a.dbg & DFFW_ARGS_SUMS) || a.relu == 1 ? "true" : "false", (a.dbg & DFFW_ARGS_SUMS) ? "true" : "false");
 }
 
 }  // namespace dffw

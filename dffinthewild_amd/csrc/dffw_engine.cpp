@@ -311,6 +311,7 @@ struct PackedConv {
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_k2 = nullptr;  // device: a 3x3x3 stride-1 32 -> 16 filter in conv_rollx_k2's order: [input half][conv_roll's 15 chunks]
     uint16_t *wslice32 = nullptr;  // device: a 1x3x3 32 -> 32 filter in conv_slice32's order: [9 taps][output tile][part]
+    uint16_t *wslice64 = nullptr;  // device: a 1x3x3 64 -> 64 filter in conv_slice64's order: [output tile][chunk = tap * 2 + channel half][part]
     uint16_t *wrollk = nullptr;    // device: a 3x3x3 stride-1 32 / 64 -> 32 / 64 filter in conv_rollk's order: [32-channel output pair][wave][7 chunks][output tile]
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
@@ -354,6 +355,8 @@ static void free_packed(PackedConv &pc) {
     pc.wrollk = nullptr;
     if (pc.wslice32) (void)hipFree(pc.wslice32);
     pc.wslice32 = nullptr;
+    if (pc.wslice64) (void)hipFree(pc.wslice64);
+    pc.wslice64 = nullptr;
     if (pc.wroll8) (void)hipFree(pc.wroll8);
     pc.wroll8 = nullptr;
     if (pc.wroll_t32) (void)hipFree(pc.wroll_t32);
@@ -703,6 +706,25 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                     }
         HIPCHK(hipMalloc((void **)&pc.wslice32, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wslice32, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- conv_slice64 (dffw_conv_slice.hip): per-slice 1x3x3, 64 -> 64 channels: wave share = one 16-channel output tile; chunk c = (filter tap c / 2, channel half c % 2),
+    // K octet g = channels 32 (c % 2) + 8g ..
+    if (geo == G2S1 && cin_pad == 64 && L.cin == 64 && L.cout == 64 && !shortcut_w && prec == P_BF16X3) {
+        std::vector<uint16_t> wr((size_t)4 * SLICE64_CHUNKS * parts * 512, 0);
+        for (int nt = 0; nt < 4; ++nt)
+            for (int c = 0; c < SLICE64_CHUNKS; ++c)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = lane & 15, gq = lane >> 4, tap = c / 2, ky = tap / 3, kx = tap % 3;
+                        const float val = (float)wval(nt * 16 + row, (c % 2) * 32 + gq * 8 + j, Tap{0, ky - 1, kx - 1, 0, ky, kx});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)nt * SLICE64_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wslice64, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wslice64, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- conv_rollk (dffw_conv_rollk.hip): 3x3x3 stride 1, 32 / 64 -> 32 / 64 channels, the contraction split over the workgroup's waves: wave w =
     // (16-channel group w >> 1, tap half w & 1); tap slot s of a half = filter tap 14 * (w & 1) + s in [dz][ky][kx] order (tap 27: zero weights);
@@ -1744,6 +1766,38 @@ struct Run {
                     prof_begin(kn, name, 2.0 * opx * 9.0 * L.cin * L.cout, bytes);
                 }
                 check(launch_conv_slice32(ak, t, s), name.c_str());
+                prof_end();
+                return out;
+            }
+        }
+        // per-slice 1x3x3, 64 -> 64 channels on whole 8 x 16 columns: the streaming kernel with one output tile's filter resident per wave
+        if (pc.wslice64 && !o.in1 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_SLICE32)) {
+            int sty, stx;
+            slice32_tile(&sty, &stx);
+            const int cols = (Ho / sty) * (Wo / stx);
+            ConvArgs ak = a;
+            ak.Ng = No; ak.Hg = Ho; ak.Wg = Wo;
+            ak.M = (int64_t)ak.B * No * Ho * Wo;
+            if (Ho % sty == 0 && Wo % stx == 0 && (int64_t)in0.B * cols >= sw.roll_min_units && slice64_ok(e->prec, ak)) {
+                if (dry) return out;
+                RollArgs t;
+                memset(&t, 0, sizeof t);
+                t.wroll = pc.wslice64;
+                t.tiles_y = Ho / sty;
+                t.tiles_x = Wo / stx;
+                t.zsplit = 1;
+                t.total_tiles = in0.B * cols;
+                t.wgs = sw.roll_wgs;
+                char kn[96];
+                conv_slice64_kernel_name(ak, kn, sizeof kn);
+                g_last_kernel = kn;
+                if (e->profiling) {
+                    const double opx = (double)out.B * No * Ho * Wo;
+                    const double obytes = o.sums ? opx / 16.0 * 3.0 * L.cout * 4.0 : opx * L.cout * elem_bytes();
+                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + obytes + 9.0 * L.cin * L.cout * elem_bytes();
+                    prof_begin(kn, name, 2.0 * opx * 9.0 * L.cin * L.cout, bytes);
+                }
+                check(launch_conv_slice64(ak, t, s), name.c_str());
                 prof_end();
                 return out;
             }

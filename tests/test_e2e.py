@@ -289,10 +289,10 @@ def test_hip_e2e_head_tail_as_plane_sums(lib_built, monkeypatch, B, H, W, precis
             want = w % 16 == 0 and B * 2 * ((h + 3) // 4) * (w // 16) >= 256
             got = [k for k, layer in prof if layer.endswith(lvl + ".4.0")]
             # conv_tile<prec, geo, NT, TZ, TY, TX, CG, pipe, waves, SPLITK (= row-sums variant for this geometry), LEAN>, or -- the 32-channel level-2
-            # head on whole 8 x 16 columns -- conv_slice32<RELU, RES, SUMS>
+            # head on whole 8 x 16 columns -- conv_slice32<RELU, RES, SUMS> (the 64-channel level-3 head: conv_slice64<RELU, SUMS>)
             assert len(got) == 1, (lvl, got)
-            if got[0].startswith("dffw::conv_slice32<"):
-                is_sums = got[0].endswith(", true>")          # conv_slice32<RELU, RES, SUMS>
+            if got[0].startswith(("dffw::conv_slice32<", "dffw::conv_slice64<")):
+                is_sums = got[0].endswith(", true>")          # conv_slice32<RELU, RES, SUMS> / conv_slice64<RELU, SUMS>
             else:
                 is_sums = got[0].rstrip(">").split(", ")[9] == "true"
             assert is_sums == want, (lvl, got, want)

@@ -252,6 +252,34 @@ def test_conv_slice32(eng, B, N, H, W, wgs, relu, residual, monkeypatch):
     assert rel(got, alt) <= 2e-5, rel(got, alt)
 
 
+@pytest.mark.parametrize("B,N,H,W,wgs,relu", [(3, 10, 64, 64, 0, 1), (2, 1, 32, 64, 8, 1), (3, 7, 64, 32, 24, 0), (2, 2, 40, 48, 16, 1), (5, 3, 8, 16, 0, 0), (1, 5, 120, 160, 0, 1)])
+def test_conv_slice64(eng, B, N, H, W, wgs, relu, monkeypatch):
+    """conv_slice64 (dffw_conv_slice.hip): per-slice 1x3x3, 64 -> 64 channels (`optical_flow_aggregation.conv1.{2,4}.0`, the level-3 alignment head of
+    End_to_End, E2E.py:33-46) with one 16-channel output tile's filter resident per wave, eight waves per 8 x 16 column: every slice count incl. 1 and 2,
+    one column per workgroup and long streams, a single column per sample, image borders in every position, ReLU on and off; against F.conv3d and
+    against conv_tile on the same input (DFFW_NO_SLICE32)."""
+    cin = cout = 64
+    x = rnd(B, cin, N, H, W, seed=91)
+    w = rnd(cout, cin, 1, 3, 3, seed=92, scale=(2.0 / (cin * 9)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 93)
+    ref = ref_bn(F.conv3d(x, w, None, 1, (0, 1, 1)), bn)
+    if relu:
+        ref = F.relu(ref)
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    kw = dict(pad=(0, 1, 1), bn=bn, relu=relu, precision="bf16x3")
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_slice64<"), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL["bf16x3"], rel(got, ref)
+    again = eng.op_conv3d(x.cuda(), w, **kw)
+    assert torch.equal(got, again)
+    monkeypatch.setenv("DFFW_NO_SLICE32", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(got, alt) <= 2e-5, rel(got, alt)
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64)])
 @pytest.mark.parametrize("N,H,W,zsplit,wgs,relu,residual", [(10, 64, 64, 1, 0, 1, False), (1, 32, 64, 1, 8, 1, True), (7, 64, 32, 3, 24, 0, True), (2, 40, 24, 2, 16, 1, False),
                                                             (3, 64, 64, 3, 8, 0, False), (5, 8, 8, 1, 0, 1, True), (3, 60, 80, 1, 0, 1, True), (4, 28, 36, 2, 8, 1, False)])
