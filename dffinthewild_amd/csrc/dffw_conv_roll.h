@@ -57,6 +57,9 @@ void conv_slice32_kernel_name(const ConvArgs &a, char *buf, int n);
 // conv_slice64: the same for 64 -> 64 channels, a wave holds ONE 16-channel output tile's filter: SLICE64_CHUNKS chunks of (one tap x 32 channels); weights
 // [output tile 4][chunk = tap * 2 + channel half][part][64 lanes][8]
 constexpr int SLICE64_CHUNKS = 18;
+// ... and its HEAD variant (cin = 32 features + 2 flow channels in 40-channel records, slice-broadcast residual): 9 feature chunks + 3 chunks over the fifth
+// channel octet (K octet g of chunk 9 + k = tap 4k + g)
+constexpr int SLICE64_HEAD_CHUNKS = 12;
 bool slice64_ok(int prec, const ConvArgs &a);
 hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_slice64_kernel_name(const ConvArgs &a, char *buf, int n);

@@ -309,24 +309,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // image itself: ~0.4 of the LDS's read rate at the matrix pipe's sustained rate.  Slice image [group 4][part][row][pixel][octet] (45 KB), ring of 3 slots
 // two slices ahead (135 KB: one workgroup per CU, two waves per SIMD), one barrier per slice; the fragments of the next chunk -- of the next pass, of
 // the next slice's first chunk -- are requested in front of every chunk's MFMAs, as in conv_slice32.
+// HEAD: the first conv of the same head over [warped features 32 | flow 2 | pad 6] records (`conv1.0.0#cur`, E2E.py:88-101; the volume flow_volume_kernel
+// writes) plus the slice-broadcast reference part as a residual: 9 chunks of (tap x 32 feature channels) + 3 chunks over the record's fifth channel octet
+// (K octet g of chunk 9 + k = tap 4k + g; taps 9-11 carry zero weights) = 12 chunks, 96 VGPRs of filter per wave; the slice image has a third channel
+// group of which only octet 0 is filled; the residual pieces of a column (one slice per sample) are loaded once per column and stay in registers.
 namespace slice64 {
-constexpr int TY = DFFW_SLICE_TY, TX = DFFW_SLICE_TX, FY = TY + 2, FX = TX + 2, NW = 8, RING = 3, NCH = SLICE64_CHUNKS, NG = 4;
-static_assert(TY == 8 && TX == 16 && NCH % 2 == 0, "wave (nt, rh): rows 4 rh .. 4 rh + 3; an even chunk count keeps the fragment buffers' parity");
+constexpr int TY = DFFW_SLICE_TY, TX = DFFW_SLICE_TX, FY = TY + 2, FX = TX + 2, NW = 8, RING = 3;
+static_assert(TY == 8 && TX == 16, "wave (nt, rh): rows 4 rh .. 4 rh + 3");
 constexpr int PARTE = FY * FX * 2;        // entries of one part of a 16-channel group: [row][pixel][octet]
 constexpr int CQE = 2 * PARTE;            // ... of a group: [part][row][pixel][octet]
-constexpr int SLOTE = NG * CQE;
-constexpr int NPIECE = (SLOTE + 63) / 64;
-constexpr int SLOTB = NPIECE * 1024;
-constexpr int PPW = (NPIECE + NW - 1) / NW;
-constexpr int LDSB = RING * SLOTB;
-static_assert(CQE % 16 == 0 && SLOTB % 256 == 0 && LDSB <= 160 * 1024, "LDS layout (one workgroup per CU)");
+template <bool HEAD>
+struct Lay {
+    static constexpr int NG = HEAD ? 3 : 4;
+    static constexpr int NCH = HEAD ? SLICE64_HEAD_CHUNKS : SLICE64_CHUNKS;
+    static constexpr int SLOTE = NG * CQE;
+    static constexpr int PPW = ((SLOTE + 63) / 64 + NW - 1) / NW;
+    static constexpr int NPIECE = PPW * NW;   // every wave issues PPW pieces per slice (the counted vmcnt waits rely on it): the slot is padded to whole rounds
+    static constexpr int SLOTB = NPIECE * 1024;
+    static constexpr int LDSB = RING * SLOTB;
+    static constexpr int RECB = HEAD ? 160 : 256, PARTB = RECB / 2, NOCT = RECB / 32;   // a pixel record [hi C][lo C] of the source
+    static_assert(NCH % 2 == 0, "an even chunk count keeps the fragment buffers' parity over passes and slices");
+    static_assert(CQE % 16 == 0 && SLOTB % 256 == 0 && LDSB <= 160 * 1024, "LDS layout (one workgroup per CU)");
+};
 }   // namespace slice64
 
-template <bool RELU, bool SUMS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice64(const ConvArgs a, const RollArgs t) {
-    static_assert(!SUMS || RELU, "row sums: relu(acc)");
+// (the body is a device function template and the kernels thin wrappers: with the layout's dependent constants directly inside a __global__ template, hipcc's host
+// pass silently emits no launch stub)
+template <bool RELU, bool SUMS, bool HEAD>
+__device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &t, unsigned char *smem) {
+    static_assert(!SUMS || (RELU && !HEAD), "row sums: relu(acc), no residual");
     using namespace slice64;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
+    using L = Lay<HEAD>;
+    constexpr int NCH = L::NCH, PPW = L::PPW, SLOTB = L::SLOTB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
@@ -354,8 +368,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return c;
     };
 
-    // ---- fill (as conv_slice32; a pixel record of the 64-channel source is [hi 64][lo 64]) ----
-    constexpr int recb = 256, partb = 128;
+    // ---- fill (as conv_slice32) ----
+    constexpr int recb = L::RECB, partb = L::PARTB;
     const char *tb = reinterpret_cast<const char *>(a.in0);
     const int slice_bytes = a.Hi * a.Wi * recb;
     int fvo[PPW];
@@ -375,8 +389,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int fy = e3 / (2 * FX), e4 = e3 - fy * (2 * FX);
             const int fx = e4 >> 1, oct = e4 & 1;
             const int iy = c.gy0 - 1 + fy, ix = c.gx0 - 1 + fx;
-            fvo[k] = (e < SLOTE && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) ? (fy * a.Wi + fx) * recb + part * partb + (cq * 2 + oct) * 16
-                                                                                                 : (int)0x80000000;
+            fvo[k] = (e < L::SLOTE && cq * 2 + oct < L::NOCT && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                         ? (fy * a.Wi + fx) * recb + part * partb + (cq * 2 + oct) * 16
+                         : (int)0x80000000;
         }
     };
     setup_fill();
@@ -384,7 +399,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto issue_piece = [&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
         const int p = k * NW + wave;
-        if (p >= NPIECE) return;                           // (wave-uniform)
         const bool zin = fu < uend;                        // past the end of the stream: zeros (the slot is never read)
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fb), 0, zin ? (int)0x80000000 : 0, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + fslotb + p * 1024), 16, fvo[k], zin ? fz * slice_bytes : 0, 0, 0);
@@ -402,10 +416,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         advance_fill();
     }
 
-    // ---- operand addressing: chunk c = (tap c / 2, channel half c % 2); K octet g of a chunk = channels 32 (c % 2) + 8g .. = (group 2 (c % 2) + (g >> 1),
-    // octet g & 1) of the tap; lane r of operand tile j of pass p = pixel (row 4 rh + 2 p + j, column r): tap, half, pass, tile and part are immediates
+    // ---- operand addressing.  64 -> 64: chunk c = (tap c / 2, channel half c % 2), K octet g = channels 32 (c % 2) + 8g .. = (group 2 (c % 2) + (g >> 1), octet g & 1)
+    // of the tap.  HEAD: chunk c < 9 = tap c over the 32 feature channels (groups 0, 1); chunk 9 + k: K octet g = octet 0 of group 2 at tap 4k + g (taps >= 9: zero
+    // weights, tap 8's operands).  Lane r of operand tile j of pass p = pixel (row 4 rh + 2 p + j, column r): tap, half, pass, tile and part are immediates.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const unsigned abase = lds0 + (unsigned)(((g >> 1) * CQE + (4 * rh) * 2 * FX + r * 2 + (g & 1)) * 16);
+    unsigned afl[3] = {0, 0, 0};
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int tap = 4 * k + g < 9 ? 4 * k + g : 8;
+            afl[k] = lds0 + (unsigned)((2 * CQE + (4 * rh + tap / 3) * 2 * FX + (r + tap % 3) * 2) * 16);
+        }
+    }
     // output: the lane's 16-byte piece (part g & 1 of channel octet nt * 2 + (g >> 1)) of pixel (row 4 rh + 2 p + j, column r)
     int vob[2][2];
 #pragma unroll
@@ -413,7 +436,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 2; ++j) vob[ps][j] = ((4 * rh + 2 * ps + j) * a.Wo + r) * 128 + (g & 1) * 64 + (nt * 2 + (g >> 1)) * 8;
 
-    // ---- this output tile's filter: 18 chunks x (hi, lo), resident for the whole walk ----
+    // ---- this output tile's filter: NCH chunks x (hi, lo), resident for the whole walk ----
     short8 w[NCH][2];
     {
         const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + (size_t)nt * NCH * 2 * 64 + lane;
@@ -429,35 +452,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(w[c][0]), "+v"(w[c][1]));   // (pinned: never re-loaded in front of an MFMA)
     asm volatile("s_barrier" ::: "memory");
 
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // operand fragments of one chunk: [operand tile][part]; chunk c of any pass sits in buffer c & 1 (18 chunks per pass)
+    // operand fragments of one chunk: [operand tile][part]; chunk c of any pass sits in buffer c & 1 (an even number of chunks per pass)
     short8 x[2][2][2];
-    auto fetch = [](auto BUF, auto C, auto PS, short8 (&xx)[2][2][2], const unsigned ad) __attribute__((always_inline)) {
+    auto fetch = [](auto BUF, auto C, auto PS, short8 (&xx)[2][2][2], const unsigned ad, const unsigned (&af)[3]) __attribute__((always_inline)) {
         constexpr int b = decltype(BUF)::value, c = decltype(C)::value, ps = decltype(PS)::value;
-        constexpr int tap = c / 2, hf = c % 2;
-        constexpr int tapo = ((tap / 3 + 2 * ps) * 2 * FX + (tap % 3) * 2 + hf * 2 * CQE) * 16, row1 = 2 * FX * 16, pb = PARTE * 16;
-        static_assert(tapo + row1 + pb < 65536, "ds_read immediate");
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][0]) : "v"(ad), "n"(tapo));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][1]) : "v"(ad), "n"(tapo + pb));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][0]) : "v"(ad), "n"(tapo + row1));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][1]) : "v"(ad), "n"(tapo + row1 + pb));
+        constexpr int row1 = 2 * FX * 16, pb = PARTE * 16;
+        if constexpr (HEAD && c >= 9) {
+            constexpr int off = (2 * ps) * 2 * FX * 16;
+            const unsigned adf = af[c - 9 < 3 ? c - 9 : 0];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][0]) : "v"(adf), "n"(off));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][1]) : "v"(adf), "n"(off + pb));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][0]) : "v"(adf), "n"(off + row1));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][1]) : "v"(adf), "n"(off + row1 + pb));
+        } else {
+            constexpr int tap = HEAD ? c : c / 2, hf = HEAD ? 0 : c % 2;
+            constexpr int tapo = ((tap / 3 + 2 * ps) * 2 * FX + (tap % 3) * 2 + hf * 2 * CQE) * 16;
+            static_assert(tapo + row1 + pb < 65536, "ds_read immediate");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][0]) : "v"(ad), "n"(tapo));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][1]) : "v"(ad), "n"(tapo + pb));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][0]) : "v"(ad), "n"(tapo + row1));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][1]) : "v"(ad), "n"(tapo + row1 + pb));
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
+    // HEAD: the column's residual pieces (the sample's one reference slice), [pass][operand tile]; requested in front of the column's first slice and waited
+    // for (vmcnt(0)) in front of its first epilogue
+    u32x4 rq[2][2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rq[ps][j] = u32x4{0, 0, 0, 0};
+
     int sidxb = 0;                        // byte offset of the ring slot of the slice being contracted
     // One pass = two rows of the wave's four.  PRE: its chunk 0 was requested by the pass in front (all but the kernel's first).
-    auto pass = [&](auto PS_, auto PRE_, const unsigned cur0, const unsigned nxtb, char *optr, float *srow) __attribute__((always_inline)) {
+    auto pass = [&](auto PS_, auto PRE_, const unsigned cur0, const unsigned nxtb, const unsigned slotd, char *optr, float *srow, const bool fresh) __attribute__((always_inline)) {
         constexpr int ps = decltype(PS_)::value;
         constexpr bool PRE = decltype(PRE_)::value;
-        if constexpr (!PRE) fetch(I0{}, I0{}, std::integral_constant<int, ps>{}, x, cur0);
+        unsigned afc[3], afn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            afc[k] = afl[k] + (unsigned)sidxb;
+            afn[k] = afl[k] + slotd;
+        }
+        if constexpr (!PRE) fetch(I0{}, I0{}, std::integral_constant<int, ps>{}, x, cur0, afc);
         f32x4 n[2] = {bias4, bias4};   // [operand tile]
         static_for<NCH>([&](auto C) __attribute__((always_inline)) {
             constexpr int c = decltype(C)::value;
             constexpr int cur = c & 1, nxt = cur ^ 1;
-            if constexpr (c + 1 < NCH) fetch(std::integral_constant<int, nxt>{}, std::integral_constant<int, (c + 1 < NCH ? c + 1 : 0)>{}, std::integral_constant<int, ps>{}, x, cur0);
-            else if constexpr (ps == 0) fetch(std::integral_constant<int, nxt>{}, I0{}, I1{}, x, cur0);   // the second pass's chunk 0
-            else fetch(std::integral_constant<int, nxt>{}, I0{}, I0{}, x, nxtb);                          // the next slice's: resident since the last barrier
+            if constexpr (c + 1 < NCH) fetch(std::integral_constant<int, nxt>{}, std::integral_constant<int, (c + 1 < NCH ? c + 1 : 0)>{}, std::integral_constant<int, ps>{}, x, cur0, afc);
+            else if constexpr (ps == 0) fetch(std::integral_constant<int, nxt>{}, I0{}, I1{}, x, cur0, afc);   // the second pass's chunk 0
+            else fetch(std::integral_constant<int, nxt>{}, I0{}, I0{}, x, nxtb, afn);                          // the next slice's: resident since the last barrier
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[cur][0][0]), "+v"(x[cur][0][1]), "+v"(x[cur][1][0]), "+v"(x[cur][1][1]));
             // product-major over the two accumulators
             n[0] = mma<false>(w[c][1], x[cur][0][0], n[0]);
@@ -468,10 +516,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             n[1] = mma<false>(w[c][0], x[cur][1][0], n[1]);
             __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (HEAD && ps == 0) {
+            // the column's residual pieces, requested in front of its first slice's DMA pieces.  A counted wait (vmcnt(PPW): "everything but this slice's pieces")
+            // is NOT enough -- measured: wrong results that vary from run to run once a workgroup walks more than one column; VGPR loads, LDS-DMA loads and the
+            // previous step's stores do not retire in one order -- so the column's first slice drains the queue here (its pieces were issued a pass ago)
+            if (fresh) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
+        }
         if constexpr (!SUMS) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                (void)epilogue_lean<P_BF16X3, false, false>(reinterpret_cast<uint16_t *>(optr), nullptr, vob[ps][j], n[j], uint4{}, RELU, zero4);
+                const uint4 q4 = make_uint4(rq[ps][j][0], rq[ps][j][1], rq[ps][j][2], rq[ps][j][3]);
+                (void)epilogue_lean<P_BF16X3, HEAD, false>(reinterpret_cast<uint16_t *>(optr), nullptr, vob[ps][j], n[j], q4, RELU, zero4);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -499,12 +555,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
-    auto step = [&](auto PRE_, char *optr, float *srow) __attribute__((always_inline)) {
+    auto step = [&](auto PRE_, char *optr, float *srow, const bool fresh) __attribute__((always_inline)) {
         static_for<PPW>([&](auto K) { issue_piece(K); });   // the slice two ahead goes into the slot the previous step left
+        const unsigned slotd = (unsigned)(sidxb + SLOTB == RING * SLOTB ? 0 : sidxb + SLOTB);
         const unsigned cur0 = abase + (unsigned)sidxb;
-        const unsigned nxtb = abase + (unsigned)(sidxb + SLOTB == RING * SLOTB ? 0 : sidxb + SLOTB);
-        pass(I0{}, PRE_, cur0, nxtb, optr, srow);
-        pass(I1{}, std::true_type{}, cur0, nxtb, optr, srow);
+        const unsigned nxtb = abase + slotd;
+        pass(I0{}, PRE_, cur0, nxtb, slotd, optr, srow, fresh);
+        pass(I1{}, std::true_type{}, cur0, nxtb, slotd, optr, srow, false);
         // the slice queued in this step (and everything older) has landed; this step's four stores may stay in flight across the barrier
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SUMS ? 0 : 4) : "memory");
         asm volatile("" : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][1][0]), "+v"(x[0][1][1]));
@@ -520,15 +577,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int64_t o0 = (((int64_t)U.b * a.No * a.Ho + U.gy0) * a.Wo + U.gx0) * 256;
         char *optr = SUMS ? nullptr : reinterpret_cast<char *>(a.out) + o0;
         float *sp = SUMS ? a.outf + (((int64_t)U.b * a.No * a.Ho + U.gy0) * t.tiles_x + U.gx0 / TX) * 3 * 64 : nullptr;
+        if constexpr (HEAD) {
+            const char *rb = reinterpret_cast<const char *>(a.res0) + (((int64_t)U.b * a.Ho + U.gy0) * a.Wo + U.gx0) * 256;   // one reference slice per sample
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned ro = (unsigned)(vob[ps][j] * 2);
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rq[ps][j]) : "v"(ro), "s"(rb) : "memory");
+                }
+        }
         for (int z = 0; z < a.No; ++z) {
-            if (first) step(std::false_type{}, optr, sp);
-            else step(std::true_type{}, optr, sp);
+            if (first) step(std::false_type{}, optr, sp, z == 0);
+            else step(std::true_type{}, optr, sp, z == 0);
             first = false;
             if (!SUMS) optr += ostride;
             if (SUMS) sp += sstride;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
+}
+
+template <bool RELU, bool SUMS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice64(const ConvArgs a, const RollArgs t) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[slice64::Lay<false>::LDSB];
+    slice64_body<RELU, SUMS, false>(a, t, smem);
+}
+template <bool RELU>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice64_head(const ConvArgs a, const RollArgs t) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[slice64::Lay<true>::LDSB];
+    slice64_body<RELU, false, true>(a, t, smem);
 }
 
 void slice32_tile(int *ty, int *tx) {
@@ -570,24 +648,30 @@ bool slice64_ok(int prec, const ConvArgs &a) {
     if (a.dbg & DFFW_ARGS_SUMS) {   // row-sums variant: nothing stored, a.outf receives the row vectors
         if (!a.outf || a.relu != 1) return false;
     } else if (!a.out || a.outf) return false;
-    if (a.res0 || a.out_pre || a.res1 || a.res_bcast || a.cls_w || a.relu == 2 || a.Cout != 64 || a.C0 != 64 || a.C1 != 0) return false;
+    const bool head = a.res_bcast && a.res0 && a.C0 == 40 && !(a.dbg & DFFW_ARGS_SUMS);   // the level-3 head's first conv over [features 32 | flow 2 | pad 6]
+    if ((a.res0 || a.res_bcast) && !head) return false;
+    if (a.out_pre || a.res1 || a.cls_w || a.relu == 2 || a.Cout != 64 || (a.C0 != 64 && !head) || a.C1 != 0) return false;
     if (a.Ho % slice64::TY || a.Wo % slice64::TX || a.Ho != a.Hi || a.Wo != a.Wi || a.No != a.Ni) return false;
     // 32-bit buffer offsets: a sample's input volume (+ one footprint) stays below 2^31 bytes
-    return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * 256 < (1ll << 31);
+    return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * 256 < (1ll << 31) && (int64_t)a.Ho * a.Wo * 256 < (1ll << 31);
 }
 
 hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t s) {
     const int want = t.wgs > 0 ? t.wgs : 256;   // one 8-wave workgroup per CU
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(slice64::NW * 64);
-    if (a.dbg & DFFW_ARGS_SUMS) hipLaunchKernelGGL((conv_slice64<true, true>), grid, block, 0, s, a, t);
+    if (a.res_bcast) {
+        if (a.relu == 1) hipLaunchKernelGGL((conv_slice64_head<true>), grid, block, 0, s, a, t);
+        else hipLaunchKernelGGL((conv_slice64_head<false>), grid, block, 0, s, a, t);
+    } else if (a.dbg & DFFW_ARGS_SUMS) hipLaunchKernelGGL((conv_slice64<true, true>), grid, block, 0, s, a, t);
     else if (a.relu == 1) hipLaunchKernelGGL((conv_slice64<true, false>), grid, block, 0, s, a, t);
     else hipLaunchKernelGGL((conv_slice64<false, false>), grid, block, 0, s, a, t);
     return hipGetLastError();
 }
 
 void conv_slice64_kernel_name(const ConvArgs &a, char *buf, int n) {
-    snprintf(buf, n, "dffw::conv_slice64<%s, %s>", (a.dbg & DFFW_ARGS_SUMS) || a.relu == 1 ? "true" : "false", (a.dbg & DFFW_ARGS_SUMS) ? "true" : "false");
+    if (a.res_bcast) snprintf(buf, n, "dffw::conv_slice64_head<%s>", a.relu == 1 ? "true" : "false");
+    else snprintf(buf, n, "dffw::conv_slice64<%s, %s>", (a.dbg & DFFW_ARGS_SUMS) || a.relu == 1 ? "true" : "false", (a.dbg & DFFW_ARGS_SUMS) ? "true" : "false");
 }
 
 }  // namespace dffw

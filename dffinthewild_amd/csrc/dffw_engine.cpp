@@ -311,7 +311,8 @@ struct PackedConv {
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_k2 = nullptr;  // device: a 3x3x3 stride-1 32 -> 16 filter in conv_rollx_k2's order: [input half][conv_roll's 15 chunks]
     uint16_t *wslice32 = nullptr;  // device: a 1x3x3 32 -> 32 filter in conv_slice32's order: [9 taps][output tile][part]
-    uint16_t *wslice64 = nullptr;  // device: a 1x3x3 64 -> 64 filter in conv_slice64's order: [output tile][chunk = tap * 2 + channel half][part]
+    uint16_t *wslice64 = nullptr;  // device: a 1x3x3 64 -> 64 filter in conv_slice64's order: [output tile][chunk = tap * 2 + channel half][part]; or (a 34 -> 64 `#cur` layer of
+                                   // an alignment head) in its HEAD order: [output tile][9 feature chunks + 3 chunks over the flow octet][part]
     uint16_t *wrollk = nullptr;    // device: a 3x3x3 stride-1 32 / 64 -> 32 / 64 filter in conv_rollk's order: [32-channel output pair][wave][7 chunks][output tile]
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
@@ -720,6 +721,27 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                         uint16_t hi, lo;
                         host_split(prec, val, hi, lo);
                         const size_t base = (((size_t)nt * SLICE64_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wslice64, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wslice64, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ... and its HEAD variant for the level-3 alignment head's first conv over [features 32 | flow 2 | pad 6] records: chunk c < 9 = tap c x the 32 feature channels;
+    // chunk 9 + k: K octet g = the record's fifth channel octet (flow_x, flow_y, zeros) at tap 4k + g (taps 9 .. 11: zero weights)
+    if (geo == G2S1 && cin_pad == 40 && L.cin == 34 && L.cout == 64 && !shortcut_w && prec == P_BF16X3) {
+        std::vector<uint16_t> wr((size_t)4 * SLICE64_HEAD_CHUNKS * parts * 512, 0);
+        for (int nt = 0; nt < 4; ++nt)
+            for (int c = 0; c < SLICE64_HEAD_CHUNKS; ++c)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = lane & 15, gq = lane >> 4;
+                        const int tap = c < 9 ? c : 4 * (c - 9) + gq, cin = c < 9 ? gq * 8 + j : 32 + j;
+                        float val = 0.f;
+                        if (tap < 9 && cin < L.cin) val = (float)wval(nt * 16 + row, cin, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)nt * SLICE64_HEAD_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
                         wr[base] = hi;
                         wr[base + 512] = lo;
                     }

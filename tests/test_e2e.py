@@ -122,6 +122,29 @@ def test_hip_e2e_matches_reference(lib_built, path):
 
 
 @pytest.mark.gpu
+def test_hip_e2e_streaming_kernels_on_the_full_size_golden(lib_built, monkeypatch):
+    """One 10x3x480x640 stack is below the unit count at which the persistent streaming kernels take over (DFFW_ROLL_MIN_UNITS); forced on, the
+    level-3 alignment head runs on conv_slice64 (its HEAD variant for the first conv over [features | flow] + the broadcast reference part, the plain
+    one, the row-sums one), the level-2 head on conv_slice32: the reference's own head outputs to 1e-4, its depth maps to 1e-3, and the default
+    (conv_tile) path to 2e-5 / 2e-4."""
+    g, sd, FS, fd, fov = load(BIG[0])
+    tags = ["head3", "head2", "head1", "alpha"]
+    with torch.no_grad():
+        base, taps0 = _model(sd).forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+        monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+        m = _model(sd)
+        outs, taps = m.forward_with_taps(FS.cuda(), fd.cuda(), fov.cuda(), tags)
+        ran = {k for k, layer in _profiled_kernels(m, FS.cuda(), fd.cuda(), fov.cuda()) if "optical_flow_aggregation.conv1." in layer}
+    assert {"dffw::conv_slice64_head<true>", "dffw::conv_slice64<true, false>", "dffw::conv_slice64<true, true>"} <= ran, ran
+    for tag in ("head3", "head2", "head1"):
+        assert cpu_ref.rel_l2(taps[tag].cpu().reshape(3, 10), g[tag]) <= 1e-4, tag
+        assert cpu_ref.rel_l2(taps[tag].cpu(), taps0[tag].cpu()) <= 2e-5, tag
+    assert cpu_ref.rel_l2(outs[3].cpu(), g["pred3"]) <= 1e-3
+    for name, a, b in zip(OUT_NAMES, outs, base):
+        assert cpu_ref.rel_l2(a.cpu(), b.cpu()) <= 2e-4, name
+
+
+@pytest.mark.gpu
 def test_hip_e2e_config5_batch8_480x640(lib_built):
     """BASELINE config 5 at its stated size: 8 stacks of 10x3x480x640 in one call.  The stack of the reference golden
     (End_to_End.Network run by oracle/make_goldens_e2e.py at 1x10x480x640) sits at batch positions 1 and 6 among six other
@@ -175,7 +198,7 @@ def test_hip_e2e_batch_is_per_sample(lib_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_HEAD_SUMS_FUSED", "DFFW_NO_HEAD_WARP"])
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_HEAD_SUMS_FUSED", "DFFW_NO_HEAD_WARP", "DFFW_NO_SLICE32"])
 def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     """The gather kernel (no LDS tiles), the unsplit alignment heads (reference slice carried in every slice's volume
     instead of entering as a slice-broadcast residual), the unsplit few-tile launches and the heads' last conv + plane mean as
