@@ -1715,17 +1715,13 @@ struct Run {
         // the 5 x 8 x 8 block (its packs of layers with more than 4 output tiles split the output channels over grid.y: not with a fused classifier,
         // whose partial dot spans all of a pixel's channels, nor under DFFW_NO_SPLIT), with enough samples / tiles to fill the chip:
         // (a) grids at most 8 x 8 (the 1/32-resolution pyramid layers at 256 x 256, round 4);  (b) round 5: stride-1 layers with 128 output channels on grids up to
-        // DFFW_NARROW_MAX (40) wide whose launch on the layer's own block would be fewer than 256 workgroups -- End_to_End's 15 x 20 and
-        // 30 x 40 pyramid levels at batch 8: `combine2` ran as 96 workgroups of 128 output channels each (0.24 -> 0.13 ms, `conv4` 0.16 -> 0.09; the 64-output layers of those levels gain 2-8 % on it at that shape and lose as much at others: left alone)
+        // DFFW_NARROW_MAX (40) wide -- End_to_End's 30 x 40 pyramid level at batch 8: `combine2` / `conv4` ran on the 4 x 4 x 8 block with all 128 output
+        // channels per workgroup, re-streaming the filter for 128 grid points at a time (0.24 -> 0.13 ms, `conv4` 0.16 -> 0.09; the 64-output layers of those levels gain 2-8 % on it at that shape and lose as much at others: left alone)
         const bool narrow_splits = pc.tile_narrow.cfg && pc.nt > pc.tile_narrow.cfg->nt;
         const int gN = L.transposed ? in0.N : No;
         bool narrow = !stem_pair && pc.tile_narrow.cfg && !sw.on(SW_NO_NARROW) && !(narrow_splits && (o.cls || sw.on(SW_NO_SPLIT))) &&
                       (int64_t)in0.B * ((gN + 4) / 5) * ((gH + 7) / 8) * ((gW + 7) / 8) * pc.nt >= 256;
-        if (narrow && !(gW <= 8 && gH <= 8)) {
-            const TileCfg *mc = pc.tile.cfg;
-            const int64_t main_wgs = mc ? (int64_t)in0.B * ((gN + mc->tz - 1) / mc->tz) * ((gH + mc->ty - 1) / mc->ty) * ((gW + mc->tx - 1) / mc->tx) : 0;
-            narrow = !L.transposed && pc.nt >= 8 && gW <= sw.narrow_max && gH <= sw.narrow_max && mc && main_wgs < 256;
-        }
+        if (narrow && !(gW <= 8 && gH <= 8)) narrow = !L.transposed && pc.nt >= 8 && gW <= sw.narrow_max && gH <= sw.narrow_max;
         const TilePack &tp = stem_pair ? pc.tile_pair : (narrow ? pc.tile_narrow : pc.tile);
         // 32 -> 16 channels on whole 8 x 16 columns: the pipelined rolling window with the contraction split over the two input halves
         {
