@@ -1266,7 +1266,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1288,6 +1288,7 @@ struct Switches {
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
+        s.split_s64 = geti("DFFW_SPLIT_S64", 1, 1025);   // ... and a stride-1 3x3x3 layer with 64 outputs (End_to_End dres16_* at batch 8: 0.093 -> 0.076 ms on two 2-tile workgroups per tile; 257 = round 4)
         s.split_t64 = geti("DFFW_SPLIT_T64", 1, 1025);   // tile count below which a transposed layer with 64 outputs splits its output channels (257 = round 4)
         s.narrow_max = geti("DFFW_NARROW_MAX", 1, 40);   // widest grid that may take the 5 x 8 x 8 block when its own block leaves the chip short of workgroups (8 = round 4)
         // conv_tile launches of at most this many (tile, channel-split) workgroups touch the weight lines of their whole contraction walk first
@@ -1941,7 +1942,7 @@ struct Run {
             // workgroups per tile keep three workgroups resident instead of two, -10 % on those layers; the stride-2 layers lose 40 % with it)
             // (transposed layers with 64 outputs: the 4-output-tile block runs at 127 TFLOP/s where two launches' worth of 2-tile workgroups run at 212 -- measured on End_to_End's
             // `dres2.conv5`, 384 tiles at batch 8 --, so they split up to 1024 tiles)
-            const int split_below = (cfg->geo == G3T && pc.nt >= 4) ? sw.split_t64 : ((cfg->geo == G3S1 || cfg->geo == G3T) ? 257 : 256);
+            const int split_below = (cfg->geo == G3T && pc.nt >= 4) ? sw.split_t64 : (cfg->geo == G3S1 && pc.nt == 4) ? sw.split_s64 : ((cfg->geo == G3S1 || cfg->geo == G3T) ? 257 : 256);
             if (t.total_tiles < split_below && pc.nt > 1 && !o.cls && !sw.on(SW_NO_SPLIT)) {
                 const int want = (256 + t.total_tiles - 1) / t.total_tiles;   // split factor that would fill the chip (narrow blocks: 512 measured level)
                 for (int nts = pc.nt / 2; nts >= 1; nts /= 2) {               // coarsest split first
