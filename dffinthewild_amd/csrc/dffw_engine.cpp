@@ -1942,7 +1942,7 @@ struct Run {
             // workgroups per tile keep three workgroups resident instead of two, -10 % on those layers; the stride-2 layers lose 40 % with it)
             // (transposed layers with 64 outputs: the 4-output-tile block runs at 127 TFLOP/s where two launches' worth of 2-tile workgroups run at 212 -- measured on End_to_End's
             // `dres2.conv5`, 384 tiles at batch 8 --, so they split up to 1024 tiles)
-            const int split_below = (cfg->geo == G3T && pc.nt >= 4) ? sw.split_t64 : (cfg->geo == G3S1 && pc.nt == 4) ? sw.split_s64 : ((cfg->geo == G3S1 || cfg->geo == G3T) ? 257 : 256);
+            const int split_below = (cfg->geo == G3T && pc.nt >= 4) ? sw.split_t64 : (cfg->geo == G3S1 && pc.nt == 4) || (cfg->geo == G3S2 && pc.nt >= 8) ? sw.split_s64 : ((cfg->geo == G3S1 || cfg->geo == G3T) ? 257 : 256);
             if (t.total_tiles < split_below && pc.nt > 1 && !o.cls && !sw.on(SW_NO_SPLIT)) {
                 const int want = (256 + t.total_tiles - 1) / t.total_tiles;   // split factor that would fill the chip (narrow blocks: 512 measured level)
                 for (int nts = pc.nt / 2; nts >= 1; nts /= 2) {               // coarsest split first
