@@ -60,6 +60,8 @@ constexpr int SLICE64_CHUNKS = 18;
 // ... and its HEAD variant (cin = 32 features + 2 flow channels in 40-channel records, slice-broadcast residual): 9 feature chunks + 3 chunks over the fifth
 // channel octet (K octet g of chunk 9 + k = tap 4k + g)
 constexpr int SLICE64_HEAD_CHUNKS = 12;
+// ... and its CAT variant (conv_slice32_cat: 32 -> 32 over t + the block's 1x1x1 shortcut over x as a tenth chunk; weights [output tile 2][chunk][part][64 lanes][8])
+constexpr int SLICE32_CAT_CHUNKS = 10;
 bool slice64_ok(int prec, const ConvArgs &a);
 hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_slice64_kernel_name(const ConvArgs &a, char *buf, int n);

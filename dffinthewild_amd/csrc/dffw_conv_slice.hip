@@ -318,16 +318,23 @@ constexpr int TY = DFFW_SLICE_TY, TX = DFFW_SLICE_TX, FY = TY + 2, FX = TX + 2, 
 static_assert(TY == 8 && TX == 16, "wave (nt, rh): rows 4 rh .. 4 rh + 3");
 constexpr int PARTE = FY * FX * 2;        // entries of one part of a 16-channel group: [row][pixel][octet]
 constexpr int CQE = 2 * PARTE;            // ... of a group: [part][row][pixel][octet]
-template <bool HEAD>
+// MODE 0: 64 -> 64; 1: HEAD; 2: CAT -- a 32 -> 32 conv over t with the block's 1x1x1 shortcut over a second 32-channel tensor x folded in as a tenth chunk
+// (`OF_feature2.1.conv.2`, End_to_End.py:135-145: out = relu(conv.2(t) + feature(x))): the image holds [t | x] as the four groups of a 64-channel virtual concat (x's
+// block starts on a DMA-piece boundary: a piece has one source), chunks 0-8 = the taps over t, chunk 9 = the centre tap over x; 2 output tiles: wave (nt, rg) = rows
+// 2 rg, 2 rg + 1, one pass per slice.
+template <int MODE>
 struct Lay {
+    static constexpr bool HEAD = MODE == 1, CAT = MODE == 2;
     static constexpr int NG = HEAD ? 3 : 4;
-    static constexpr int NCH = HEAD ? SLICE64_HEAD_CHUNKS : SLICE64_CHUNKS;
-    static constexpr int SLOTE = NG * CQE;
+    static constexpr int NCH = HEAD ? SLICE64_HEAD_CHUNKS : CAT ? SLICE32_CAT_CHUNKS : SLICE64_CHUNKS;
+    static constexpr int SRC1E = CAT ? (2 * CQE + 63) / 64 * 64 : 2 * CQE;   // entry at which groups 2, 3 start
+    static constexpr int SLOTE = SRC1E + (NG - 2) * CQE;
     static constexpr int PPW = ((SLOTE + 63) / 64 + NW - 1) / NW;
     static constexpr int NPIECE = PPW * NW;   // every wave issues PPW pieces per slice (the counted vmcnt waits rely on it): the slot is padded to whole rounds
     static constexpr int SLOTB = NPIECE * 1024;
     static constexpr int LDSB = RING * SLOTB;
-    static constexpr int RECB = HEAD ? 160 : 256, PARTB = RECB / 2, NOCT = RECB / 32;   // a pixel record [hi C][lo C] of the source
+    static constexpr int RECB = HEAD ? 160 : CAT ? 128 : 256, PARTB = RECB / 2, NOCT = RECB / 32;   // a pixel record [hi C][lo C] of a source
+    static constexpr int NTW = CAT ? 2 : 4, PASSES = CAT ? 1 : 2, COUT = NTW * 16;   // output tiles; passes of two rows per wave and slice
     static_assert(NCH % 2 == 0, "an even chunk count keeps the fragment buffers' parity over passes and slices");
     static_assert(CQE % 16 == 0 && SLOTB % 256 == 0 && LDSB <= 160 * 1024, "LDS layout (one workgroup per CU)");
 };
@@ -335,16 +342,17 @@ struct Lay {
 
 // (the body is a device function template and the kernels thin wrappers: with the layout's dependent constants directly inside a __global__ template, hipcc's host
 // pass silently emits no launch stub)
-template <bool RELU, bool SUMS, bool HEAD>
+template <bool RELU, bool SUMS, int MODE>
 __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &t, unsigned char *smem) {
-    static_assert(!SUMS || (RELU && !HEAD), "row sums: relu(acc), no residual");
+    constexpr bool HEAD = MODE == 1, CAT = MODE == 2;
+    static_assert(!SUMS || (RELU && MODE == 0), "row sums: relu(acc), no residual");
     using namespace slice64;
-    using L = Lay<HEAD>;
+    using L = Lay<MODE>;
     constexpr int NCH = L::NCH, PPW = L::PPW, SLOTB = L::SLOTB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
-    const int nt = wave & 3, rh = wave >> 2;
+    const int nt = wave & (L::NTW - 1), rh = wave / L::NTW;   // (CAT: rh = row pair 0..3)
 
     const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     int ufirst, uend;
@@ -371,25 +379,30 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
     // ---- fill (as conv_slice32) ----
     constexpr int recb = L::RECB, partb = L::PARTB;
     const char *tb = reinterpret_cast<const char *>(a.in0);
+    const char *tb1 = CAT ? reinterpret_cast<const char *>(a.in1) : tb;
     const int slice_bytes = a.Hi * a.Wi * recb;
     int fvo[PPW];
-    const char *fb = tb;
+    const char *fb = tb, *fb1 = tb1;
     int fu = ufirst, fz = 0;
     auto setup_fill = [&]() {
         const Unit c = decode(fu);
         fz = 0;
         fb = tb + ((int64_t)c.b * a.Ni * a.Hi * a.Wi + (int64_t)(c.gy0 - 1) * a.Wi + (c.gx0 - 1)) * recb;
+        fb1 = tb1 + ((int64_t)c.b * a.Ni * a.Hi * a.Wi + (int64_t)(c.gy0 - 1) * a.Wi + (c.gx0 - 1)) * recb;
         int ln = lane;
         asm volatile("" : "+v"(ln));                       // (opaque: no hoisting of the decode out of the unit loop)
 #pragma unroll
         for (int k = 0; k < PPW; ++k) {
-            const int e = (k * NW + wave) * 64 + ln;       // entry inside the slot: [group][part][row][pixel][octet]
-            const int cq = e / CQE, e2 = e - cq * CQE;
+            const int e = (k * NW + wave) * 64 + ln;       // entry inside the slot: [group][part][row][pixel][octet] (CAT: groups 2, 3 from entry SRC1E)
+            const bool s1 = CAT && e >= L::SRC1E;
+            const int es = s1 ? e - L::SRC1E : e;
+            const int cqs = es / CQE, e2 = es - cqs * CQE; // group inside its source
+            const int cq = cqs + (s1 ? 0 : 0);
             const int part = e2 / PARTE, e3 = e2 - part * PARTE;
             const int fy = e3 / (2 * FX), e4 = e3 - fy * (2 * FX);
             const int fx = e4 >> 1, oct = e4 & 1;
             const int iy = c.gy0 - 1 + fy, ix = c.gx0 - 1 + fx;
-            fvo[k] = (e < L::SLOTE && cq * 2 + oct < L::NOCT && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+            fvo[k] = (e < L::SLOTE && (!CAT || s1 || e < 2 * CQE) && cq * 2 + oct < L::NOCT && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
                          ? (fy * a.Wi + fx) * recb + part * partb + (cq * 2 + oct) * 16
                          : (int)0x80000000;
         }
@@ -400,7 +413,8 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
         constexpr int k = decltype(K)::value;
         const int p = k * NW + wave;
         const bool zin = fu < uend;                        // past the end of the stream: zeros (the slot is never read)
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fb), 0, zin ? (int)0x80000000 : 0, 0x00020000);
+        const char *fbp = (CAT && p * 64 >= L::SRC1E) ? fb1 : fb;   // (wave-uniform: a piece has one source)
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fbp), 0, zin ? (int)0x80000000 : 0, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smem + fslotb + p * 1024), 16, fvo[k], zin ? fz * slice_bytes : 0, 0, 0);
     };
     auto advance_fill = [&]() {
@@ -420,7 +434,8 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
     // of the tap.  HEAD: chunk c < 9 = tap c over the 32 feature channels (groups 0, 1); chunk 9 + k: K octet g = octet 0 of group 2 at tap 4k + g (taps >= 9: zero
     // weights, tap 8's operands).  Lane r of operand tile j of pass p = pixel (row 4 rh + 2 p + j, column r): tap, half, pass, tile and part are immediates.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned abase = lds0 + (unsigned)(((g >> 1) * CQE + (4 * rh) * 2 * FX + r * 2 + (g & 1)) * 16);
+    constexpr int RPW = 2 * L::PASSES;   // rows per wave
+    const unsigned abase = lds0 + (unsigned)(((g >> 1) * CQE + (RPW * rh) * 2 * FX + r * 2 + (g & 1)) * 16);
     unsigned afl[3] = {0, 0, 0};
     if constexpr (HEAD) {
 #pragma unroll
@@ -434,7 +449,7 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) vob[ps][j] = ((4 * rh + 2 * ps + j) * a.Wo + r) * 128 + (g & 1) * 64 + (nt * 2 + (g >> 1)) * 8;
+        for (int j = 0; j < 2; ++j) vob[ps][j] = ((RPW * rh + 2 * ps + j) * a.Wo + r) * (2 * L::COUT) + (g & 1) * L::COUT + (nt * 2 + (g >> 1)) * 8;
 
     // ---- this output tile's filter: NCH chunks x (hi, lo), resident for the whole walk ----
     short8 w[NCH][2];
@@ -467,8 +482,8 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][0]) : "v"(adf), "n"(off + row1));
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][1][1]) : "v"(adf), "n"(off + row1 + pb));
         } else {
-            constexpr int tap = HEAD ? c : c / 2, hf = HEAD ? 0 : c % 2;
-            constexpr int tapo = ((tap / 3 + 2 * ps) * 2 * FX + (tap % 3) * 2 + hf * 2 * CQE) * 16;
+            constexpr int tap = HEAD ? c : CAT ? (c < 9 ? c : 4) : c / 2, hf = HEAD ? 0 : CAT ? (c < 9 ? 0 : 1) : c % 2;
+            constexpr int tapo = ((tap / 3 + 2 * ps) * 2 * FX + (tap % 3) * 2 + hf * L::SRC1E) * 16;
             static_assert(tapo + row1 + pb < 65536, "ds_read immediate");
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][0]) : "v"(ad), "n"(tapo));
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xx[b][0][1]) : "v"(ad), "n"(tapo + pb));
@@ -504,7 +519,7 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
             constexpr int c = decltype(C)::value;
             constexpr int cur = c & 1, nxt = cur ^ 1;
             if constexpr (c + 1 < NCH) fetch(std::integral_constant<int, nxt>{}, std::integral_constant<int, (c + 1 < NCH ? c + 1 : 0)>{}, std::integral_constant<int, ps>{}, x, cur0, afc);
-            else if constexpr (ps == 0) fetch(std::integral_constant<int, nxt>{}, I0{}, I1{}, x, cur0, afc);   // the second pass's chunk 0
+            else if constexpr (ps + 1 < L::PASSES) fetch(std::integral_constant<int, nxt>{}, I0{}, I1{}, x, cur0, afc);   // the second pass's chunk 0
             else fetch(std::integral_constant<int, nxt>{}, I0{}, I0{}, x, nxtb, afn);                          // the next slice's: resident since the last barrier
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[cur][0][0]), "+v"(x[cur][0][1]), "+v"(x[cur][1][0]), "+v"(x[cur][1][1]));
             // product-major over the two accumulators
@@ -561,20 +576,20 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
         const unsigned cur0 = abase + (unsigned)sidxb;
         const unsigned nxtb = abase + slotd;
         pass(I0{}, PRE_, cur0, nxtb, slotd, optr, srow, fresh);
-        pass(I1{}, std::true_type{}, cur0, nxtb, slotd, optr, srow, false);
+        if constexpr (L::PASSES == 2) pass(I1{}, std::true_type{}, cur0, nxtb, slotd, optr, srow, false);
         // the slice queued in this step (and everything older) has landed; this step's four stores may stay in flight across the barrier
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SUMS ? 0 : 4) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SUMS ? 0 : 2 * L::PASSES) : "memory");
         asm volatile("" : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][1][0]), "+v"(x[0][1][1]));
         sidxb = (sidxb + SLOTB == RING * SLOTB) ? 0 : sidxb + SLOTB;
         advance_fill();
     };
 
-    const int64_t ostride = (int64_t)a.Ho * a.Wo * 256;   // bytes per output slice (64 channels, hi + lo)
+    const int64_t ostride = (int64_t)a.Ho * a.Wo * 4 * L::COUT;   // bytes per output slice (hi + lo)
     const int64_t sstride = (int64_t)a.Ho * t.tiles_x * 3 * 64;   // row-sum floats per slice
     bool first = true;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
-        const int64_t o0 = (((int64_t)U.b * a.No * a.Ho + U.gy0) * a.Wo + U.gx0) * 256;
+        const int64_t o0 = (((int64_t)U.b * a.No * a.Ho + U.gy0) * a.Wo + U.gx0) * 4 * L::COUT;
         char *optr = SUMS ? nullptr : reinterpret_cast<char *>(a.out) + o0;
         float *sp = SUMS ? a.outf + (((int64_t)U.b * a.No * a.Ho + U.gy0) * t.tiles_x + U.gx0 / TX) * 3 * 64 : nullptr;
         if constexpr (HEAD) {
@@ -600,13 +615,18 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
 
 template <bool RELU, bool SUMS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice64(const ConvArgs a, const RollArgs t) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[slice64::Lay<false>::LDSB];
-    slice64_body<RELU, SUMS, false>(a, t, smem);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[slice64::Lay<0>::LDSB];
+    slice64_body<RELU, SUMS, 0>(a, t, smem);
 }
 template <bool RELU>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice64_head(const ConvArgs a, const RollArgs t) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[slice64::Lay<true>::LDSB];
-    slice64_body<RELU, false, true>(a, t, smem);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[slice64::Lay<1>::LDSB];
+    slice64_body<RELU, false, 1>(a, t, smem);
+}
+template <bool RELU>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_slice32_cat(const ConvArgs a, const RollArgs t) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[slice64::Lay<2>::LDSB];
+    slice64_body<RELU, false, 2>(a, t, smem);
 }
 
 void slice32_tile(int *ty, int *tx) {
@@ -649,8 +669,9 @@ bool slice64_ok(int prec, const ConvArgs &a) {
         if (!a.outf || a.relu != 1) return false;
     } else if (!a.out || a.outf) return false;
     const bool head = a.res_bcast && a.res0 && a.C0 == 40 && !(a.dbg & DFFW_ARGS_SUMS);   // the level-3 head's first conv over [features 32 | flow 2 | pad 6]
+    const bool cat = a.C0 == 32 && a.C1 == 32 && a.in1 && a.Cout == 32 && !a.res0 && !a.res_bcast && !(a.dbg & DFFW_ARGS_SUMS);   // 32 -> 32 with the folded shortcut over a second tensor
     if ((a.res0 || a.res_bcast) && !head) return false;
-    if (a.out_pre || a.res1 || a.cls_w || a.relu == 2 || a.Cout != 64 || (a.C0 != 64 && !head) || a.C1 != 0) return false;
+    if (a.out_pre || a.res1 || a.cls_w || a.relu == 2 || (a.Cout != 64 && !cat) || (a.C0 != 64 && !head && !cat) || (a.C1 != 0 && !cat)) return false;
     if (a.Ho % slice64::TY || a.Wo % slice64::TX || a.Ho != a.Hi || a.Wo != a.Wi || a.No != a.Ni) return false;
     // 32-bit buffer offsets: a sample's input volume (+ one footprint) stays below 2^31 bytes
     return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * 256 < (1ll << 31) && (int64_t)a.Ho * a.Wo * 256 < (1ll << 31);
@@ -660,7 +681,10 @@ hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t
     const int want = t.wgs > 0 ? t.wgs : 256;   // one 8-wave workgroup per CU
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(slice64::NW * 64);
-    if (a.res_bcast) {
+    if (a.C1 == 32) {
+        if (a.relu == 1) hipLaunchKernelGGL((conv_slice32_cat<true>), grid, block, 0, s, a, t);
+        else hipLaunchKernelGGL((conv_slice32_cat<false>), grid, block, 0, s, a, t);
+    } else if (a.res_bcast) {
         if (a.relu == 1) hipLaunchKernelGGL((conv_slice64_head<true>), grid, block, 0, s, a, t);
         else hipLaunchKernelGGL((conv_slice64_head<false>), grid, block, 0, s, a, t);
     } else if (a.dbg & DFFW_ARGS_SUMS) hipLaunchKernelGGL((conv_slice64<true, true>), grid, block, 0, s, a, t);
@@ -670,7 +694,8 @@ hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t
 }
 
 void conv_slice64_kernel_name(const ConvArgs &a, char *buf, int n) {
-    if (a.res_bcast) snprintf(buf, n, "dffw::conv_slice64_head<%s>", a.relu == 1 ? "true" : "false");
+    if (a.C1 == 32) snprintf(buf, n, "dffw::conv_slice32_cat<%s>", a.relu == 1 ? "true" : "false");
+    else if (a.res_bcast) snprintf(buf, n, "dffw::conv_slice64_head<%s>", a.relu == 1 ? "true" : "false");
     else snprintf(buf, n, "dffw::conv_slice64<%s, %s>", (a.dbg & DFFW_ARGS_SUMS) || a.relu == 1 ? "true" : "false", (a.dbg & DFFW_ARGS_SUMS) ? "true" : "false");
 }
 

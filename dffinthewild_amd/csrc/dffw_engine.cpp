@@ -311,6 +311,7 @@ struct PackedConv {
     bool roll_pair = false;     // ... packed for its pixel-pair variant (<= 8 output channels)
     uint16_t *wroll_k2 = nullptr;  // device: a 3x3x3 stride-1 32 -> 16 filter in conv_rollx_k2's order: [input half][conv_roll's 15 chunks]
     uint16_t *wslice32 = nullptr;  // device: a 1x3x3 32 -> 32 filter in conv_slice32's order: [9 taps][output tile][part]
+    bool slice_cat = false;        // wslice64 holds a 32 -> 32 filter + folded 1x1x1 shortcut over a second 32-channel tensor in conv_slice32_cat's order
     uint16_t *wslice64 = nullptr;  // device: a 1x3x3 64 -> 64 filter in conv_slice64's order: [output tile][chunk = tap * 2 + channel half][part]; or (a 34 -> 64 `#cur` layer of
                                    // an alignment head) in its HEAD order: [output tile][9 feature chunks + 3 chunks over the flow octet][part]
     uint16_t *wrollk = nullptr;    // device: a 3x3x3 stride-1 32 / 64 -> 32 / 64 filter in conv_rollk's order: [32-channel output pair][wave][7 chunks][output tile]
@@ -747,6 +748,26 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                     }
         HIPCHK(hipMalloc((void **)&pc.wslice64, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wslice64, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ... and its CAT variant (conv_slice32_cat): 32 -> 32 over t with the block's folded 1x1x1 shortcut over x: chunks 0-8 = the taps over t, chunk 9 = the centre tap
+    // over the shortcut's 32 channels (channels 32 .. 63 of the virtual concat)
+    if (geo == G2S1 && cin_own == 32 && shortcut_w && shortcut_cin == 32 && L.cout == 32 && prec == P_BF16X3) {
+        std::vector<uint16_t> wr((size_t)2 * SLICE32_CAT_CHUNKS * parts * 512, 0);
+        for (int nt = 0; nt < 2; ++nt)
+            for (int c = 0; c < SLICE32_CAT_CHUNKS; ++c)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = lane & 15, gq = lane >> 4, tap = c < 9 ? c : 4;
+                        const float val = (float)wval(nt * 16 + row, (c < 9 ? 0 : 32) + gq * 8 + j, Tap{0, tap / 3 - 1, tap % 3 - 1, 0, tap / 3, tap % 3});
+                        uint16_t hi, lo;
+                        host_split(prec, val, hi, lo);
+                        const size_t base = (((size_t)nt * SLICE32_CAT_CHUNKS + c) * parts) * 512 + (size_t)lane * 8 + j;
+                        wr[base] = hi;
+                        wr[base + 512] = lo;
+                    }
+        HIPCHK(hipMalloc((void **)&pc.wslice64, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wslice64, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        pc.slice_cat = true;
     }
     // ---- conv_rollk (dffw_conv_rollk.hip): 3x3x3 stride 1, 32 / 64 -> 32 / 64 channels, the contraction split over the workgroup's waves: wave w =
     // (16-channel group w >> 1, tap half w & 1); tap slot s of a half = filter tap 14 * (w & 1) + s in [dz][ky][kx] order (tap 27: zero weights);
@@ -1791,7 +1812,7 @@ struct Run {
             }
         }
         // per-slice 1x3x3, 64 -> 64 channels on whole 8 x 16 columns: the streaming kernel with one output tile's filter resident per wave
-        if (pc.wslice64 && !o.in1 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_SLICE32)) {
+        if (pc.wslice64 && (pc.slice_cat ? (o.in1 && o.in1->C == 32) : !o.in1) && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_SLICE32)) {
             int sty, stx;
             slice32_tile(&sty, &stx);
             const int cols = (Ho / sty) * (Wo / stx);
