@@ -730,6 +730,10 @@ hipError_t launch_srd_attention(int prec, const uint16_t *feat, uint16_t *out, c
 // bilinear corners once and reuses them for every channel.  The fp32 operation order of the reference
 // (normalise to [-1,1], then grid_sample's un-normalise) is kept so the result matches to rounding.
 // (WarpPoint / warp_point / warp_octet: dffw_device.h, shared with conv_tile's warp-fill variant)
+// OFF: the type of a corner's byte offset inside one (sample, channel) volume -- unsigned whenever the volume is below 4 GiB (any real stack): the loads and the
+// store then address as uniform base + 32-bit lane offset (round 5: the 64-bit per-lane address arithmetic was 100 of the kernel's 470 vector instructions, and the
+// kernel is bound by them: valu_issue 0.80); int64_t otherwise.  Sample arithmetic and summation order are the same in both.
+template <typename OFF>
 __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__ x, const float *__restrict__ alpha,
                                                        const float *__restrict__ fov, float *__restrict__ out,
                                                        float *__restrict__ flow, int B, int C, int N, int H, int W,
@@ -738,29 +742,51 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
     // kernel's longest dependency chain)
     const int64_t plane = (int64_t)H * W;
     const int n = blockIdx.y % N, b = blockIdx.y / N;
+    // the reference's batch>1 quirk (End_to_End.py:112): `alpha[:,0,:,:] + FOVs` broadcasts to (B,B,N,1,1) and `[:,0]` keeps
+    // alpha[0,n] + FOVs[b,n] -- sample 0's scale offset, but every sample's OWN field of view
+    const int ab = alpha_from_sample0 ? 0 : b;
+    const float a0 = alpha[(ab * 3 + 0) * N + n], a1 = alpha[(b * 3 + 1) * N + n], a2 = alpha[(b * 3 + 2) * N + n];
+    const float f = a0 + fov[b * N + n];
+    const float gz = 2.0f * (float)n / (float)(N > 1 ? N - 1 : 1) - 1.0f;
+    const float sz = ((gz + 1.0f) * 0.5f) * (float)(N - 1);
+    const float z0f = floorf(sz);
+    const int z0 = (int)z0f;
+    const float wz1 = sz - z0f;
+    const float wz[2] = {1.0f - wz1, wz1};
+    const bool blend_z = wz1 != 0.f;   // (wave-uniform: the slice coordinate depends on n alone)
+    // 32-bit offsets go through buffer instructions (scalar descriptor of the wave-uniform base + the lane's byte offset: no 64-bit address per lane)
+    auto ld = [](const char *base, OFF off) -> float {
+        if constexpr (sizeof(OFF) == 4) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, (int)0xFFFFFFFF, 0x00020000);
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+        } else {
+            return *reinterpret_cast<const float *>(base + off);
+        }
+    };
+    auto st = [](char *base, OFF off, float v) {
+        if constexpr (sizeof(OFF) == 4) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)0xFFFFFFFF, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)off, 0, 0);
+        } else {
+            *reinterpret_cast<float *>(base + off) = v;
+        }
+    };
     for (unsigned ip = blockIdx.x * 256u + threadIdx.x; ip < (unsigned)plane; ip += gridDim.x * 256u) {
         const int yy = (int)(ip / (unsigned)W), xx = (int)(ip - (unsigned)yy * (unsigned)W);
-        // the reference's batch>1 quirk (End_to_End.py:112): `alpha[:,0,:,:] + FOVs` broadcasts to (B,B,N,1,1) and `[:,0]` keeps
-        // alpha[0,n] + FOVs[b,n] -- sample 0's scale offset, but every sample's OWN field of view
-        const int ab = alpha_from_sample0 ? 0 : b;
-        const float a0 = alpha[(ab * 3 + 0) * N + n], a1 = alpha[(b * 3 + 1) * N + n], a2 = alpha[(b * 3 + 2) * N + n];
-        const float f = a0 + fov[b * N + n];
         const WarpPoint wp = warp_point(xx, yy, H, W, f, a1, a2);
         if (flow) {
-            flow[((int64_t)(b * 2 + 0) * N + n) * plane + (int64_t)yy * W + xx] = wp.fx;
-            flow[((int64_t)(b * 2 + 1) * N + n) * plane + (int64_t)yy * W + xx] = wp.fy;
+            flow[((int64_t)(b * 2 + 0) * N + n) * plane + ip] = wp.fx;
+            flow[((int64_t)(b * 2 + 1) * N + n) * plane + ip] = wp.fy;
         }
-        const float gz = 2.0f * (float)n / (float)(N > 1 ? N - 1 : 1) - 1.0f;
         const float sx = wp.sx, sy = wp.sy;
-        const float sz = ((gz + 1.0f) * 0.5f) * (float)(N - 1);
-        const float x0f = floorf(sx), y0f = floorf(sy), z0f = floorf(sz);
-        const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
-        const float wx1 = sx - x0f, wy1 = sy - y0f, wz1 = sz - z0f;
-        const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1}, wz[2] = {1.0f - wz1, wz1};
-        // the (up to) 8 corners once per pixel: offset, weight, validity; then per channel all corner loads are requested
+        const float x0f = floorf(sx), y0f = floorf(sy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float wx1 = sx - x0f, wy1 = sy - y0f;
+        const float wx[2] = {1.0f - wx1, wx1}, wy[2] = {1.0f - wy1, wy1};
+        // the (up to) 8 corners once per pixel: byte offset, weight, validity; then per channel all corner loads are requested
         // together (as nested loops with early-outs every corner waited for its own load).  Corners outside the volume, or on a
         // slice with zero weight, are skipped exactly as before, and the sum runs in the same (dz, dy, dx) order.
-        int64_t coff[8];
+        OFF coff[8];
         float cw[8];
         bool cok[8];
 #pragma unroll
@@ -768,35 +794,38 @@ __global__ __launch_bounds__(256) void fov_warp_kernel(const float *__restrict__
             const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
             const int zz = z0 + dz, yc = y0 + dy, xc = x0 + dx;
             cok[k] = zz >= 0 && zz < N && wz[dz] != 0.f && yc >= 0 && yc < H && xc >= 0 && xc < W;
-            coff[k] = cok[k] ? (int64_t)zz * plane + (int64_t)yc * W + xc : 0;
+            coff[k] = cok[k] ? ((OFF)zz * (OFF)plane + (OFF)(yc * W + xc)) * (OFF)4 : (OFF)0;
             cw[k] = wx[dx] * wy[dy] * wz[dz];
         }
+        const OFF ooff = (OFF)ip * (OFF)4;
         // the slice coordinate is the slice index itself for most slices (exactly: for N = 10 all but slices 1 and 2, where it falls
-        // one ulp short): when no lane of the wave blends two slices only the four in-plane corners are requested
-        if (__builtin_amdgcn_ballot_w64(wz1 != 0.f) == 0) {
+        // one ulp short): then only the four in-plane corners are requested
+        if (!blend_z) {
             for (int c = 0; c < C; ++c) {
-                const float *src = x + ((int64_t)b * C + c) * N * plane;
+                const char *src = reinterpret_cast<const char *>(x + ((int64_t)b * C + c) * N * plane);   // (wave-uniform bases)
+                char *dst = reinterpret_cast<char *>(out + (((int64_t)b * C + c) * N + n) * plane);
                 float v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = src[coff[k]];
+                for (int k = 0; k < 4; ++k) v[k] = ld(src, coff[k]);
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (cok[k]) acc += v[k] * cw[k];
-                out[(((int64_t)b * C + c) * N + n) * plane + (int64_t)yy * W + xx] = acc;
+                st(dst, ooff, acc);
             }
             continue;
         }
         for (int c = 0; c < C; ++c) {
-            const float *src = x + ((int64_t)b * C + c) * N * plane;
+            const char *src = reinterpret_cast<const char *>(x + ((int64_t)b * C + c) * N * plane);
+            char *dst = reinterpret_cast<char *>(out + (((int64_t)b * C + c) * N + n) * plane);
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = src[coff[k]];
+            for (int k = 0; k < 8; ++k) v[k] = ld(src, coff[k]);
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (cok[k]) acc += v[k] * cw[k];
-            out[(((int64_t)b * C + c) * N + n) * plane + (int64_t)yy * W + xx] = acc;
+            st(dst, ooff, acc);
         }
     }
 }
@@ -805,8 +834,9 @@ hipError_t launch_fov_warp(const float *x, const float *alpha, const float *fov,
                            int H, int W, int alpha_from_sample0, hipStream_t s) {
     const int64_t plane = (int64_t)H * W;
     if (plane >= (1ll << 31) || (int64_t)B * N > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fov_warp_kernel, dim3((unsigned)std::min<int64_t>((plane + 255) / 256, 65535), B * N), dim3(256), 0, s, x, alpha, fov, out, flow,
-                       B, C, N, H, W, alpha_from_sample0);
+    const dim3 grid((unsigned)std::min<int64_t>((plane + 255) / 256, 65535), B * N);
+    if ((int64_t)N * plane * 4 < (1ll << 32)) hipLaunchKernelGGL(fov_warp_kernel<unsigned>, grid, dim3(256), 0, s, x, alpha, fov, out, flow, B, C, N, H, W, alpha_from_sample0);
+    else hipLaunchKernelGGL(fov_warp_kernel<int64_t>, grid, dim3(256), 0, s, x, alpha, fov, out, flow, B, C, N, H, W, alpha_from_sample0);
     return hipGetLastError();
 }
 
