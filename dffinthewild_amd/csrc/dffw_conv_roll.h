@@ -65,6 +65,44 @@ constexpr int SLICE32_CAT_CHUNKS = 10;
 bool slice64_ok(int prec, const ConvArgs &a);
 hipError_t launch_conv_slice64(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_slice64_kernel_name(const ConvArgs &a, char *buf, int n);
+// conv_rollt (dffw_conv_rollt.hip, round 6): transposed 3x3x3 s(1,2,2) p1 op(0,1,1) over 32 / 64 input channels, 32 output channels per workgroup row
+// (grid.y = 32-channel output half), rolling window over 8 x 8 columns of the INPUT grid.  The filter is resident and split over the workgroup's waves
+// by OUTPUT PHASE (py, px) -- 3 / 6 / 6 / 12 of the 27 taps -- and 16-channel output tile; only phase (1,1) at 64 input channels is also split over K
+// (between the wave pair A / B, which exchange one partial tile per operand tile through LDS).  A wave's program is a list of operand fragment
+// sets (window slice d, row tap dy, column tap dx, 32-channel chunk) and the accumulator slots each set feeds; host packing and kernel share it.
+#define DFFW_ROLLT_TY 8
+#define DFFW_ROLLT_TX 8
+namespace rollt {
+enum Role { R_A = 0, R_B = 1, R_C = 2, R_D = 3, R_A32 = 4, R_C32 = 5 };
+constexpr int MAXU = 15;   // weight units (one tap x 32 channels x 16 outputs, hi + lo) per wave: the filter buffer's wave stride
+template <int ROLE>
+struct Prog {
+    static constexpr bool AB = ROLE == R_A || ROLE == R_B || ROLE == R_A32;   // phases (1,1) [slot 0] + (0,0) [slot 1]
+    static constexpr bool XCH = ROLE == R_A || ROLE == R_B;                   // K-split pair: A sends slot 0, B sends slot 1
+    static constexpr int SEND = ROLE == R_A ? 0 : ROLE == R_B ? 1 : -1;
+    static constexpr int NS = ROLE == R_C32 ? 9 : 12;                         // operand fragment sets per operand-tile pair
+    static constexpr int NACC = (ROLE == R_C || ROLE == R_D) ? 1 : 2;         // accumulator slots
+    static constexpr int NOWN = XCH ? 1 : NACC;                               // ... whose result this wave finishes
+    static constexpr int own(int k) { return XCH ? 1 - SEND : k; }            // k-th own slot
+    static constexpr int d(int i) { return ROLE == R_C32 ? i / 3 : i / 4; }   // window slice 0..2 = input slice z - 1 + d = filter slice 2 - d
+    static constexpr int dy(int i) { return AB ? (i % 4) / 2 : ROLE == R_C ? 0 : ROLE == R_D ? i % 2 : (i % 3 == 2 ? 1 : 0); }
+    static constexpr int dx(int i) { return AB ? i % 2 : ROLE == R_C ? i % 2 : ROLE == R_D ? 0 : (i % 3 == 1 ? 1 : 0); }
+    static constexpr int chunk(int i) { return ROLE == R_B ? 1 : (ROLE == R_C || ROLE == R_D) ? (i % 4) / 2 : 0; }
+    static constexpr int feeds(int i) { return AB ? (i % 4 == 0 ? 3 : 1) : ROLE == R_C32 ? (i % 3 == 0 ? 3 : i % 3 == 1 ? 1 : 2) : 1; }   // bit mask of slots
+    static constexpr int phase(int slot) { return AB ? (slot == 0 ? 3 : 0) : ROLE == R_C ? 1 : ROLE == R_D ? 2 : (slot == 0 ? 1 : 2); }   // py * 2 + px
+    static constexpr int nfeed(int i) { return (feeds(i) & 1) + (feeds(i) >> 1); }
+    static constexpr int ubase(int i) { return i == 0 ? 0 : ubase(i - 1) + nfeed(i - 1); }   // first weight unit of set i (one per fed slot, slot order)
+    static constexpr int NU = ubase(NS);
+    static_assert(NU <= MAXU, "filter share");
+};
+// filter tap (ky or kx) of output phase bit p at input offset dd (p = 0: offset 0 only, tap 1; p = 1: offset 0 -> tap 2, offset 1 -> tap 0)
+constexpr int tap_of(int p, int dd) { return p == 0 ? 1 : (dd ? 0 : 2); }
+}   // namespace rollt
+// wave w of an 8-wave workgroup (64 input channels): output tile (w >> 1) & 1, role (w >> 2) * 2 + (w & 1) = A, B | C, D; of a 4-wave one (32): tile w >> 1, role A32 / C32
+inline int rollt_role(int cin, int wave) { return cin == 64 ? (wave >> 2) * 2 + (wave & 1) : (wave & 1 ? rollt::R_C32 : rollt::R_A32); }
+bool rollt_ok(int prec, const ConvArgs &a);   // the kernel covers the launch (a.Ng/Hg/Wg = input grid)
+hipError_t launch_conv_rollt(const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_rollt_kernel_name(const ConvArgs &a, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)
 constexpr int ROLL_CHUNKS_T = 9;
 // transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one launch per output row phase py (filter packed per phase: 9 / 18 chunks of one

@@ -315,6 +315,7 @@ struct PackedConv {
     uint16_t *wslice64 = nullptr;  // device: a 1x3x3 64 -> 64 filter in conv_slice64's order: [output tile][chunk = tap * 2 + channel half][part]; or (a 34 -> 64 `#cur` layer of
                                    // an alignment head) in its HEAD order: [output tile][9 feature chunks + 3 chunks over the flow octet][part]
     uint16_t *wrollk = nullptr;    // device: a 3x3x3 stride-1 32 / 64 -> 32 / 64 filter in conv_rollk's order: [32-channel output pair][wave][7 chunks][output tile]
+    uint16_t *wrollt = nullptr;    // device: a transposed 3x3x3 32 / 64 -> 32 / 64 filter in conv_rollt's order: [32-channel output half][wave][rollt::MAXU units][part]
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
     uint16_t *wroll_s2 = nullptr;  // device: a 3x3x3 stride-(1,2,2) 16 -> 16 / 32 filter in conv_roll_s2's order (15 chunks per 16-channel output tile)
@@ -355,6 +356,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll_k2 = nullptr;
     if (pc.wrollk) (void)hipFree(pc.wrollk);
     pc.wrollk = nullptr;
+    if (pc.wrollt) (void)hipFree(pc.wrollt);
+    pc.wrollt = nullptr;
     if (pc.wslice32) (void)hipFree(pc.wslice32);
     pc.wslice32 = nullptr;
     if (pc.wslice64) (void)hipFree(pc.wslice64);
@@ -797,6 +800,47 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                             }
         HIPCHK(hipMalloc((void **)&pc.wrollk, wr.size() * sizeof(uint16_t)));
         HIPCHK(hipMemcpy(pc.wrollk, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    // ---- conv_rollt (dffw_conv_rollt.hip): transposed 3x3x3 s(1,2,2), 32 / 64 -> 32 / 64 channels, the filter split over the workgroup's waves by output phase
+    // and 16-channel output tile (rollt::Prog<role>: the wave's operand fragment sets and the accumulator slots = output phases each feeds).  A weight unit =
+    // one tap x 32 channels (K octet g = channels 32 chunk + 8 g ..) x 16 outputs; units in the wave's set order, one per fed slot
+    if (geo == G3T && (cin_pad == 32 || cin_pad == 64) && L.cin == cin_pad && L.cout % 32 == 0 && L.cout <= 64 && !shortcut_w && prec == P_BF16X3) {
+        const int nw = cin_pad / 8, nhalf = L.cout / 32;
+        std::vector<uint16_t> wr((size_t)nhalf * nw * rollt::MAXU * parts * 512, 0);
+        auto pack_role = [&](auto ROLE_, int oh, int wv) {
+            using PR = rollt::Prog<decltype(ROLE_)::value>;
+            const int cout0 = (oh * 2 + ((wv >> 1) & 1)) * 16;
+            for (int i = 0; i < PR::NS; ++i) {
+                int u = PR::ubase(i);
+                for (int sl = 0; sl < PR::NACC; ++sl) {
+                    if (!((PR::feeds(i) >> sl) & 1)) continue;
+                    const int ph = PR::phase(sl), py = ph >> 1, px = ph & 1, d = PR::d(i), dy = PR::dy(i), dx = PR::dx(i);
+                    const Tap tp{d - 1, dy, dx, 2 - d, rollt::tap_of(py, dy), rollt::tap_of(px, dx)};
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const float val = (float)wval(cout0 + (lane & 15), PR::chunk(i) * 32 + (lane >> 4) * 8 + j, tp);
+                            uint16_t hi, lo;
+                            host_split(prec, val, hi, lo);
+                            const size_t base = ((((size_t)oh * nw + wv) * rollt::MAXU + u) * parts) * 512 + (size_t)lane * 8 + j;
+                            wr[base] = hi;
+                            wr[base + 512] = lo;
+                        }
+                    ++u;
+                }
+            }
+        };
+        for (int oh = 0; oh < nhalf; ++oh)
+            for (int wv = 0; wv < nw; ++wv)
+                switch (rollt_role(cin_pad, wv)) {
+                    case rollt::R_A: pack_role(std::integral_constant<int, rollt::R_A>{}, oh, wv); break;
+                    case rollt::R_B: pack_role(std::integral_constant<int, rollt::R_B>{}, oh, wv); break;
+                    case rollt::R_C: pack_role(std::integral_constant<int, rollt::R_C>{}, oh, wv); break;
+                    case rollt::R_D: pack_role(std::integral_constant<int, rollt::R_D>{}, oh, wv); break;
+                    case rollt::R_A32: pack_role(std::integral_constant<int, rollt::R_A32>{}, oh, wv); break;
+                    default: pack_role(std::integral_constant<int, rollt::R_C32>{}, oh, wv); break;
+                }
+        HIPCHK(hipMalloc((void **)&pc.wrollt, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(pc.wrollt, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- srd_roll stage C: the attention convs of the 8-channel SRD block (DEN.py:322-323) in pixel-pair form.  Result row
     // m = (pixel m >> 3 of the pair, channel m & 7).  3x1x1: chunk 0 K octet g = (pixel g >> 1, slice g & 1), chunk 1 = slice 2 in the
@@ -1278,7 +1322,7 @@ static bool getenv_flag(const char *name) {
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_SPLIT) X(NO_SPLITK)  \
     X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_ROLLK) X(NO_SLICE32) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_ROLLK) X(NO_ROLLT) X(NO_SLICE32) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1287,7 +1331,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1316,8 +1360,10 @@ struct Switches {
         // (TileArgs::warm; 0: never).  Measured r03 on 10x256x256 stacks, ms per forward at 0 / 256 / 1024 / always: batch 2 1.29 / 1.17 / 1.17 /
         // 1.17, batch 8 2.74 / 2.65 / 2.63 / 2.63, batch 16 4.71 / 4.66 / 4.62 / 4.66, batch 32 8.58 / 8.57 / 8.57 / 8.70
         s.warm_max_wgs = geti("DFFW_WARM_MAX_WGS", 0, 1024);
+        s.rollt_min_units = geti("DFFW_ROLLT_MIN_UNITS", 1, 128);   // (column, output half) units the transposed streaming kernel conv_rollt needs (DFFW_ROLL_MIN_UNITS lowers it too)
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
+        s.rollt_min_units = std::min(s.rollt_min_units, s.roll_min_units);
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
         { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
         { const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS"); s.concurrent_max_pixels = z ? atoll(z) : -1; }
@@ -1329,7 +1375,7 @@ struct Switches {
 
 inline int Switches::path_bits() const {
     return (f[SW_NO_LEAN_TILE] ? DFFW_ARGS_NO_LEAN_TILE : 0) | (f[SW_NO_LEAN_ROLL] ? DFFW_ARGS_NO_LEAN_ROLL : 0) | (f[SW_NO_ROLLX] ? DFFW_ARGS_NO_ROLLX : 0) |
-           (f[SW_NO_ROLLK] ? DFFW_ARGS_NO_ROLLK : 0) | (f[SW_NO_SLICE32] ? DFFW_ARGS_NO_SLICE32 : 0);
+           (f[SW_NO_ROLLK] ? DFFW_ARGS_NO_ROLLK : 0) | (f[SW_NO_SLICE32] ? DFFW_ARGS_NO_SLICE32 : 0) | (f[SW_NO_ROLLT] ? DFFW_ARGS_NO_ROLLT : 0);
 }
 
 struct ConvOpt {
@@ -1586,6 +1632,40 @@ struct Run {
             }
             a.outf = o.sums;
             a.dbg |= DFFW_ARGS_SUMS;
+        }
+        // transposed 32 / 64 -> 32 / 64 (deconv_1, dres2.conv5 / conv6, dres3.conv5, SPP conv9) on 8 x 8 columns of the input grid: the streaming kernel with the
+        // filter split over the waves by output phase; a unit = (column, 32-channel output half)
+        if (pc.wrollt && !o.in1 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLLT)) {
+            const int cols = ((in0.H + DFFW_ROLLT_TY - 1) / DFFW_ROLLT_TY) * ((in0.W + DFFW_ROLLT_TX - 1) / DFFW_ROLLT_TX);   // (partial columns are predicated in the kernel)
+            ConvArgs ak = a;
+            ak.Ng = in0.N; ak.Hg = in0.H; ak.Wg = in0.W;
+            ak.M = (int64_t)ak.B * in0.N * in0.H * in0.W;
+            if ((int64_t)in0.B * cols * (L.cout / 32) >= sw.rollt_min_units && rollt_ok(e->prec, ak)) {
+                if (dry) return out;
+                RollArgs t;
+                memset(&t, 0, sizeof t);
+                t.wroll = pc.wrollt;
+                t.tiles_y = (in0.H + DFFW_ROLLT_TY - 1) / DFFW_ROLLT_TY;
+                t.tiles_x = (in0.W + DFFW_ROLLT_TX - 1) / DFFW_ROLLT_TX;
+                t.zsplit = 1;
+                t.total_tiles = in0.B * cols;
+                t.wgs = sw.roll_wgs;
+                char kn[96];
+                conv_rollt_kernel_name(ak, kn, sizeof kn);
+                g_last_kernel = kn;
+                const double opx = (double)out.B * No * Ho * Wo;
+                // the fused classifier's two partial dots per pixel are ADDED to the score volume
+                if (ak.cls_w) check(hipMemsetAsync(ak.cls_out, 0, (size_t)(opx * 4.0), s), "score memset");
+                if (e->profiling) {
+                    const double bytes = (double)in0.pixels() * L.cin * elem_bytes()
+                                         + opx * L.cout * elem_bytes() * ((o.discard ? 0 : 1) + (o.out_pre ? 1 : 0) + (o.res0 ? 1 : 0)) + (o.cls ? opx * 4.0 : 0.0)
+                                         + 27.0 * L.cin * L.cout * elem_bytes();
+                    prof_begin(kn, name, 2.0 * (double)ak.M * 27.0 * L.cin * L.cout, bytes);
+                }
+                check(launch_conv_rollt(ak, t, s), name.c_str());
+                prof_end();
+                return out;
+            }
         }
         // transposed 32 -> 16 (deconv_2, dres3.conv6): two sweeps of conv_roll_t32, one per output row phase
         if (pc.wroll_t32 && (in0.C == 32 || in0.C == 16) && !o.in1 && !o.res_bcast && !o.res1 && !o.outf && in0.H % 8 == 0 && in0.W % 16 == 0 &&
@@ -3153,6 +3233,14 @@ int dffw_profile_collect(dffw_engine *e, dffw_prof_entry *out, int capacity) {
 int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, int N, int H, int W, const float *weight,
                    int Cout, const int kernel[3], const int stride[3], const int pad[3], const int dilation[3], int transposed,
                    const float *bn, const float *conv_bias, const float *residual, int relu, float *y, void *hip_stream) {
+    return dffw_op_conv3d_ex(device, precision, x, B, Cin, N, H, W, weight, Cout, kernel, stride, pad, dilation, transposed, bn, conv_bias, residual, relu, y,
+                             nullptr, nullptr, nullptr, hip_stream);
+}
+
+int dffw_op_conv3d_ex(int device, int precision, const float *x, int B, int Cin, int N, int H, int W, const float *weight,
+                      int Cout, const int kernel[3], const int stride[3], const int pad[3], const int dilation[3], int transposed,
+                      const float *bn, const float *conv_bias, const float *residual, int relu, float *y, float *y_pre, const float *cls_weight,
+                      float *cls_score, void *hip_stream) {
     if (!x || !weight || !y || !kernel || !stride || !pad || !dilation) return fail(DFFW_EINVAL, "null argument");
     if (precision < 0 || precision > 2) return fail(DFFW_EINVAL, "unknown precision %d", precision);
     if (stride[0] != 1 || dilation[0] != 1) return fail(DFFW_EINVAL, "slice stride/dilation must be 1");
@@ -3170,6 +3258,13 @@ int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, in
     eng.prec = precision;
     int rc = pack_conv(L, precision, weight, bn, conv_bias, eng.convs["op"]);
     if (rc) return rc;
+    if ((cls_weight != nullptr) != (cls_score != nullptr)) return fail(DFFW_EINVAL, "cls_weight and cls_score go together");
+    if ((y_pre || cls_weight) && (Cout == 1 || Cout % 8)) return fail(DFFW_EINVAL, "second output / fused classifier need Cout %% 8 == 0");
+    if (cls_weight) {   // the 1x1x1 Cout -> 1 classifier applied to the final value (DEN.py:51-55), bias-free, no BatchNorm
+        LayerDef C{"cls", "", Cout, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, false, true, false};
+        rc = pack_conv(C, precision, cls_weight, nullptr, nullptr, eng.convs["cls"]);
+        if (rc) return rc;
+    }
     const int parts = prec_parts(precision);
     const int cpad = (Cin + 7) / 8 * 8;
     const bool stem = (!transposed && kernel[0] == 1 && kernel[1] == 9 && kernel[2] == 9 && dilation[1] == 2 && pad[0] == 0 && pad[1] == 8 &&
@@ -3204,7 +3299,7 @@ int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, in
     const int No = N + 2 * pad[0] - (kernel[0] - 1);
     const int64_t opix = (int64_t)B * No * Ho * Wo;
     // run through the same Run::conv path the graph uses, on a private workspace
-    const int64_t ws_bytes = 2 * (opix * parts * std::max(Cout, 4) * 2 + 4096) + opix * 4 + 4096
+    const int64_t ws_bytes = 3 * (opix * parts * std::max(Cout, 4) * 2 + 4096) + 2 * (opix * 4 + 4096)
                              + 8 * opix * ((Cout + 15) / 16 * 16) * 4 + 4096;   // + split-K partial sums (up to 8 splits)
     char *ws = nullptr;
     HIPCHK(hipMalloc((void **)&ws, ws_bytes));
@@ -3221,12 +3316,23 @@ int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, in
         HIPCHK(launch_from_ncdhw(precision, residual, res.p, B, Cout, No, Ho, Wo, s));
         o.res0 = &res;
     }
+    Act pre;
+    float *clsf = nullptr;
+    if (y_pre) o.out_pre = &pre;
+    if (cls_weight) {
+        clsf = (float *)r.raw(opix * sizeof(float));
+        o.cls = "cls";
+        o.cls_out = clsf;
+    }
     Act out = r.conv("op", in, o);
     rc = r.err;
     if (rc == DFFW_OK) {
         if (Cout == 1) rc = hipMemcpyAsync(y, scoref, opix * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? DFFW_OK : fail(DFFW_EHIP, "copy");
         else rc = launch_to_ncdhw(precision, out.p, y, B, Cout, No, Ho, Wo, s) == hipSuccess ? DFFW_OK : fail(DFFW_EHIP, "to_ncdhw");
     }
+    if (rc == DFFW_OK && y_pre) rc = launch_to_ncdhw(precision, pre.p, y_pre, B, Cout, No, Ho, Wo, s) == hipSuccess ? DFFW_OK : fail(DFFW_EHIP, "to_ncdhw");
+    if (rc == DFFW_OK && cls_weight)
+        rc = hipMemcpyAsync(cls_score, clsf, opix * sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? DFFW_OK : fail(DFFW_EHIP, "copy");
     hipError_t se = hipStreamSynchronize(s);
     (void)hipFree(ws);
     (void)hipFree(in.p);

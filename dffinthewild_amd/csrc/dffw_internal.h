@@ -49,6 +49,7 @@ struct RawStack {
 #define DFFW_ARGS_NO_LEAN_ROLL 64   // DFFW_NO_LEAN_ROLL: the same for the rolling-window kernels
 #define DFFW_ARGS_NO_ROLLX 256   // DFFW_NO_ROLLX: conv_roll's serial step instead of conv_rollx's pipelined one
 #define DFFW_ARGS_NO_SLICE32 1024 // DFFW_NO_SLICE32: conv_tile instead of the streaming per-slice kernel conv_slice32 (1x3x3, 32 -> 32 channels)
+#define DFFW_ARGS_NO_ROLLT 2048  // DFFW_NO_ROLLT: conv_tile instead of the streaming transposed-conv kernel conv_rollt (32 / 64 -> 32 / 64 channels)
 #define DFFW_ARGS_NO_ROLLK 512   // DFFW_NO_ROLLK: conv_tile instead of the K-split rolling window conv_rollk (32 / 64 -> 32 / 64 channels)
 // (ConvArgs must not grow: the register allocation of the lean transposed-conv kernels is sensitive to its size, a
 // 56-byte larger argument block cost them 38 %)

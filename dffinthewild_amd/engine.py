@@ -69,6 +69,9 @@ def _load():
     lib.dffw_op_conv3d.argtypes = [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int,
                                    POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int,
                                    POINTER(c_float), POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p]
+    lib.dffw_op_conv3d_ex.argtypes = [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int,
+                                      POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), c_int,
+                                      POINTER(c_float), POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p, POINTER(c_float), c_void_p, c_void_p]
     lib.dffw_op_pool.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.dffw_op_fov_warp.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p]
@@ -103,7 +106,7 @@ RAW_NORM_F64 = 16   # DFFW_RAW_NORM_F64: the FS6 loader's float64 normalisation
 ABI_SYMBOLS = (
     "dffw_version", "dffw_last_error", "dffw_param_count", "dffw_param_info", "dffw_engine_create",
     "dffw_engine_destroy", "dffw_engine_precision", "dffw_workspace_bytes", "dffw_forward",
-    "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_pool", "dffw_op_regress",
+    "dffw_forward_taps", "dffw_profile_enable", "dffw_profile_collect", "dffw_op_conv3d", "dffw_op_conv3d_ex", "dffw_op_pool", "dffw_op_regress",
     "dffw_op_fov_warp", "dffw_forward_e2e", "dffw_last_conv_kernel",
     "dffw_forward_raw", "dffw_pack_stack", "dffw_unpack_stack", "dffw_colorize", "dffw_jet_lut", "dffw_metrics_scratch_bytes", "dffw_metrics",
     "dffw_comm_unique_id", "dffw_comm_init_rank", "dffw_comm_init_all", "dffw_comm_destroy", "dffw_comm_rank", "dffw_comm_size",
@@ -311,9 +314,12 @@ def _i3(v):
 
 
 def op_conv3d(x, weight, *, stride=1, pad=0, dilation=1, transposed=False, bn=None, bias=None,
-              residual=None, relu=0, precision="bf16x3"):
+              residual=None, relu=0, precision="bf16x3", want_pre=False, cls_weight=None):
     """y = [relu](BN(conv(x)) [+ residual]) through the MFMA implicit-GEMM kernel.  ``x`` (B,C,N,H,W)
-    float32 on the GPU; ``weight`` CPU/GPU float32 in PyTorch layout; ``bn`` = (gamma, beta, mean, var)."""
+    float32 on the GPU; ``weight`` CPU/GPU float32 in PyTorch layout; ``bn`` = (gamma, beta, mean, var).
+    ``want_pre`` / ``cls_weight`` (dffw_op_conv3d_ex): also return BN(conv(x)) before the residual add and / or the scores
+    of a bias-free 1x1x1 Cout -> 1 classifier applied to y (the hourglass's last layer, DEN.py:96-97): the result is then
+    the tuple (y, y_pre or None, scores or None)."""
     B, Cin, N, H, W = x.shape
     w = weight.detach().to("cpu", torch.float32).contiguous()
     Cout = w.shape[1] if transposed else w.shape[0]
@@ -333,12 +339,20 @@ def op_conv3d(x, weight, *, stride=1, pad=0, dilation=1, transposed=False, bn=No
     x = x.contiguous()
     res = residual.contiguous() if residual is not None else None
     dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    ex = want_pre or cls_weight is not None
+    y_pre = torch.empty_like(y) if want_pre else None
+    cw = cls_weight.detach().to("cpu", torch.float32).reshape(-1).contiguous() if cls_weight is not None else None
+    score = torch.empty((B, No, Ho, Wo), dtype=torch.float32, device=x.device) if cw is not None else None
     with torch.cuda.device(dev):
-        _check(lib.dffw_op_conv3d(dev, PRECISIONS[precision], c_void_p(x.data_ptr()), B, Cin, N, H, W, _f32(w), Cout,
-                                  (c_int * 3)(*k), s, p, d, int(transposed),
-                                  _f32(bnh) if bnh is not None else None, _f32(bh) if bh is not None else None,
-                                  c_void_p(res.data_ptr()) if res is not None else None, relu,
-                                  c_void_p(y.data_ptr()), _stream_ptr(dev)), "dffw_op_conv3d")
+        args = (dev, PRECISIONS[precision], c_void_p(x.data_ptr()), B, Cin, N, H, W, _f32(w), Cout,
+                (c_int * 3)(*k), s, p, d, int(transposed),
+                _f32(bnh) if bnh is not None else None, _f32(bh) if bh is not None else None,
+                c_void_p(res.data_ptr()) if res is not None else None, relu, c_void_p(y.data_ptr()))
+        if ex:
+            _check(lib.dffw_op_conv3d_ex(*args, c_void_p(y_pre.data_ptr()) if want_pre else None, _f32(cw) if cw is not None else None,
+                                         c_void_p(score.data_ptr()) if cw is not None else None, _stream_ptr(dev)), "dffw_op_conv3d_ex")
+            return y, y_pre, score
+        _check(lib.dffw_op_conv3d(*args, _stream_ptr(dev)), "dffw_op_conv3d")
     return y
 
 

@@ -148,6 +148,16 @@ int dffw_op_conv3d(int device, int precision, const float *x, int B, int Cin, in
                    void *hip_stream);
 
 /* mode 0: max-pool (1,k,k) stride (1,k,k) (DEN.py:310); mode 1: average-pool (DEN.py:149-153). */
+/* The same operator with the two extras the hourglass's last layer uses (DEN.py:96-97, 260-284: `out_in = x + conv6(...)`,
+ * `cost = classif(out_in)`): y_pre (device fp32, y's shape, or NULL) receives BN(conv(x)) BEFORE the residual add; cls_weight (host fp32
+ * Cout values, or NULL) is a bias-free 1x1x1 Cout -> 1 classifier applied to the final value y, its scores written to cls_score (device
+ * fp32 (B,No,Ho,Wo)).  Needs Cout % 8 == 0. */
+int dffw_op_conv3d_ex(int device, int precision, const float *x, int B, int Cin, int N, int H, int W,
+                      const float *weight, int Cout, const int kernel[3], const int stride[3],
+                      const int pad[3], const int dilation[3], int transposed, const float *bn,
+                      const float *conv_bias, const float *residual, int relu, float *y, float *y_pre,
+                      const float *cls_weight, float *cls_score, void *hip_stream);
+
 int dffw_op_pool(int device, int precision, int mode, int k, const float *x, int B, int C, int N,
                  int H, int W, float *y, void *hip_stream);
 

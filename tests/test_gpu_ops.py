@@ -316,6 +316,81 @@ def test_conv_rollk(eng, cin, cout, N, H, W, zsplit, wgs, relu, residual, monkey
     assert rel(got, alt) <= 2e-5, rel(got, alt)
 
 
+ROLLT_SHAPES = [(10, 32, 32, 0, 1, False), (1, 16, 24, 8, 1, True), (7, 24, 16, 24, 0, True), (2, 30, 40, 16, 1, False), (3, 8, 8, 0, 0, False),
+                (5, 12, 20, 8, 1, True), (2, 60, 80, 0, 1, True), (4, 14, 18, 8, 0, True)]
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64)])
+@pytest.mark.parametrize("N,H,W,wgs,relu,residual", ROLLT_SHAPES)
+def test_conv_rollt(eng, cin, cout, N, H, W, wgs, relu, residual, monkeypatch):
+    """conv_rollt (dffw_conv_rollt.hip): ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1), 32 / 64 -> 32 / 64 channels (`deconv_1`, `dres2.conv5`, `dres3.conv5`, the
+    pyramid's `conv9`; DEN.py:41-42, 194-200, 260-264) as a rolling window over 8 x 8 columns of the input grid with the resident filter split over the
+    waves by output phase (64 inputs: phase (1,1) also over K between a wave pair that exchanges one partial per operand tile): every slice count
+    incl. 1 and 2, one column per workgroup and long streams, a single column per sample, partial columns at the bottom / right edge (30 x 40 and 60 x 80:
+    the 1/16- and 1/8-resolution volumes of a 480 x 640 stack; 12 x 20, 14 x 18), ReLU and residual on and off; against F.conv_transpose3d, bitwise
+    repeatable, and against conv_tile on the same input (DFFW_NO_ROLLT)."""
+    B = 3
+    x = rnd(B, cin, N, H, W, seed=81)
+    w = rnd(cin, cout, 3, 3, 3, seed=82, scale=(2.0 / (cin * 27)) ** 0.5 * 3)
+    bn = bn_params(cout, 83)
+    res = rnd(B, cout, N, 2 * H, 2 * W, seed=84) if residual else None
+    ref = ref_bn(F.conv_transpose3d(x, w, None, (1, 2, 2), 1, (0, 1, 1)), bn)
+    if residual:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, relu=relu, residual=res.cuda() if residual else None, precision="bf16x3")
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel() == "dffw::conv_rollt<%d, %d>" % (cin, 1 if residual else 0), eng.last_conv_kernel()
+    assert rel(got, ref) <= TOL["bf16x3"], rel(got, ref)
+    again = eng.op_conv3d(x.cuda(), w, **kw)
+    assert torch.equal(got, again)                      # the K-split pair adds its two partials in a fixed order
+    monkeypatch.setenv("DFFW_NO_ROLLT", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(got, alt) <= 2e-5, rel(got, alt)
+
+
+@pytest.mark.parametrize("cin", [64, 32])
+@pytest.mark.parametrize("N,H,W,wgs,relu", [(10, 32, 32, 0, 0), (1, 16, 24, 8, 0), (2, 30, 40, 16, 1), (3, 8, 8, 0, 0), (5, 12, 20, 8, 0)])
+@pytest.mark.parametrize("pre,cls", [(True, True), (True, False), (False, True)])
+def test_conv_rollt_second_output_and_classifier(eng, cin, N, H, W, wgs, relu, pre, cls, monkeypatch):
+    """conv_rollt<.., 2>: the hourglass's last layer (`dres2.conv6`, DEN.py:96-97, 264: `out = conv6(...)`, `out_in = x + out`, `cost = classif(out_in)`): the
+    value before the skip add as a second output and the 1x1x1 32 -> 1 classifier folded into the epilogue -- its dot spans the two 16-channel output tiles
+    of a pixel, i.e. two waves, each adding its partial to the zeroed score volume (two addends: order-independent, so bitwise repeatable)."""
+    B, cout = 2, 32
+    x = rnd(B, cin, N, H, W, seed=91)
+    w = rnd(cin, cout, 3, 3, 3, seed=92, scale=(2.0 / (cin * 27)) ** 0.5 * 3)
+    bn = bn_params(cout, 93)
+    res = rnd(B, cout, N, 2 * H, 2 * W, seed=94)
+    cw = rnd(1, cout, 1, 1, 1, seed=95)
+    ref_pre = ref_bn(F.conv_transpose3d(x, w, None, (1, 2, 2), 1, (0, 1, 1)), bn)
+    ref = ref_pre + res
+    if relu:
+        ref = F.relu(ref)
+    ref_cls = F.conv3d(ref, cw).squeeze(1)
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, relu=relu, residual=res.cuda(), precision="bf16x3", want_pre=pre, cls_weight=cw if cls else None)
+    y, yp, sc = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel() == "dffw::conv_rollt<%d, 2>" % cin, eng.last_conv_kernel()
+    assert rel(y, ref) <= TOL["bf16x3"], rel(y, ref)
+    if pre:
+        assert rel(yp, ref_pre) <= TOL["bf16x3"], rel(yp, ref_pre)
+    if cls:
+        assert rel(sc, ref_cls) <= TOL["bf16x3"], rel(sc, ref_cls)
+    y2, yp2, sc2 = eng.op_conv3d(x.cuda(), w, **kw)
+    assert torch.equal(y, y2) and (not pre or torch.equal(yp, yp2)) and (not cls or torch.equal(sc, sc2))
+    monkeypatch.setenv("DFFW_NO_ROLLT", "1")
+    ya, ypa, sca = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert rel(y, ya) <= 2e-5 and (not pre or rel(yp, ypa) <= 2e-5) and (not cls or rel(sc, sca) <= 2e-5)
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("N,H,W,zsplit,residual,wgs", [(10, 64, 256, 1, True, 0), (5, 128, 128, 1, False, 16), (1, 64, 256, 1, True, 8),
                                                         (7, 64, 256, 3, False, 24), (2, 128, 128, 2, True, 0)])
