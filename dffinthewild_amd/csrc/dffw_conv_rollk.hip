@@ -209,7 +209,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     const unsigned gmask = (g >> 1) ? 0xFFFFFFFFu : 0u;
     // output: the lane's 16-byte piece of its pixel's record in the unit it owns (after the hi / lo exchange lane row g holds part g & 1 of
     // channel octet g >> 1 of the output tile)
-    const int ntb = t.pair;                            // first 16-channel output tile of this launch
+    const int ntb = (t.pair < 0 ? 0 : t.pair) + 2 * (int)blockIdx.y;   // first 16-channel output tile of this workgroup (RollArgs::pair < 0: grid.y = the 32-channel output halves, one launch)
     auto vob_of = [&](int half) {                      // element offset inside the output slice's column
         const int row = 2 * half + (myu >> 1) + 4 * (r >> 3), col = r & 7;
         return (row * a.Wo + col) * (2 * a.Cout) + (g & 1) * a.Cout + ((ntb + (myu & 1)) * 2 + (g >> 1)) * 8;
@@ -224,7 +224,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     // ---- the filter share: 7 chunks x 2 output tiles x (hi, lo), resident for the whole walk ----
     short8 w[NCH][2][2];
     {
-        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + (size_t)wave * NCH * 4 * 64 + lane;
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + ((size_t)blockIdx.y * NW + wave) * NCH * 4 * 64 + lane;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -318,7 +318,11 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         };
         auto fin_store = [&]() {
             if constexpr (FIN) {
-                if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq)::"memory");
+                if constexpr (RES) {   // (wait, THEN tie: as a "+v" operand of the wait hipcc may copy rq into the operand register in front of it)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("" : "+v"(rq));
+                }
                 uint4 rq4 = make_uint4(rq[0], rq[1], rq[2], rq[3]);
                 float cls = 0.f;
                 if constexpr (!(ABL & 32))
@@ -562,9 +566,10 @@ int rollk_waves(int prec, const ConvArgs &a) {
 
 hipError_t launch_conv_rollk(const ConvArgs &a, const RollArgs &t, hipStream_t s) {
     const int nw = (a.C0 + a.C1) / 8;
-    const int want = t.wgs > 0 ? t.wgs : (nw == 8 ? 256 : 512);   // 16 waves per CU either way
+    const int ny = t.pair < 0 ? a.Cout / 32 : 1;                  // (RollArgs::pair < 0: every 32-channel output half in ONE launch, as grid.y)
+    const int want = (t.wgs > 0 ? t.wgs : (nw == 8 ? 256 : 512)) / ny;   // 16 waves per CU either way
     const int per_xcd = (t.total_tiles + 7) / 8;
-    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(nw * 64);
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8))), (unsigned)ny), block(nw * 64);
     const bool relu = a.relu == 1, res = a.res0 != nullptr;
 #define DFFW_ROLLK_LAUNCH(NW, RL, RS) hipLaunchKernelGGL((conv_rollk<NW, RL, RS>), grid, block, 0, s, a, t)
 #ifdef DFFW_ABL_BUILD   // development (make ABL=1): timing ablations of the two most used instantiations (results are wrong)

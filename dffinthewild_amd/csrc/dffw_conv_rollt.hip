@@ -60,6 +60,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ void wait_vm0(u32x4 (&p)[N]) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);   // (no copy hipcc makes for the ties below may be scheduled in front of the wait: dffw_conv_slice.hip, conv_slice64_head)
 #pragma unroll
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(p[i]));
 }
@@ -277,7 +278,10 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
                     part_read(std::integral_constant<int, 0>{}, part, xrd);
                     part_read(std::integral_constant<int, 1>{}, part, xrd);
                 }
-                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[cur][0][0]), "+v"(x[cur][0][1]), "+v"(x[cur][1][0]), "+v"(x[cur][1][1]) : "n"(PR ? 6 : 4));
+                // (the tie is a statement of its own BEHIND the wait: as "+v" operands of the wait itself hipcc may copy the registers into the asm's operand
+                // registers in front of it, i.e. read a fragment that has not landed -- dffw_conv_slice.hip's conv_slice64_head met exactly that)
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PR ? 6 : 4));
+                asm volatile("" : "+v"(x[cur][0][0]), "+v"(x[cur][0][1]), "+v"(x[cur][1][0]), "+v"(x[cur][1][1]));
                 // sets of a slice the volume does not have: zero operands (a uniform branch, taken by two steps per unit)
                 if constexpr (P::d(i) != 1) {
                     if (P::d(i) == 0 ? nofront : noback) {

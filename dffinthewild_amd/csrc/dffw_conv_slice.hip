@@ -222,8 +222,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-        // epilogue of the wave's four result tiles
-        if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
+        // epilogue of the wave's four result tiles.  The queue is drained in front of its stores: the slice's DMA pieces (issued a whole contraction ago) and the
+        // residual pieces have landed.  (A counted wait behind the stores -- "everything but this step's four stores" -- would assume that LDS-DMA loads and
+        // stores retire in one order, which they do not, see conv_slice64_head below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the tie is a statement of its own BEHIND the wait and a scheduling barrier: as "+v" operands of the wait itself hipcc may copy the registers in front of
+        // it -- conv_slice64_head below met that)
+        if constexpr (RES) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
+        }
         if constexpr (!SUMS) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -260,9 +268,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        // the slice queued in this step (and everything older) has landed; this step's four stores may stay in flight across the barrier.  All
+        // the slice queued in this step has landed (drained in front of the epilogue); this step's stores stay in flight across the barrier.  All
         // waves are done reading this slice's slot: the step after the next one refills it.
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SUMS ? 0 : 4) : "memory");   // (row sums: masked stores whose count the compiler owns -- wait for them too)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {
             constexpr int nb = (PAR + NCH) & 1;
             asm volatile("" : "+v"(x[nb][0][0]), "+v"(x[nb][0][1]), "+v"(x[nb][1][0]), "+v"(x[nb][1][1]));
@@ -531,12 +539,21 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
             n[1] = mma<false>(w[c][0], x[cur][1][0], n[1]);
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (HEAD && ps == 0) {
-            // the column's residual pieces, requested in front of its first slice's DMA pieces.  A counted wait (vmcnt(PPW): "everything but this slice's pieces")
-            // is NOT enough -- measured: wrong results that vary from run to run once a workgroup walks more than one column; VGPR loads, LDS-DMA loads and the
-            // previous step's stores do not retire in one order -- so the column's first slice drains the queue here (its pieces were issued a pass ago)
-            if (fresh) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
+        // Every slice's first pass drains the queue in front of its stores: the slice's DMA pieces were issued a pass ago, the previous slice's stores long before
+        // (round 6, ADVICE r05: the end-of-step wait used to be a counted one behind the stores).  HEAD: the column's residual pieces were requested in front of its
+        // first slice's DMA pieces; a counted wait (vmcnt(PPW): "everything but this slice's pieces") is NOT enough for them -- measured: wrong results that vary from
+        // run to run once a workgroup walks more than one column; VGPR loads, LDS-DMA loads and the previous step's stores do not retire in one order.  (The wait
+        // comes first and names the registers: the epilogue's arithmetic on them must not be scheduled in front of it.)
+        if constexpr (ps == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The tie is a statement of its own BEHIND the wait, with a scheduling barrier between them.  The residual registers stay live for the column's ten slices
+            // and the epilogue's lane swaps are destructive, so hipcc gives the tie's results other registers than its operands -- i.e. copies rq in front of the tie.
+            // As "+v" operands of the wait itself, or without the barrier, (half of) these copies were scheduled in front of the wait: a read of a load that has not
+            // landed -- measured: wrong by 2e-3, varying from run to run (profiles/r06_wait_tie_hazard.txt).
+            if constexpr (HEAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
+            }
         }
         if constexpr (!SUMS) {
 #pragma unroll
@@ -577,8 +594,8 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
         const unsigned nxtb = abase + slotd;
         pass(I0{}, PRE_, cur0, nxtb, slotd, optr, srow, fresh);
         if constexpr (L::PASSES == 2) pass(I1{}, std::true_type{}, cur0, nxtb, slotd, optr, srow, false);
-        // the slice queued in this step (and everything older) has landed; this step's four stores may stay in flight across the barrier
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(SUMS ? 0 : 2 * L::PASSES) : "memory");
+        // the slice queued in this step has landed (drained in front of the first pass's epilogue); this step's stores may stay in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         asm volatile("" : "+v"(x[0][0][0]), "+v"(x[0][0][1]), "+v"(x[0][1][0]), "+v"(x[0][1][1]));
         sidxb = (sidxb + SLOTB == RING * SLOTB) ? 0 : sidxb + SLOTB;
         advance_fill();

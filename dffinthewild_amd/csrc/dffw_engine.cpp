@@ -1331,7 +1331,7 @@ enum SwitchId {
 };
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, rollk_merge_below = 1 << 30, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1360,6 +1360,10 @@ struct Switches {
         // (TileArgs::warm; 0: never).  Measured r03 on 10x256x256 stacks, ms per forward at 0 / 256 / 1024 / always: batch 2 1.29 / 1.17 / 1.17 /
         // 1.17, batch 8 2.74 / 2.65 / 2.63 / 2.63, batch 16 4.71 / 4.66 / 4.62 / 4.66, batch 32 8.58 / 8.57 / 8.57 / 8.70
         s.warm_max_wgs = geti("DFFW_WARM_MAX_WGS", 0, 1024);
+        // conv_rollk layers with 64 outputs on fewer columns than this run their two output halves as ONE launch (grid.y = 2); 1: never.  Round 6, same-run layer
+        // tables at batch 32: the 16 x 16-grid layers (128 columns: one unit per CU) 0.058 -> 0.050-0.054 ms against conv_tile, dres0.0 0.099 -> 0.090, dres0.2 /
+        // dres2.conv2 -1..2 % against two launches
+        s.rollk_merge_below = geti("DFFW_ROLLK_MERGE_BELOW", 0, 1 << 30);
         s.rollt_min_units = geti("DFFW_ROLLT_MIN_UNITS", 1, 128);   // (column, output half) units the transposed streaming kernel conv_rollt needs (DFFW_ROLL_MIN_UNITS lowers it too)
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
@@ -1931,29 +1935,34 @@ struct Run {
             ConvArgs ak = a;
             ak.Ng = No; ak.Hg = Ho; ak.Wg = Wo;
             ak.M = (int64_t)ak.B * No * Ho * Wo;
-            if ((int64_t)in0.B * cols >= sw.roll_min_units && rollk_waves(e->prec, ak) == cin_pad / 8) {
+            // 64 output channels = two 32-channel halves as grid.y of ONE launch (round 6: the 16 x 16-grid layers `dres16_*`, `conv2`, `dres2.conv4` at batch 32
+            // are 128 columns x 2 halves = one unit per CU and now take this kernel; DFFW_ROLLK_MERGE_BELOW=1: two launches)
+            const int npair = L.cout / 32;
+            const bool merged = npair == 2 && (int64_t)in0.B * cols < sw.rollk_merge_below;
+            if ((int64_t)in0.B * cols * (merged ? npair : 1) >= sw.roll_min_units && rollk_waves(e->prec, ak) == cin_pad / 8) {
                 if (dry) return out;
-                const int npair = L.cout / 32;
-                for (int op = 0; op < npair; ++op) {
+                const int nlaunch = merged ? 1 : npair;
+                for (int op = 0; op < nlaunch; ++op) {
                     RollArgs t;
                     memset(&t, 0, sizeof t);
                     t.wroll = pc.wrollk + (size_t)op * (cin_pad / 8) * ROLLK_CHUNKS * 2 * prec_parts(e->prec) * 512;
                     t.tiles_y = (Ho + kty - 1) / kty;
                     t.tiles_x = (Wo + ktx - 1) / ktx;
-                    t.zsplit = ((int64_t)in0.B * cols < 512 && No >= 8) ? 2 : 1;
+                    // a sample's slices as two ranges where whole columns leave the chip short of workgroups (16 waves per CU: 256 8-wave / 512 4-wave units)
+                    t.zsplit = ((int64_t)in0.B * cols * (merged ? npair : 1) < (cin_pad == 64 && merged ? 256 : 512) && No >= 8) ? 2 : 1;
                     if (sw.roll_zsplit >= 1 && sw.roll_zsplit <= No) t.zsplit = sw.roll_zsplit;
                     t.total_tiles = in0.B * t.zsplit * cols;
                     t.wgs = sw.roll_wgs;
-                    t.pair = op * 2;     // first 16-channel output tile of this launch
+                    t.pair = merged ? -1 : op * 2;     // first 16-channel output tile of this launch (-1: every half, as grid.y)
                     char kn[96];
                     conv_rollk_kernel_name(ak, kn, sizeof kn);
                     g_last_kernel = kn;
                     if (e->profiling) {
                         const double opx = (double)out.B * No * Ho * Wo;
-                        const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout / npair * elem_bytes() * (1 + (o.res0 ? 1 : 0)) +
-                                             27.0 * L.cin * L.cout / npair * elem_bytes();
-                        prof_begin(kn, npair > 1 ? name + (op ? " (upper output channels)" : " (lower output channels)") : name,
-                                   2.0 * opx * 27.0 * L.cin * L.cout / npair, bytes);
+                        const double bytes = (double)in0.pixels() * L.cin * elem_bytes() + opx * L.cout / nlaunch * elem_bytes() * (1 + (o.res0 ? 1 : 0)) +
+                                             27.0 * L.cin * L.cout / nlaunch * elem_bytes();
+                        prof_begin(kn, nlaunch > 1 ? name + (op ? " (upper output channels)" : " (lower output channels)") : name,
+                                   2.0 * opx * 27.0 * L.cin * L.cout / nlaunch, bytes);
                     }
                     check(launch_conv_rollk(ak, t, s), name.c_str());
                     prof_end();

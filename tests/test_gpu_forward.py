@@ -115,9 +115,15 @@ def test_streaming_kernels_at_golden_sizes(lib_built, which, monkeypatch):
     torch.cuda.synchronize()
     for name, o in zip(("mid_out", "pred1", "pred2", "pred3"), outs):
         if name in g.files:
-            assert cpu_ref.rel_l2(o.cpu(), g[name]) <= OUT_TOL["bf16x3"], (name, cpu_ref.rel_l2(o.cpu(), g[name]))
+            err = cpu_ref.rel_l2(o.cpu(), g[name])
+            assert err <= OUT_TOL["bf16x3"], (name, err)
+            if name == "pred3":
+                assert err <= DRIFT_OUT, ("drift guard", name, err)
     for nm in names:
-        assert cpu_ref.rel_l2(taps[nm].cpu(), g["tap_" + nm]) <= TAP_TOL["bf16x3"], (nm, cpu_ref.rel_l2(taps[nm].cpu(), g["tap_" + nm]))
+        err = cpu_ref.rel_l2(taps[nm].cpu(), g["tap_" + nm])
+        assert err <= TAP_TOL["bf16x3"], (nm, err)
+        if nm in DRIFT_TAP:
+            assert err <= DRIFT_TAP[nm], ("drift guard", nm, err)
 
 
 @pytest.mark.parametrize("prec,tol", [("fp16", 2e-2), ("bf16", 1e-1)])
@@ -334,7 +340,8 @@ def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monk
 
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK", "DFFW_NO_SMALL", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
                                  "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR",
-                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_SLICE32", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE"])
+                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_ROLLT", "DFFW_NO_SLICE32", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE",
+                                 "DFFW_ROLLK_MERGE_BELOW"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback
@@ -345,7 +352,7 @@ def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch
     path = [p for p in GOLDEN if which in p][0]
     g, meta, FS, fd, sd = case(path)
     model = model_for(sd, (meta["wseed"], meta["profile"]))
-    monkeypatch.setenv(env, "1")
+    monkeypatch.setenv(env, "1")       # (DFFW_ROLLK_MERGE_BELOW=1: conv_rollk's 64-output layers as two launches instead of one with grid.y = 2)
     model.invalidate()                 # (DFFW_NO_STEM_PAIR is read when the weights are packed)
     with torch.no_grad():
         outs = model(FS.cuda(), fd.cuda())
@@ -354,4 +361,7 @@ def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch
     model.invalidate()
     for name, o in zip(("mid_out", "pred1", "pred2", "pred3"), outs):
         if name in g.files:
-            assert cpu_ref.rel_l2(o.cpu(), g[name]) <= OUT_TOL["bf16x3"], (env, name)
+            err = cpu_ref.rel_l2(o.cpu(), g[name])
+            assert err <= OUT_TOL["bf16x3"], (env, name, err)
+            if name == "pred3":
+                assert err <= DRIFT_OUT, ("drift guard", env, name, err)

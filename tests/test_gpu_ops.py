@@ -310,6 +310,12 @@ def test_conv_rollk(eng, cin, cout, N, H, W, zsplit, wgs, relu, residual, monkey
     assert rel(got, ref) <= TOL["bf16x3"], rel(got, ref)
     again = eng.op_conv3d(x.cuda(), w, **kw)
     assert torch.equal(got, again)                      # the partial sums are added in a fixed order
+    if cout == 64:                                      # the two 32-channel output halves as two launches instead of grid.y = 2 of one: same arithmetic
+        monkeypatch.setenv("DFFW_ROLLK_MERGE_BELOW", "1")
+        two = eng.op_conv3d(x.cuda(), w, **kw)
+        assert eng.last_conv_kernel().startswith("dffw::conv_rollk<"), eng.last_conv_kernel()
+        assert torch.equal(got, two)
+        monkeypatch.delenv("DFFW_ROLLK_MERGE_BELOW")
     monkeypatch.setenv("DFFW_NO_ROLLK", "1")
     alt = eng.op_conv3d(x.cuda(), w, **kw)
     assert not eng.last_conv_kernel().startswith("dffw::conv_rollk<"), eng.last_conv_kernel()
