@@ -545,13 +545,19 @@ __device__ __forceinline__ void slice64_body(const ConvArgs &a, const RollArgs &
         // run to run once a workgroup walks more than one column; VGPR loads, LDS-DMA loads and the previous step's stores do not retire in one order.  (The wait
         // comes first and names the registers: the epilogue's arithmetic on them must not be scheduled in front of it.)
         if constexpr (ps == 0) {
+#if defined(DFFW_SLICE_HAZARD) && DFFW_SLICE_HAZARD == 1   // development only: round 5's first form -- a COUNTED wait for the residual pieces ("everything but this slice's DMA pieces")
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             // The tie is a statement of its own BEHIND the wait, with a scheduling barrier between them.  The residual registers stay live for the column's ten slices
             // and the epilogue's lane swaps are destructive, so hipcc gives the tie's results other registers than its operands -- i.e. copies rq in front of the tie.
             // As "+v" operands of the wait itself, or without the barrier, (half of) these copies were scheduled in front of the wait: a read of a load that has not
             // landed -- measured: wrong by 2e-3, varying from run to run (profiles/r06_wait_tie_hazard.txt).
             if constexpr (HEAD) {
+#if !(defined(DFFW_SLICE_HAZARD) && DFFW_SLICE_HAZARD == 2)   // development only, 2: the tie straight behind the wait, no scheduling barrier (the copies move in front of the wait)
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 asm volatile("" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]));
             }
         }

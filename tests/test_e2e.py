@@ -19,6 +19,9 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "e2e
 OUT_NAMES = ("mid_out", "pred1", "pred2", "pred3", "aligned")
 SMOOTH = [p for p in GOLDEN if "smooth_64x96" in p]
 BIG = [p for p in GOLDEN if "480x640" in p]
+# drift guard: the north-star gate (1e-3) is ~15x looser than what the split-bf16 path delivers on the End_to_End goldens; a kernel
+# change that costs accuracy -- or a wait that does not cover its load -- must not hide under it.  pred3 of every reference golden, ~4x above the measured errors.
+DRIFT_PRED3 = 2e-4
 
 
 def load(path):
@@ -116,7 +119,10 @@ def test_hip_e2e_matches_reference(lib_built, path):
     checked = 0
     for name, o in zip(OUT_NAMES, outs):
         if name in g.files:
-            assert cpu_ref.rel_l2(o.cpu(), g[name]) <= 1e-3, name
+            err = cpu_ref.rel_l2(o.cpu(), g[name])
+            assert err <= 1e-3, (name, err)
+            if name == "pred3":   # (measured 3.2e-5 / 4.5e-5 / 6.3e-5 on the smooth-profile goldens, 3.2e-4 on the saturating "he" one)
+                assert err <= (6e-4 if "_he_" in path else DRIFT_PRED3), ("drift guard", name, err)
             checked += 1
     assert checked >= 1
 
@@ -139,9 +145,39 @@ def test_hip_e2e_streaming_kernels_on_the_full_size_golden(lib_built, monkeypatc
     for tag in ("head3", "head2", "head1"):
         assert cpu_ref.rel_l2(taps[tag].cpu().reshape(3, 10), g[tag]) <= 1e-4, tag
         assert cpu_ref.rel_l2(taps[tag].cpu(), taps0[tag].cpu()) <= 2e-5, tag
-    assert cpu_ref.rel_l2(outs[3].cpu(), g["pred3"]) <= 1e-3
+    assert cpu_ref.rel_l2(outs[3].cpu(), g["pred3"]) <= DRIFT_PRED3
     for name, a, b in zip(OUT_NAMES, outs, base):
         assert cpu_ref.rel_l2(a.cpu(), b.cpu()) <= 2e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wgs", [16, 64])
+def test_hip_e2e_streaming_kernels_long_streams_repeat_bit_for_bit(lib_built, monkeypatch, wgs):
+    """Stress test of the waits of End_to_End's streaming kernels (conv_slice64_head, conv_slice32_cat and the row-sums variants
+    have no operator-level test): two 10x3x480x640 stacks, every streaming kernel forced on, few workgroups (DFFW_ROLL_WGS / DFFW_SRD_WGS) so that each walks
+    many columns -- the situation in which conv_slice64_head's residual registers were once read before their loads had landed (wrong by 2e-3, varying from
+    run to run; this round's wait / tie hazard showed the same signature, profiles/r06_wait_tie_hazard.txt).  Twelve runs: each bit-identical to the first,
+    the reference golden at batch position 1 within the drift guard, its head outputs to 1e-4."""
+    g, sd, FS1, fd1, fov1 = load(BIG[0])
+    B, H, W = 2, int(g["H"]), int(g["W"])
+    FS = torch.from_numpy(synth.focal_stack(B, 10, H, W, seed=777))
+    FS[1] = FS1[0]
+    fov = fov1.expand(B, -1, -1, -1, -1).contiguous()
+    fd = fd1.expand(B, -1, -1, -1).contiguous()
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    monkeypatch.setenv("DFFW_SRD_WGS", str(wgs))
+    m = _model(sd)
+    FSd, fdd, fovd = FS.cuda(), fd.cuda(), fov.cuda()
+    with torch.no_grad():
+        first = [o.clone() for o in m(FSd, fdd, fovd)]
+        torch.cuda.synchronize()
+        assert cpu_ref.rel_l2(first[3][1:2].cpu(), g["pred3"]) <= DRIFT_PRED3
+        for rep in range(12):
+            outs = m(FSd, fdd, fovd)
+            torch.cuda.synchronize()
+            for k, (a, b) in enumerate(zip(outs, first)):
+                assert torch.equal(a, b), (rep, OUT_NAMES[k])
 
 
 @pytest.mark.gpu
@@ -170,7 +206,7 @@ def test_hip_e2e_config5_batch8_480x640(lib_built):
     for o in outs[:4]:
         assert tuple(o.shape) == (B, H, W) and torch.isfinite(o).all()
     for pos in (1, 6):
-        assert cpu_ref.rel_l2(outs[3][pos:pos + 1].cpu(), g["pred3"]) <= 1e-3, pos
+        assert cpu_ref.rel_l2(outs[3][pos:pos + 1].cpu(), g["pred3"]) <= DRIFT_PRED3, pos
         assert cpu_ref.rel_l2(outs[4][pos:pos + 1].cpu().numpy()[ALIGNED_SAMPLE], g["aligned_sample"]) <= 1e-3, pos
     for k in range(5):
         assert torch.equal(outs[k][1], outs[k][6]), OUT_NAMES[k]

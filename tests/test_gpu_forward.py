@@ -126,6 +126,39 @@ def test_streaming_kernels_at_golden_sizes(lib_built, which, monkeypatch):
             assert err <= DRIFT_TAP[nm], ("drift guard", nm, err)
 
 
+@pytest.mark.parametrize("wgs", [8, 40])
+def test_streaming_kernels_long_streams_repeat_bit_for_bit(lib_built, wgs, monkeypatch):
+    """Stress test of the counted / drained waits of the persistent streaming kernels: the kernels that request
+    residual pieces or DMA slices ahead of their use (conv_roll's residual variants, conv_roll_t / _t32, conv_rollx, conv_rollk, conv_rollt,
+    conv_slice32, the fused SRD / EFD blocks) are correct only if every wait covers what it claims to.  The round-5 bug of that class was timing
+    dependent -- wrong by 2e-3, varying from run to run, and only once a workgroup walked MORE THAN ONE column.  Here few workgroups
+    (DFFW_ROLL_WGS / DFFW_SRD_WGS) walk every column of a batch of six 10x256x256 stacks -- hundreds of columns and thousands of steps per
+    workgroup, all streaming kernels forced on (DFFW_ROLL_MIN_UNITS=1) -- twenty times: every run bit-identical to the first, the two reference
+    goldens inside the batch within the drift guard."""
+    ga, meta, FSa, fda, sd = case([p for p in GOLDEN if "full_10x256" in p][0])
+    gb, metab, FSb, fdb, sdb = case([p for p in GOLDEN if "full2_10x256" in p][0])
+    model = model_for(sd, (meta["wseed"], meta["profile"]))
+    B, N, H, W = 6, 10, 256, 256
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=4242))
+    FS[1] = FSa[0]
+    FS[4] = FSb[0]
+    fd = fda.expand(B, -1, -1, -1).contiguous()
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    monkeypatch.setenv("DFFW_SRD_WGS", str(wgs))
+    FSd, fdd = FS.cuda(), fd.cuda()
+    with torch.no_grad():
+        first = [o.clone() for o in model(FSd, fdd)]
+        torch.cuda.synchronize()
+        assert cpu_ref.rel_l2(first[3][1:2].cpu(), ga["pred3"]) <= DRIFT_OUT
+        assert cpu_ref.rel_l2(first[3][4:5].cpu(), gb["pred3"]) <= DRIFT_OUT
+        for rep in range(20):
+            outs = model(FSd, fdd)
+            torch.cuda.synchronize()
+            for k, (a, b) in enumerate(zip(outs, first)):
+                assert torch.equal(a, b), (rep, k)
+
+
 @pytest.mark.parametrize("prec,tol", [("fp16", 2e-2), ("bf16", 1e-1)])
 def test_fast_precisions_run_and_are_close(lib_built, prec, tol):
     """fp16 / bf16 single-product modes: same graph, looser arithmetic; the error is reported by
