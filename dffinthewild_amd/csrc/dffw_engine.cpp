@@ -1332,6 +1332,7 @@ enum SwitchId {
 struct Switches {
     bool f[SW_COUNT];
     int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, rollk_merge_below = 1 << 30, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
+    bool srd_pipe = false;   // DFFW_SRD_PIPE=1: the 16-channel SRD block on srd_pipe16 (one barrier per step) instead of srd_roll16
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
@@ -1371,6 +1372,7 @@ struct Switches {
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
         { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
         { const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS"); s.concurrent_max_pixels = z ? atoll(z) : -1; }
+        s.srd_pipe = getenv_flag("DFFW_SRD_PIPE");
         s.trace_layer = getenv("DFFW_TRACE_LAYER");
         s.trace_out = getenv("DFFW_TRACE_OUT");
         return s;
@@ -2256,7 +2258,9 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
                 a.total_tiles = x.B * a.tiles_y * a.tiles_x;
                 a.wgs = r.sw.srd_wgs;
                 char kn[64];
-                if (x.C == 16) srd_roll16_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
+                const bool pipe16 = x.C == 16 && r.sw.srd_pipe;   // (opt-in: measured 6 % slower than srd_roll16, profiles/r06_srd_two_slice.txt)
+                if (pipe16) srd_pipe16_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
+                else if (x.C == 16) srd_roll16_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
                 else srd_roll_kernel_name(r.e->prec, with_pool, kn, sizeof kn);
                 g_last_kernel = kn;
                 const double px = (double)x.pixels();
@@ -2265,7 +2269,7 @@ static Act srd(Run &r, const std::string &p, Act &x, bool drop_x, Act *pooled = 
 #ifdef DFFW_TRACE_BUILD
                 a.trace = r.trace_begin(p, 1024, 4);
 #endif
-                r.check(x.C == 16 ? launch_srd_roll16(r.e->prec, a, r.s) : launch_srd_roll(r.e->prec, a, r.s), "srd_roll");
+                r.check(pipe16 ? launch_srd_pipe16(r.e->prec, a, r.s) : x.C == 16 ? launch_srd_roll16(r.e->prec, a, r.s) : launch_srd_roll(r.e->prec, a, r.s), "srd_roll");
                 r.prof_end();
                 r.trace_end();
             }

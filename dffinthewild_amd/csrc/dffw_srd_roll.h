@@ -31,6 +31,9 @@ constexpr int SRD16_CHUNKS = 5;
 void srd_roll16_tile(int *ty, int *tx);
 hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s);
 void srd_roll16_kernel_name(int prec, bool pool, char *buf, int n);
+// srd_pipe16 (round 6): the same block as a software pipeline over the slice stream (stage A of position p, B of p - 1, C of p - 2 in one step, one barrier)
+hipError_t launch_srd_pipe16(int prec, const SrdArgs &a, hipStream_t s);
+void srd_pipe16_kernel_name(int prec, bool pool, char *buf, int n);
 
 // a stride-1 residual block of the alignment network (8 or 16 -> 16 channels, columns of 8 x 16 pixels): a.w0 = conv.0 as 3 (8
 // input channels: 4 taps per chunk) or 5 chunks, a.w2 = conv.2 as 5 chunks + 1 shortcut chunk (pack_conv); a.b0 / a.b2 their shifts

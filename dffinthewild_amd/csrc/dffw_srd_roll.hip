@@ -1224,6 +1224,415 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- srd_pipe16 (round 6): srd_roll16's block as a software pipeline over the workgroup's slice stream -----------------------------------------
+// srd_roll16 walks a column slice by slice as  barrier | stage A | barrier | stage B, stage C | barrier | fill : three barriers and three dependent
+// stage chains per step that add up (profiles/r04_ablation_srd_roll.txt: no A -36 %, no B -25 %, no C -24 %, no barriers only -8 %), plus one drain step
+// per column.  Here the stages of ONE step belong to three consecutive stream positions -- stage A of position p (t into one of TWO t buffers), stage B
+// of position p - 1 (its residual pixels of x were read into registers a step earlier, so x[p - 1]'s slot is free), stage C of position p - 2 -- so
+// nothing a wave does inside a step depends on what another wave does in the same step: ONE barrier per step (t[p - 1] complete, x[p] landed, the
+// slot of x[p - 1] and the buffer t[p] free), the three chains are independent work for the scheduler and the SIMD's other wave, and the stream runs
+// on across columns (positions carry their own column / slice; the attention's zero slices at a column's ends are a zeroed ring slot / a zero operand),
+// so a column costs N steps, not N + 1.  Same arithmetic in the same order as srd_roll16: bit-identical results (tested).
+// 16 output channels fill the MFMA result rows, so no pixel pairs: a GEMM column is one pixel, the 1x3x3 convs contract over
+// 5 chunks of (2 taps x 16 channels) (tap 9 = zeros), records are 32 bytes per plane (natural column order).  Columns are
+// 4 x 16 pixels (LDS: 4 x-slices of 8 x 20 pixels + t + the feat ring = 67 KB, two workgroups per CU).  Stage B / C tiles
+// are 2 rows x 8 pixels per wave so that the 2x2 max-pool stays inside a wave.  Streaming skeleton, counted waits, inline-asm
+// LDS access and the MFMA attention (its split result = the 1x1x1 conv's operand in place) as in srd_roll_kernel.
+// ABL (development only, DFFW_SRD_ABL): timing ablations -- 1 no stage C, 2 no stage A, 4 no stage B, 8 no fill, 16 no barriers, 32 no global stores
+template <int PREC, bool POOL, int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void srd_pipe16_kernel(const SrdArgs a) {
+    constexpr int PARTS = Fmt<PREC>::PARTS;
+    constexpr bool F16 = (PREC == P_FP16);
+    constexpr int C = 16, TY = 4, TX = 16, NWAVES = 4;
+    constexpr int XY = TY + 4, XX = TX + 4, XPIX = XY * XX;
+    constexpr int TYT = TY + 2, TXT = TX + 2, TPIX = TYT * TXT;
+    // t rows at a pitch of 24 pixels = 768 bytes: a stage-B tile is 2 rows x 8 pixels, and the 16 lanes of a ds_read_b128 row group only cover 16 distinct
+    // 16-byte bank groups when its two rows are a multiple of 256 bytes apart (18-pixel rows, 576 bytes: two-way conflicts on every stage-B read)
+    constexpr int TXTP = 24;
+    constexpr int PIXB = C * 2;
+    constexpr int NPIECE = 6;                                      // 1 KiB wave instructions per plane (5 hold the 160 pixels; 6 keeps 3 per wave)
+    static_assert(NPIECE * 32 >= XPIX, "plane holds the footprint");
+    constexpr int PLANEB = NPIECE * 1024;
+    constexpr int SLOTB = PARTS * PLANEB;
+    constexpr int RX = 4;
+    constexpr int NP = PARTS * NPIECE, PPW = (NP + NWAVES - 1) / NWAVES;
+    static_assert(NP % PPW == 0, "every wave issues PPW pieces or none (counted vmcnt waits)");
+    constexpr int TPLANEB = TYT * TXTP * PIXB;
+    constexpr int FPLANEB = TY * TX * PIXB;
+    constexpr int FSLOTB = PARTS * FPLANEB;
+    constexpr int X_OFF = 0, T_OFF = RX * SLOTB, TBUFB = PARTS * TPLANEB, F_OFF = T_OFF + 2 * TBUFB;   // two t buffers (positions of either parity)
+    constexpr int NCH = 5;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[F_OFF + 3 * FSLOTB];
+    static_assert(2 * (F_OFF + 3 * FSLOTB) <= 160 * 1024, "two workgroups per CU");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto lds_store8 = [&](unsigned byte_off, uint32_t v0, uint32_t v1) {
+        const u32x2 d = {v0, v1};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(lds0 + byte_off), "v"(d) : "memory");
+    };
+    auto lds_store16 = [&](unsigned byte_off, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds0 + byte_off), "v"(v) : "memory"); };
+
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    int ufirst, uend;
+    {
+        const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+        const int xs = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+        uend = xs + q + (xcd < rem ? 1 : 0);
+        ufirst = xs + widx;
+    }
+    if (ufirst >= uend) return;
+    struct Unit {
+        int b, gy0, gx0;
+    };
+    auto decode = [&](int u) {
+        Unit c;
+        const int txi = u % a.tiles_x;
+        const int tt = u / a.tiles_x;
+        c.b = tt / a.tiles_y;
+        c.gy0 = (tt % a.tiles_y) * TY;
+        c.gx0 = txi * TX;
+        return c;
+    };
+
+    const int rec = PARTS * C;
+    const int slice_elems = a.H * a.W * rec;
+    const uint16_t *fsrc[PPW];
+    bool fok[PPW];
+    int fu = ufirst, fq = 0;
+    auto setup_fill = [&]() {
+        const Unit c = decode(fu);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const int ci = i * 64 + lane, pix = ci >> 1, oct = ci & 1;
+            const int fy = pix / XX, fx = pix - fy * XX;
+            const int iy = c.gy0 - 2 + fy, ix = c.gx0 - 2 + fx;
+            fok[k] = p < NP && pix < XPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            fsrc[k] = a.x + (int64_t)c.b * a.N * slice_elems + (int64_t)(iy * a.W + ix) * rec + part * C + oct * 8;
+        }
+    };
+    setup_fill();
+    int fslot = 0;
+    auto issue_next = [&]() {
+        const bool zin = fu < uend;
+        unsigned char *slot = smem + X_OFF + fslot * SLOTB;
+        const int64_t zo = (int64_t)fq * slice_elems;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = wave * PPW + k;
+            if (p >= NP) break;
+            const int part = p / NPIECE, i = p % NPIECE;
+            const uint16_t *src = (zin && fok[k]) ? fsrc[k] + zo : a.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + part * PLANEB + i * 1024), 16, 0, 0);
+        }
+        fslot = (fslot + 1 == RX) ? 0 : fslot + 1;
+        if (++fq == a.N && fu < uend) {
+            fq = 0;
+            fu += wgs_per_xcd;
+            if (fu < uend) setup_fill();
+        }
+    };
+
+    // stage A: the 6 x 18 t pixels are 7 operand tiles: tiles 0-5 = the first 16 pixels of row 0-5 (16 consecutive pixels of ONE row: conflict-free
+    // operand reads; tiles of 16 consecutive indices of the 6 x 18 region wrapped rows and collided two ways), tile 6 = the two remaining pixels of
+    // each row (12 of its 16 lanes busy); waves 0-2 take two tiles, wave 3 one
+    constexpr int TA = 2;
+    const int nA = wave < 3 ? 2 : 1;
+    int pa[TA], ta_y[TA], ta_x[TA], ta_st[TA];
+    bool ta_ok[TA];
+#pragma unroll
+    for (int j = 0; j < TA; ++j) {
+        const int tile = j == 0 ? wave : 4 + wave;
+        ta_ok[j] = tile < TYT || r < 2 * TYT;
+        ta_y[j] = tile < TYT ? tile : (r < 2 * TYT ? r >> 1 : TYT - 1);
+        ta_x[j] = tile < TYT ? r : TX + (r & 1);
+        pa[j] = (ta_y[j] * XX + ta_x[j]) * PIXB + (g & 1) * 16;
+        ta_st[j] = T_OFF + (ta_y[j] * TXTP + ta_x[j]) * PIXB + g * 8;
+    }
+    // K octet g of chunk k = (filter tap 2k + (g >> 1), channel octet g & 1); tap 9 carries zero weights
+    int tapA[NCH], tapB[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int tap = 2 * k + (g >> 1);
+        const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;
+        tapA[k] = (dy * XX + dx) * PIXB;
+        tapB[k] = (dy * TXTP + dx) * PIXB;
+    }
+    // stage B / C: wave w = rows 2*(w >> 1), +1 x columns 8*(w & 1) .. +7 (the 2x2 pooling blocks stay inside the wave)
+    const int pb_y = 2 * (wave >> 1) + (r >> 3), pb_x = 8 * (wave & 1) + (r & 7);
+    const int pbo = (pb_y * TXTP + pb_x) * PIXB + (g & 1) * 16;
+    const int pb_res = ((pb_y + 2) * XX + pb_x + 2) * PIXB + g * 8;
+    const int pb_f = (pb_y * TX + pb_x) * PIXB;
+    short8 w0[NCH][PARTS], w2[NCH][PARTS], w3f[2][PARTS], w1f[PARTS];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) {
+            w0[k][pt] = reinterpret_cast<const short8 *>(a.w0)[(k * PARTS + pt) * 64 + lane];
+            w2[k][pt] = reinterpret_cast<const short8 *>(a.w2)[(k * PARTS + pt) * 64 + lane];
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt) w3f[k][pt] = reinterpret_cast<const short8 *>(a.w3f)[(k * PARTS + pt) * 64 + lane];
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) w1f[pt] = reinterpret_cast<const short8 *>(a.w1f)[pt * 64 + lane];
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(a.b0 + g * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
+    auto tile_mma = [&](unsigned base, const int (&tapo)[NCH], auto loB_c, const short8 (&wf)[NCH][PARTS], f32x4 acc) {
+        constexpr int loB = decltype(loB_c)::value;   // the lo plane as an immediate of the read
+        short8 xh[NCH], xl[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const unsigned ad = base + tapo[k];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(ad), "n"(loB));
+            else xl[k] = xh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int left = (NCH - 1 - k) * PARTS;   // reads still allowed in flight (compile-time after unrolling)
+            if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xh[k]), "+v"(xl[k]));
+            else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xh[k]), "+v"(xl[k]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh[k]), "+v"(xl[k]));
+            if constexpr (PARTS == 2) {
+                acc = mma<F16>(wf[k][1], xh[k], acc);
+                acc = mma<F16>(wf[k][0], xl[k], acc);
+            }
+            acc = mma<F16>(wf[k][0], xh[k], acc);
+        }
+        return acc;
+    };
+
+    // two operand tiles side by side (stage A of the waves that own two): the reads of both run three chunks ahead of the MFMAs and the two
+    // accumulator chains alternate, so one tile's LDS latency and MFMA dependency gaps are covered by the other's work
+    auto tile_mma2 = [&](unsigned base0, unsigned base1, const int (&tapo)[NCH], auto loB_c, const short8 (&wf)[NCH][PARTS], f32x4 &acc0, f32x4 &acc1) {
+        static_assert(PARTS == 2 || PARTS == 1, "");
+        constexpr int NBUF = 3;
+        short8 xh[NBUF][2], xl[NBUF][2];
+        auto fetch = [&](int k) {
+            const unsigned a0 = base0 + tapo[k], a1 = base1 + tapo[k];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k % NBUF][0]) : "v"(a0));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k % NBUF][0]) : "v"(a0), "n"(decltype(loB_c)::value));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k % NBUF][1]) : "v"(a1));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k % NBUF][1]) : "v"(a1), "n"(decltype(loB_c)::value));
+        };
+        fetch(0);
+        fetch(1);
+        fetch(2);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int left = (NCH - 1 - k < 2 ? NCH - 1 - k : 2) * 2 * PARTS;   // reads of later chunks that may still be in flight
+            auto &h0 = xh[k % NBUF][0], &h1 = xh[k % NBUF][1], &l0 = xl[k % NBUF][0], &l1 = xl[k % NBUF][1];
+            if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));
+            if constexpr (PARTS == 1) {
+                l0 = h0;
+                l1 = h1;
+            }
+            if constexpr (PARTS == 2) {
+                acc0 = mma<F16>(wf[k][1], h0, acc0);
+                acc1 = mma<F16>(wf[k][1], h1, acc1);
+                acc0 = mma<F16>(wf[k][0], l0, acc0);
+                acc1 = mma<F16>(wf[k][0], l1, acc1);
+            }
+            acc0 = mma<F16>(wf[k][0], h0, acc0);
+            acc1 = mma<F16>(wf[k][0], h1, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 3 < NCH) fetch(k + 3);
+        }
+    };
+
+    constexpr int INFLIGHT = (RX - 2) * PPW;
+#pragma unroll
+    for (int q = 0; q < RX - 1; ++q) issue_next();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+
+    int xslot = 0;
+    f32x4 vq0 = f32x4{0.f, 0.f, 0.f, 0.f}, vq1 = vq0;
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v fop = {0u, 0u, 0u, 0u};
+    // the residual pixels of x for stage B: requested while their slice is stage A's (rn*), used one step later (rc*)
+    u32x2 rnh = {0u, 0u}, rnl = {0u, 0u}, rch = {0u, 0u}, rcl = {0u, 0u};
+    // stream positions: stage A works on (UA, zA), stage C on (UC, zC); P positions in all
+    const int ncol = (uend - ufirst + wgs_per_xcd - 1) / wgs_per_xcd;
+    const int P = ncol * a.N;
+    int cuA = ufirst, zA = 0;
+    Unit UA = decode(cuA), UB = UA, UC = UA;
+    int zB = 0, zC = 0;
+    for (int p = 0; p < P + 2; ++p) {
+        const bool hasA = p < P, hasB = p >= 1 && p <= P, hasC = p >= 2;
+        // ---- the step's one barrier: x[p] has landed (this wave's pieces; after the barrier everyone's), t[p - 1] is complete, x[p - 1]'s slot and t[p]'s buffer are free
+        if (hasA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(rnh), "+v"(rnl));   // (requested in the previous step, landed by the lgkmcnt(0) above)
+        rch = rnh;
+        rcl = rnl;
+        if (hasA && !(ABL & 8)) issue_next();      // slice p + RX - 1 into the slot x[p - 1] left
+        const unsigned tA = T_OFF + (p & 1) * TBUFB, tB = T_OFF + ((p & 1) ^ 1) * TBUFB;
+        // ---- stage A of position p -------------------------------------------------------------------------------------------------
+        if (hasA && !(ABL & 2)) {
+            f32x4 accA[TA];
+            if (nA == 2) {
+                accA[0] = b0;
+                accA[1] = b0;
+                tile_mma2(lds0 + X_OFF + xslot * SLOTB + pa[0], lds0 + X_OFF + xslot * SLOTB + pa[1], tapA, std::integral_constant<int, PLANEB>{}, w0, accA[0], accA[1]);
+            } else {
+                accA[0] = tile_mma(lds0 + X_OFF + xslot * SLOTB + pa[0], tapA, std::integral_constant<int, PLANEB>{}, w0, b0);
+                accA[1] = b0;
+            }
+#pragma unroll
+            for (int j = 0; j < TA; ++j) {
+                if (j >= nA) break;
+                const f32x4 acc = accA[j];
+                const int iy = UA.gy0 - 1 + ta_y[j], ix = UA.gx0 - 1 + ta_x[j];
+                const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                if (ta_ok[j]) {
+                    uint32_t h01, h23, l01, l23;
+                    Fmt<PREC>::split2(relu_lim_bits(acc[0], inside ? 0x7f800000 : 0), relu_lim_bits(acc[1], inside ? 0x7f800000 : 0), h01, l01);
+                    Fmt<PREC>::split2(relu_lim_bits(acc[2], inside ? 0x7f800000 : 0), relu_lim_bits(acc[3], inside ? 0x7f800000 : 0), h23, l23);
+                    lds_store8(tA + ta_st[j] - T_OFF, h01, h23);
+                    if constexpr (PARTS == 2) lds_store8(tA + ta_st[j] - T_OFF + TPLANEB, l01, l23);
+                }
+            }
+        }
+        if (hasA) {   // stage B's residual pixels of this slice, for the next step
+            const unsigned xp = lds0 + X_OFF + xslot * SLOTB + pb_res;
+            asm volatile("ds_read_b64 %0, %1" : "=v"(rnh) : "v"(xp));
+            if constexpr (PARTS == 2) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rnl) : "v"(xp), "n"(PLANEB));
+        }
+        // ---- stage B of position p - 1 ---------------------------------------------------------------------------------------------
+        if (hasB) {
+            if constexpr (!(ABL & 4)) {
+                const unsigned fslot_off = F_OFF + ((p - 1) % 3) * FSLOTB;
+                const f32x4 acc = tile_mma(lds0 + tB + pbo, tapB, std::integral_constant<int, TPLANEB>{}, w2, b2);
+                float r0, r1, r2, r3;
+                Fmt<PREC>::join2(rch[0], rcl[0], r0, r1);
+                Fmt<PREC>::join2(rch[1], rcl[1], r2, r3);
+                f32x4 v;
+                v[0] = relu_bits(acc[0] + r0);
+                v[1] = relu_bits(acc[1] + r1);
+                v[2] = relu_bits(acc[2] + r2);
+                v[3] = relu_bits(acc[3] + r3);
+                uint32_t fh01, fh23, fl01, fl23;
+                Fmt<PREC>::split2(v[0], v[1], fh01, fl01);
+                Fmt<PREC>::split2(v[2], v[3], fh23, fl23);
+                lds_store8(fslot_off + pb_f + g * 8, fh01, fh23);
+                if constexpr (PARTS == 2) lds_store8(fslot_off + FPLANEB + pb_f + g * 8, fl01, fl23);
+                fop = u32x4v{fh01, fh23, fl01, fl23};   // feat of position p - 1, channels 4g..4g+3 as [hi x4 | lo x4]: stage C's K octet for the slice behind it
+                vq1 = vq0;
+                vq0 = v;
+            }
+        } else {
+            vq1 = vq0;
+            fop = u32x4v{0u, 0u, 0u, 0u};
+        }
+        // ---- stage C of position q = p - 2: attention for slice zC of column UC (feat[zC + 1] = what stage B just wrote, unless the column ends here) ----
+        if (hasC && !(ABL & 1)) {
+            const int q = p - 2;
+            const unsigned sm = F_OFF + ((q + 2) % 3) * FSLOTB, sc = F_OFF + (q % 3) * FSLOTB;
+            if (zC == 0) {   // feat[-1] = 0: the ring slot behind holds the previous column's last slice, which nothing needs any more (the wave's own pixels)
+                lds_store8(sm + pb_f + g * 8, 0u, 0u);
+                if constexpr (PARTS == 2) lds_store8(sm + FPLANEB + pb_f + g * 8, 0u, 0u);
+            }
+            // chunk 0: K octet g = (slice zC - 1 + (g >> 1), channel octet g & 1) out of the ring; chunk 1: K octet g = channels 4g..4g+3 of feat[zC + 1] as
+            // [hi x4 | lo x4], straight from stage B's registers (fragments [w_hi w_hi] and [w_lo 0]: two MFMAs)
+            const unsigned ad0 = lds0 + ((g >> 1) ? sc : sm) + pb_f + (g & 1) * 16;
+            short8 fh0, fl0;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fh0) : "v"(ad0));
+            if constexpr (PARTS == 2) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl0) : "v"(ad0), "n"(FPLANEB));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0), "+v"(fl0));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh0));
+            }
+            const u32x4v fz = zC == a.N - 1 ? u32x4v{0u, 0u, 0u, 0u} : fop;   // feat[N] = 0
+            const short8 f1op = __builtin_bit_cast(short8, fz);
+            f32x4 at = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PARTS == 2) {
+                at = mma<F16>(w3f[1][1], f1op, at);
+                at = mma<F16>(w3f[0][1], fh0, at);
+                at = mma<F16>(w3f[0][0], fl0, at);
+            }
+            at = mma<F16>(w3f[1][0], f1op, at);
+            at = mma<F16>(w3f[0][0], fh0, at);
+            uint32_t ah01, ah23, al01, al23;
+            Fmt<PREC>::split2(relu_bits(at[0]), relu_bits(at[1]), ah01, al01);
+            Fmt<PREC>::split2(relu_bits(at[2]), relu_bits(at[3]), ah23, al23);
+            const u32x4v bq = {ah01, ah23, al01, al23};
+            const short8 b2op = __builtin_bit_cast(short8, bq);
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PARTS == 2) o = mma<F16>(w1f[1], b2op, o);
+            o = mma<F16>(w1f[0], b2op, o);
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = vq1[i] + relu_bits(o[i]);
+            uint32_t h01, h23, l01, l23;
+            Fmt<PREC>::split2(v[0], v[1], h01, l01);
+            Fmt<PREC>::split2(v[2], v[3], h23, l23);
+            const int64_t pix = (((int64_t)UC.b * a.N + zC) * a.H + UC.gy0 + pb_y) * a.W + UC.gx0 + pb_x;
+            if constexpr (POOL) {   // 2x2 block: column neighbour = lane r ^ 1, row neighbour = lane r ^ 8
+                float m[4];
+                Fmt<PREC>::join2(h01, l01, m[0], m[1]);
+                Fmt<PREC>::join2(h23, l23, m[2], m[3]);
+                uint32_t ph01, ph23, pl01, pl23;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {   // non-negative values (sums of two ReLU results): maxima on the bit patterns
+                    uint32_t mu = __float_as_uint(m[i]);
+                    mu = max(mu, (uint32_t)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                    mu = max(mu, (uint32_t)__builtin_amdgcn_mov_dpp((int)mu, 0x128, 0xF, 0xF, true));   // row_ror:8
+                    m[i] = __uint_as_float(mu);
+                }
+                Fmt<PREC>::split2(m[0], m[1], ph01, pl01);
+                Fmt<PREC>::split2(m[2], m[3], ph23, pl23);
+                if constexpr (PARTS == 2) {
+                    swap16(ph01, pl01);
+                    swap16(ph23, pl23);
+                }
+                if ((r & 9) == 0 && !(ABL & 32)) {
+                    const int64_t pp = (((int64_t)UC.b * a.N + zC) * (a.H / 2) + (UC.gy0 / 2 + (wave >> 1))) * (a.W / 2) + UC.gx0 / 2 + 4 * (wave & 1) + ((r & 7) >> 1);
+                    if constexpr (PARTS == 2) *reinterpret_cast<uint4 *>(a.pooled + pp * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(ph01, ph23, pl01, pl23);
+                    else *reinterpret_cast<uint2 *>(a.pooled + pp * rec + g * 4) = make_uint2(ph01, ph23);
+                }
+            }
+            if constexpr (PARTS == 2) {
+                swap16(h01, l01);
+                swap16(h23, l23);
+                if ((ABL & 32) == 0 || h01 == 0x12345u) *reinterpret_cast<uint4 *>(a.out + pix * rec + (g & 1) * C + (g >> 1) * 8) = make_uint4(h01, h23, l01, l23);
+            } else {
+                *reinterpret_cast<uint2 *>(a.out + pix * rec + g * 4) = make_uint2(h01, h23);
+            }
+        }
+        // ---- the positions move on --------------------------------------------------------------------------------------------------------
+        UC = UB;
+        zC = zB;
+        UB = UA;
+        zB = zA;
+        if (hasA) {
+            xslot = (xslot + 1 == RX) ? 0 : xslot + 1;
+            if (++zA == a.N) {
+                zA = 0;
+                cuA += wgs_per_xcd;
+                if (cuA < uend) UA = decode(cuA);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // one operand fragment (hi [+ lo] plane) of an of_roll tile, and the counted wait that releases it (DS operations retire in order: `left` =
 // operations requested after it that may still be in flight; the "+v" ties keep the MFMAs behind the wait)
 template <int PARTS, int LOB>
@@ -2130,6 +2539,26 @@ void srd_roll16_tile(int *ty, int *tx) {
 }
 
 void srd_roll16_kernel_name(int prec, bool pool, char *buf, int n) { snprintf(buf, n, "dffw::srd_roll16_kernel<%d, %s>", prec, pool ? "true" : "false"); }
+void srd_pipe16_kernel_name(int prec, bool pool, char *buf, int n) { snprintf(buf, n, "dffw::srd_pipe16_kernel<%d, %s, 0>", prec, pool ? "true" : "false"); }
+
+hipError_t launch_srd_pipe16(int prec, const SrdArgs &a, hipStream_t s) {
+    const int want = a.wgs > 0 ? a.wgs : 512;   // two resident workgroups per CU
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8)))), block(256);
+#define DFFW_SRDP16_LAUNCH(P)                                                                     \
+    do {                                                                                          \
+        if (a.pooled) hipLaunchKernelGGL((srd_pipe16_kernel<P, true>), grid, block, 0, s, a);     \
+        else hipLaunchKernelGGL((srd_pipe16_kernel<P, false>), grid, block, 0, s, a);             \
+    } while (0)
+    switch (prec) {
+        case P_BF16X3: DFFW_SRDP16_LAUNCH(P_BF16X3); break;
+        case P_FP16: DFFW_SRDP16_LAUNCH(P_FP16); break;
+        case P_BF16: DFFW_SRDP16_LAUNCH(P_BF16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef DFFW_SRDP16_LAUNCH
+    return hipGetLastError();
+}
 
 hipError_t launch_srd_roll16(int prec, const SrdArgs &a, hipStream_t s) {
     const int want = a.wgs > 0 ? a.wgs : 512;   // two resident workgroups per CU

@@ -191,6 +191,33 @@ def test_oracle_parity_fresh_inputs_and_batch_independence(lib_built):
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 3, 128, 256, 16), (3, 1, 128, 128, 0), (2, 2, 96, 288, 8), (3, 2, 352, 96, 0), (4, 10, 128, 128, 24),
+                                         (2, 15, 64, 96, 8)])
+def test_pipelined_srd_blocks_are_bit_identical_to_the_step_form(lib_built, B, N, H, W, wgs, prec, monkeypatch):
+    """srd_pipe16 (round 6, opt-in with DFFW_SRD_PIPE=1 -- it measured 6 % slower than the step form, profiles/r06_srd_two_slice.txt: stage A of stream
+    position p, stage B of p - 1 and stage C of p - 2 in one step with one barrier, the stream running on across columns) does the arithmetic of srd_roll16 (barrier | A | barrier | B, C | barrier per slice, one drain step per column) in the same order: V2 and
+    V3 (fed by its pooled copy) bit for bit, for every slice count incl. 1 and 2 (columns shorter than the pipeline), non-square maps, one column per
+    workgroup and long streams, all three arithmetics."""
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 3, "smooth").items()}
+    model = model_for(sd, (3, "smooth"), prec)
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=78)).cuda()
+    fd = torch.from_numpy(synth.focus_dists(B, N, 1, 1)).cuda()
+    if wgs:
+        monkeypatch.setenv("DFFW_SRD_WGS", str(wgs))
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    from dffinthewild_amd import engine
+    with torch.no_grad():
+        outs2, taps2 = model.forward_with_taps(FS, fd, ["V1", "V2", "V3"])
+        monkeypatch.setenv("DFFW_SRD_PIPE", "1")
+        outs, taps = model.forward_with_taps(FS, fd, ["V1", "V2", "V3"])
+    for nm in ("V1", "V2", "V3"):
+        assert torch.equal(taps[nm], taps2[nm]), nm
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 3, 128, 256, 16), (3, 1, 128, 128, 0), (2, 2, 96, 288, 8), (3, 2, 352, 96, 0)])
 def test_fused_srd_block_matches_three_launch_form(lib_built, B, N, H, W, wgs, prec, monkeypatch):
     """srd_roll (dffw_srd_roll.hip): conv.0 -> conv.2 (+x) -> attention over slices -> (1,2,2) max-pool of the 8-channel
@@ -373,7 +400,7 @@ def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monk
 
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK", "DFFW_NO_SMALL", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
                                  "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR",
-                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_ROLLT", "DFFW_NO_SLICE32", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE",
+                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_ROLLT", "DFFW_SRD_PIPE", "DFFW_NO_SLICE32", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE",
                                  "DFFW_ROLLK_MERGE_BELOW"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
