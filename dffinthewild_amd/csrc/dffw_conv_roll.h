@@ -99,8 +99,10 @@ struct Prog {
 constexpr int tap_of(int p, int dd) { return p == 0 ? 1 : (dd ? 0 : 2); }
 }   // namespace rollt
 // wave w of an 8-wave workgroup (64 input channels): output tile (w >> 1) & 1, role (w >> 2) * 2 + (w & 1) = A, B | C, D; of a 4-wave one (32): tile w >> 1, role A32 / C32
+// (32 -> 16 channels, the wide form: eight waves = roles A32 / C32 x four pixel sub-blocks; the filter buffer holds the two roles' shares once)
 inline int rollt_role(int cin, int wave) { return cin == 64 ? (wave >> 2) * 2 + (wave & 1) : (wave & 1 ? rollt::R_C32 : rollt::R_A32); }
 bool rollt_ok(int prec, const ConvArgs &a);   // the kernel covers the launch (a.Ng/Hg/Wg = input grid)
+void rollt_tile(int cout, int *ty, int *tx);  // input-grid column of the instantiation that serves `cout` output channels (16: the wide form, 8 x 16)
 hipError_t launch_conv_rollt(const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_rollt_kernel_name(const ConvArgs &a, char *buf, int n);
 // transposed 3x3x3 s(1,2,2), 16 -> 8 channels (tiles are columns of the INPUT grid; filter packed as ROLL_CHUNKS_T chunks)

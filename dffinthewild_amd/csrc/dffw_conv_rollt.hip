@@ -32,11 +32,16 @@
 namespace dffw {
 
 namespace rollt {
-constexpr int TY = DFFW_ROLLT_TY, TX = DFFW_ROLLT_TX, FY = TY + 1, ROWP = 2 * (TX + 2), RING = 4;
-static_assert(TY == 8 && TX == 8 && (4 * ROWP) % 16 == 0, "operand tiles are rows (j, j + 4) of an 8 x 8 column, a multiple of 256 bytes apart");
-template <int CIN>
+constexpr int TY = DFFW_ROLLT_TY, FY = TY + 1;
+// WIDE (32 -> 16 channels: `deconv_2`, `dres3.conv6`): one 16-channel output tile only, so the workgroup's eight waves are (role A32 / C32) x FOUR pixel
+// sub-blocks of an 8 x 16 column -- sub-block s = operand rows 2 (s >> 1), +1 (and +4) of column half s & 1 -- and a step is ONE pass per wave; ring of 5
+// slots (the slice issued in a step is waited for in front of the NEXT step's epilogue: a one-pass step is too short to cover the DMA latency)
+template <int CIN, bool WIDE>
 struct Lay {
-    static constexpr int NW = CIN / 8;            // waves per workgroup
+    static constexpr int TX = WIDE ? 2 * DFFW_ROLLT_TX : DFFW_ROLLT_TX;
+    static constexpr int ROWP = 2 * (TX + 2);     // row pitch in entries: [pixel TX + 1 (+ 1 pad)][octet]
+    static constexpr int RING = WIDE ? 5 : 4;
+    static constexpr int NW = WIDE ? 8 : CIN / 8; // waves per workgroup
     static constexpr int NG = CIN / 16;           // 16-channel groups of the input
     static constexpr int PARTE = FY * ROWP;       // entries of one part of a group: [row][pixel][octet]
     static constexpr int CQE = 2 * PARTE;         // ... of a group: [part][row][pixel][octet]
@@ -45,9 +50,11 @@ struct Lay {
     static constexpr int SLOTB = NPIECE * 1024;
     static constexpr int PPW = (NPIECE + NW - 1) / NW;   // DMA pieces per wave and slice (the last one exists for the first waves only)
     static constexpr int XCH_OFF = RING * SLOTB;
-    static constexpr int XCHB = CIN == 64 ? 8 * 1024 : 0;   // one pass's exchange: [output tile 2][direction 2][operand tile 2] partials of 1 KiB
+    static constexpr int XCHB = (CIN == 64 && !WIDE) ? 8 * 1024 : 0;   // one pass's exchange: [output tile 2][direction 2][operand tile 2] partials of 1 KiB
     static constexpr int LDSB = XCH_OFF + 2 * XCHB;
+    static_assert(DFFW_ROLLT_TY == 8 && DFFW_ROLLT_TX == 8 && (4 * ROWP) % 16 == 0, "operand tiles are rows (j, j + 4) x 8 columns, a multiple of 256 bytes apart");
     static_assert(SLOTB % 256 == 0 && LDSB <= 160 * 1024, "LDS layout");
+    static_assert(!WIDE || CIN == 32, "the wide form is built for 32 input channels");
 };
 // orders every later use of p[] behind the (volatile) asm statements before this point: the counted waits that cover their ds_reads
 template <int N>
@@ -71,16 +78,18 @@ __device__ __forceinline__ void res_load(u32x4 &dst, const unsigned ro, const ch
 }   // namespace rollt
 
 // MODE 0: out = [relu](acc); 1: out = [relu](acc + residual); 2: + second output (the value before the residual) + fused 1x1x1 classifier
-template <int CIN, int ROLE, int MODE>
+template <int CIN, int ROLE, int MODE, bool WIDE>
 __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t, unsigned char *smem, const int lane, const int wave) {
     using namespace rollt;
-    using L = Lay<CIN>;
+    using L = Lay<CIN, WIDE>;
     using P = Prog<ROLE>;
     constexpr bool RES = MODE >= 1, FULL = MODE == 2;
-    constexpr int NW = L::NW, NS = P::NS, NACC = P::NACC, NOWN = P::NOWN, NPT = 2 * NOWN, SLOTB = L::SLOTB;
+    constexpr int NW = L::NW, NS = P::NS, NACC = P::NACC, NOWN = P::NOWN, NPT = 2 * NOWN, SLOTB = L::SLOTB, TX = L::TX, ROWP = L::ROWP, RING = L::RING;
+    static_assert(!WIDE || !P::XCH, "wide form: roles A32 / C32");
     const int g = lane >> 4, r = lane & 15;
-    const int nt = (wave >> 1) & 1;
-    const int ntg = (int)blockIdx.y * 2 + nt;        // this wave's 16-channel output tile
+    const int nt = WIDE ? 0 : (wave >> 1) & 1;
+    const int ntg = WIDE ? 0 : (int)blockIdx.y * 2 + nt;   // this wave's 16-channel output tile
+    const int psw = WIDE ? wave >> 2 : 0, hw = WIDE ? (wave >> 1) & 1 : 0;   // wide form: this wave's operand row pair and column half
     const bool relu = a.relu == 1;
 
     // ---- this workgroup's units (8 x 8 columns of one sample's input grid): XCD x owns a contiguous range, as conv_roll -------------
@@ -149,7 +158,7 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
         }
     };
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {                          // the fill runs two slices ahead of the window's centre
+    for (int q = 0; q < RING - 2; ++q) {                   // the fill runs two (wide form: three) slices ahead of the window's centre
         static_for<L::PPW>([&](auto K) { issue_piece(K); });
         advance_fill();
     }
@@ -157,14 +166,14 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
     // ---- operand addressing: K octet g of a chunk = channels 32 chunk + 8 g .. = (group 2 chunk + (g >> 1), octet g & 1) of the set's tap; lane r of
     // operand tile j = input pixel (row j + 4 (r >> 3), column r & 7): window slice -> one of three address registers, everything else an immediate
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned abase = lds0 + (unsigned)(((g >> 1) * L::CQE + 4 * (r >> 3) * ROWP + (r & 7) * 2 + (g & 1)) * 16);
+    const unsigned abase = lds0 + (unsigned)(((g >> 1) * L::CQE + (4 * (r >> 3) + 2 * psw) * ROWP + (8 * hw + (r & 7)) * 2 + (g & 1)) * 16);
     // output: own slot k = phase (py, px): the lane's 16-byte piece (part g & 1 of channel octet 2 ntg + (g >> 1)) of output pixel (2 row + py, 2 col + px)
     // of operand tile 0; tile j adds 2 j output rows (wave-uniform).  vcls: the pixel's position in the fp32 score volume
     int vob[NOWN], vcls[NOWN];
 #pragma unroll
     for (int k = 0; k < NOWN; ++k) {
         const int ph = P::phase(P::own(k)), py = ph >> 1, px = ph & 1;
-        vcls[k] = (8 * (r >> 3) + py) * a.Wo + 2 * (r & 7) + px;
+        vcls[k] = (8 * (r >> 3) + py) * a.Wo + 2 * (8 * hw + (r & 7)) + px;
         vob[k] = vcls[k] * (2 * a.Cout) + (g & 1) * a.Cout + (ntg * 2 + (g >> 1)) * 8;
     }
     const int tstride = 8 * a.Wo * a.Cout;               // bytes between the output rows of consecutive operand tiles (2 rows of 2 Cout 16-bit elements)
@@ -176,7 +185,7 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
     // ---- the filter share: NU units x (hi, lo), resident for the whole walk ----
     short8 w[P::NU][2];
     {
-        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + ((size_t)blockIdx.y * NW + wave) * MAXU * 2 * 64 + lane;
+        const short8 *wp = reinterpret_cast<const short8 *>(t.wroll) + (WIDE ? (size_t)(wave & 1) : (size_t)blockIdx.y * NW + wave) * MAXU * 2 * 64 + lane;
 #pragma unroll
         for (int u = 0; u < P::NU; ++u) {
             w[u][0] = wp[(u * 2 + 0) * 64];
@@ -218,17 +227,19 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
     // centre is the volume's first / last slice -- the ring holds real slices only, so the sets of the missing slice contract zeroed operands.
     auto pass = [&](auto PS_, auto LIVE_, auto PEND_, auto PRE_, const bool nofront, const bool noback, char *o_f, char *pre_f, const char *res_f,
                     float *cls_f, const int rowlim_f) __attribute__((always_inline)) {
-        constexpr int ps = decltype(PS_)::value, pps = ps ^ 1;
+        constexpr int ps = decltype(PS_)::value, pps = ps ^ 1;   // (wide form: ps = the step's parity -- it only selects the fragment buffers)
+        const int tg0 = WIDE ? 2 * psw : 2 * pps;               // first operand tile (row) of the pending pass
         constexpr bool LIVE = decltype(LIVE_)::value, PEND = decltype(PEND_)::value, PRE = decltype(PRE_)::value;
         auto bufof = [](int q, int i) constexpr { return (q * NS + i) & 1; };
-        auto immof = [](int q, int i) constexpr { return (P::chunk(i) * 2 * L::CQE + (2 * q + P::dy(i)) * ROWP + P::dx(i) * 2) * 16; };
+        auto immof = [](int q, int i) constexpr { return (P::chunk(i) * 2 * L::CQE + ((WIDE ? 0 : 2 * q) + P::dy(i)) * ROWP + P::dx(i) * 2) * 16; };
         // residual pieces of the pending tiles (a lane outside the volume reads the column's first pixel instead: always inside)
         u32x4 rq[NPT];
 #pragma unroll
         for (int e = 0; e < NPT; ++e) rq[e] = u32x4{0, 0, 0, 0};
         if constexpr (RES && PEND) {
             static_for<NPT>([&](auto E) __attribute__((always_inline)) {
-                constexpr int e = decltype(E)::value, k = e / 2, tg = 2 * pps + e % 2;
+                constexpr int e = decltype(E)::value, k = e / 2;
+                const int tg = tg0 + e % 2;
                 const unsigned ro = tg < rowlim_f ? (unsigned)(vob[k] * 2 + tg * tstride) : 0u;
                 rollt::res_load(rq[e], ro, res_f);
             });
@@ -239,7 +250,8 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pp[tt]) : "v"(adr), "n"(pps * L::XCHB + tt * 1024));
         };
         auto epi = [&](auto E) __attribute__((always_inline)) {
-            constexpr int e = decltype(E)::value, k = e / 2, tt = e % 2, tg = 2 * pps + tt;
+            constexpr int e = decltype(E)::value, k = e / 2, tt = e % 2;
+            const int tg = tg0 + tt;
             f32x4 vv = pend[k][tt];
             if constexpr (P::XCH) vv += part[tt];
             const bool pv = tg < rowlim_f;
@@ -260,7 +272,7 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
         if constexpr (LIVE) {
             unsigned adw[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) adw[d] = abase + (unsigned)(((sidx + d) & (RING - 1)) * SLOTB);
+            for (int d = 0; d < 3; ++d) adw[d] = abase + (unsigned)((sidx + d >= RING ? sidx + d - RING : sidx + d) * SLOTB);
             if constexpr (!PRE) fetch(std::integral_constant<int, bufof(ps, 0)>{}, std::integral_constant<int, immof(ps, 0)>{}, x, adw[0]);
             f32x4 n[NACC][2];
 #pragma unroll
@@ -271,8 +283,8 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
                 // the next set's fragments: of this pass, of the step's second pass, or of the next step's window (its slice 0 = this window's slice 1)
                 if constexpr (i + 1 < NS)
                     fetch(std::integral_constant<int, bufof(ps, i + 1 < NS ? i + 1 : 0)>{}, std::integral_constant<int, immof(ps, i + 1 < NS ? i + 1 : 0)>{}, x, adw[P::d(i + 1 < NS ? i + 1 : 0)]);
-                else if constexpr (ps == 0) fetch(std::integral_constant<int, bufof(1, 0)>{}, std::integral_constant<int, immof(1, 0)>{}, x, adw[0]);
-                else fetch(std::integral_constant<int, bufof(2, 0)>{}, std::integral_constant<int, immof(0, 0)>{}, x, adw[1]);
+                else if constexpr (ps == 0 && !WIDE) fetch(std::integral_constant<int, bufof(1, 0)>{}, std::integral_constant<int, immof(1, 0)>{}, x, adw[0]);
+                else fetch(std::integral_constant<int, bufof(ps + 1, 0)>{}, std::integral_constant<int, immof(0, 0)>{}, x, adw[1]);
                 constexpr bool PR = P::XCH && PEND && i == 1;
                 if constexpr (PR) {
                     part_read(std::integral_constant<int, 0>{}, part, xrd);
@@ -309,12 +321,12 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
                 if constexpr (PEND) {
                     if constexpr (P::XCH && i == 2) rollt::tie(part);   // (set 2's wait has passed: the partials requested behind set 2's operands have landed)
                     if constexpr (i >= 3 && i - 3 < NPT) {
-                        if constexpr (RES && i == 3) rollt::wait_vm0(rq);
+                        if constexpr ((RES || WIDE) && i == 3) rollt::wait_vm0(rq);   // (wide form: also the slice queued in the previous step)
                         epi(std::integral_constant<int, (i >= 3 && i - 3 < NPT) ? i - 3 : 0>{});
                     }
                 }
-                if constexpr (ps == 0 && i >= NS - L::PPW) issue_piece(std::integral_constant<int, (i >= NS - L::PPW) ? i - (NS - L::PPW) : 0>{});
-                if constexpr ((PEND && i >= 2 && i - 3 < NPT) || (ps == 0 && i >= NS - L::PPW)) __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((ps == 0 || WIDE) && i >= NS - L::PPW) issue_piece(std::integral_constant<int, (i >= NS - L::PPW) ? i - (NS - L::PPW) : 0>{});
+                if constexpr ((PEND && i >= 2 && i - 3 < NPT) || ((ps == 0 || WIDE) && i >= NS - L::PPW)) __builtin_amdgcn_sched_barrier(0);
             });
             // hand the partial to the partner, keep the own tiles for the next pass.  (The MFMA -> DS wait states: hipcc does not see that an asm
             // blob reads an accumulator, so they are spelled out.)
@@ -328,7 +340,7 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
                 pend[k][0] = n[P::own(k)][0];
                 pend[k][1] = n[P::own(k)][1];
             }
-            if constexpr (ps == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (ps == 1 && !WIDE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // the operands requested for the next pass have landed (lgkmcnt(0) above): from here on they are ordinary values
             {
@@ -343,7 +355,7 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 rollt::tie(part);
             }
-            if constexpr (RES) rollt::wait_vm0(rq);
+            if constexpr (RES || WIDE) rollt::wait_vm0(rq);
             static_for<NPT>([&](auto E) __attribute__((always_inline)) { epi(E); });
         }
     };
@@ -360,6 +372,7 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
     const int64_t ostride = (int64_t)a.Ho * a.Wo * a.Cout * 4;   // bytes per output slice
     const int64_t cstride = (int64_t)a.Ho * a.Wo;                // score floats per slice
     bool first = true;
+    int par = 0;
     for (int cu = ufirst; cu < uend; cu += wgs_per_xcd) {
         const Unit U = decode(cu);
         const int64_t p0 = (((int64_t)U.b * a.No * a.Ho + 2 * U.gy0) * a.Wo + 2 * U.gx0);   // the column's first output pixel in slice 0
@@ -367,14 +380,21 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
         char *preptr = (FULL && a.out_pre) ? reinterpret_cast<char *>(a.out_pre) + p0 * a.Cout * 4 : nullptr;
         const char *resptr = RES ? reinterpret_cast<const char *>(a.res0) + p0 * a.Cout * 4 : nullptr;
         float *clsptr = (FULL && a.cls_w) ? a.cls_out + p0 : nullptr;
-        const int rowlim = (U.gx0 + (r & 7) < a.Wi) ? a.Hi - U.gy0 - 4 * (r >> 3) : 0;
+        const int rowlim = (U.gx0 + 8 * hw + (r & 7) < a.Wi) ? a.Hi - U.gy0 - 4 * (r >> 3) : 0;
         for (int z = 0; z < a.No; ++z) {
             const bool nofront = z == 0, noback = z == a.No - 1;
-            if (first) pass(I0{}, T{}, F{}, F{}, nofront, noback, pptr, ppre, pres, pcls, prowlim);
-            else pass(I0{}, T{}, T{}, T{}, nofront, noback, pptr, ppre, pres, pcls, prowlim);
-            pass(I1{}, T{}, T{}, T{}, nofront, noback, optr, preptr, resptr, clsptr, rowlim);
+            if constexpr (WIDE) {   // one pass per step; the template index is the step's parity (fragment buffers)
+                if (first) pass(I0{}, T{}, F{}, F{}, nofront, noback, pptr, ppre, pres, pcls, prowlim);
+                else if (par) pass(I1{}, T{}, T{}, T{}, nofront, noback, pptr, ppre, pres, pcls, prowlim);
+                else pass(I0{}, T{}, T{}, T{}, nofront, noback, pptr, ppre, pres, pcls, prowlim);
+                par ^= 1;
+            } else {
+                if (first) pass(I0{}, T{}, F{}, F{}, nofront, noback, pptr, ppre, pres, pcls, prowlim);
+                else pass(I0{}, T{}, T{}, T{}, nofront, noback, pptr, ppre, pres, pcls, prowlim);
+                pass(I1{}, T{}, T{}, T{}, nofront, noback, optr, preptr, resptr, clsptr, rowlim);
+            }
             first = false;
-            sidx = (sidx + 1) & (RING - 1);
+            sidx = sidx + 1 == RING ? 0 : sidx + 1;
             advance_fill();
             pptr = optr;
             ppre = preptr;
@@ -393,59 +413,74 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int CIN, int MODE>
-__global__ __launch_bounds__(CIN * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_rollt(const ConvArgs a, const RollArgs t) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[rollt::Lay<CIN>::LDSB];
+template <int CIN, int MODE, bool WIDE = false>
+__global__ __launch_bounds__((rollt::Lay<CIN, WIDE>::NW * 64)) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_rollt(const ConvArgs a, const RollArgs t) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[rollt::Lay<CIN, WIDE>::LDSB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the body is specialised on the wave's role: its sets, tap offsets and accumulator slots are compile-time constants
     if constexpr (CIN == 64) {
         if (wave < 4) {
-            if (wave & 1) rollt_body<CIN, rollt::R_B, MODE>(a, t, smem, lane, wave);
-            else rollt_body<CIN, rollt::R_A, MODE>(a, t, smem, lane, wave);
+            if (wave & 1) rollt_body<CIN, rollt::R_B, MODE, false>(a, t, smem, lane, wave);
+            else rollt_body<CIN, rollt::R_A, MODE, false>(a, t, smem, lane, wave);
         } else {
-            if (wave & 1) rollt_body<CIN, rollt::R_D, MODE>(a, t, smem, lane, wave);
-            else rollt_body<CIN, rollt::R_C, MODE>(a, t, smem, lane, wave);
+            if (wave & 1) rollt_body<CIN, rollt::R_D, MODE, false>(a, t, smem, lane, wave);
+            else rollt_body<CIN, rollt::R_C, MODE, false>(a, t, smem, lane, wave);
         }
     } else {
-        if (wave & 1) rollt_body<CIN, rollt::R_C32, MODE>(a, t, smem, lane, wave);
-        else rollt_body<CIN, rollt::R_A32, MODE>(a, t, smem, lane, wave);
+        if (wave & 1) rollt_body<CIN, rollt::R_C32, MODE, WIDE>(a, t, smem, lane, wave);
+        else rollt_body<CIN, rollt::R_A32, MODE, WIDE>(a, t, smem, lane, wave);
     }
 }
 
 static int rollt_mode(const ConvArgs &a) { return (a.out_pre || a.cls_w) ? 2 : a.res0 ? 1 : 0; }
+static bool rollt_wide(const ConvArgs &a) { return a.Cout == 16; }
+
+void rollt_tile(int cout, int *ty, int *tx) {
+    *ty = DFFW_ROLLT_TY;
+    *tx = cout == 16 ? 2 * DFFW_ROLLT_TX : DFFW_ROLLT_TX;
+}
 
 bool rollt_ok(int prec, const ConvArgs &a) {
     if (prec != P_BF16X3 || (a.dbg & DFFW_ARGS_NO_ROLLT)) return false;
-    if (a.outf || a.res1 || a.res_bcast || a.relu == 2 || a.C1 != 0 || (a.C0 != 32 && a.C0 != 64) || a.Cout % 32 || a.Cout > 64) return false;
+    if (a.outf || a.res1 || a.res_bcast || a.relu == 2 || a.C1 != 0 || (a.C0 != 32 && a.C0 != 64)) return false;
+    if (!(a.Cout == 32 || a.Cout == 64 || (a.Cout == 16 && a.C0 == 32))) return false;
     if (a.No != a.Ni || a.Ho != 2 * a.Hi || a.Wo != 2 * a.Wi) return false;
     const int mode = rollt_mode(a);
-    if (mode == 2 && (!a.res0 || (a.cls_w && (!a.cls_out || a.Cout != 32)))) return false;   // (the classifier's two partial dots: exactly two addends)
+    // (the classifier's partial dots are ADDED to the zeroed score volume: one or two addends, so the sum does not depend on their order)
+    if (mode == 2 && (!a.res0 || (a.cls_w && (!a.cls_out || a.Cout > 32)))) return false;
     if (mode != 2 && !a.out) return false;
     // 32-bit buffer / lane offsets: a sample's input volume (+ one footprint) and an output slice stay below 2^31 bytes
     return (int64_t)(a.Ni + 1) * a.Hi * a.Wi * a.C0 * 4 < (1ll << 31) && (int64_t)a.Ho * a.Wo * a.Cout * 4 < (1ll << 31);
 }
 
 hipError_t launch_conv_rollt(const ConvArgs &a, const RollArgs &t, hipStream_t s) {
-    const int nw = a.C0 / 8, ny = a.Cout / 32;
+    const bool wide = rollt_wide(a);
+    const int nw = wide ? 8 : a.C0 / 8, ny = wide ? 1 : a.Cout / 32;
     const int want = (t.wgs > 0 ? t.wgs : (nw == 8 ? 256 : 512)) / ny;   // 16 waves per CU either way
     const int per_xcd = (t.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8))), (unsigned)ny), block(nw * 64);
     const int mode = rollt_mode(a);
-#define DFFW_ROLLT_LAUNCH(CI, MD) hipLaunchKernelGGL((conv_rollt<CI, MD>), grid, block, 0, s, a, t)
-    if (nw == 8) {
-        if (mode == 2) DFFW_ROLLT_LAUNCH(64, 2);
-        else if (mode == 1) DFFW_ROLLT_LAUNCH(64, 1);
-        else DFFW_ROLLT_LAUNCH(64, 0);
+#define DFFW_ROLLT_LAUNCH(CI, MD, WD) hipLaunchKernelGGL((conv_rollt<CI, MD, WD>), grid, block, 0, s, a, t)
+    if (wide) {
+        if (mode == 2) DFFW_ROLLT_LAUNCH(32, 2, true);
+        else if (mode == 1) DFFW_ROLLT_LAUNCH(32, 1, true);
+        else DFFW_ROLLT_LAUNCH(32, 0, true);
+    } else if (nw == 8) {
+        if (mode == 2) DFFW_ROLLT_LAUNCH(64, 2, false);
+        else if (mode == 1) DFFW_ROLLT_LAUNCH(64, 1, false);
+        else DFFW_ROLLT_LAUNCH(64, 0, false);
     } else {
-        if (mode == 2) DFFW_ROLLT_LAUNCH(32, 2);
-        else if (mode == 1) DFFW_ROLLT_LAUNCH(32, 1);
-        else DFFW_ROLLT_LAUNCH(32, 0);
+        if (mode == 2) DFFW_ROLLT_LAUNCH(32, 2, false);
+        else if (mode == 1) DFFW_ROLLT_LAUNCH(32, 1, false);
+        else DFFW_ROLLT_LAUNCH(32, 0, false);
     }
 #undef DFFW_ROLLT_LAUNCH
     return hipGetLastError();
 }
 
-void conv_rollt_kernel_name(const ConvArgs &a, char *buf, int n) { snprintf(buf, n, "dffw::conv_rollt<%d, %d>", a.C0, rollt_mode(a)); }
+void conv_rollt_kernel_name(const ConvArgs &a, char *buf, int n) {
+    snprintf(buf, n, "dffw::conv_rollt<%d, %d, %s>", a.C0, rollt_mode(a), rollt_wide(a) ? "true" : "false");
+}
 
 }  // namespace dffw

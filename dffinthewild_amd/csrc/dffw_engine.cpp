@@ -804,8 +804,10 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // ---- conv_rollt (dffw_conv_rollt.hip): transposed 3x3x3 s(1,2,2), 32 / 64 -> 32 / 64 channels, the filter split over the workgroup's waves by output phase
     // and 16-channel output tile (rollt::Prog<role>: the wave's operand fragment sets and the accumulator slots = output phases each feeds).  A weight unit =
     // one tap x 32 channels (K octet g = channels 32 chunk + 8 g ..) x 16 outputs; units in the wave's set order, one per fed slot
-    if (geo == G3T && (cin_pad == 32 || cin_pad == 64) && L.cin == cin_pad && L.cout % 32 == 0 && L.cout <= 64 && !shortcut_w && prec == P_BF16X3) {
-        const int nw = cin_pad / 8, nhalf = L.cout / 32;
+    if (geo == G3T && (cin_pad == 32 || cin_pad == 64) && L.cin == cin_pad && ((L.cout % 32 == 0 && L.cout <= 64) || (L.cout == 16 && cin_pad == 32)) && !shortcut_w &&
+        prec == P_BF16X3) {
+        // (16 output channels, the wide form: the shares of the roles A32 / C32 once -- "waves" 0, 1 of one "half")
+        const int nw = L.cout == 16 ? 2 : cin_pad / 8, nhalf = L.cout == 16 ? 1 : L.cout / 32;
         std::vector<uint16_t> wr((size_t)nhalf * nw * rollt::MAXU * parts * 512, 0);
         auto pack_role = [&](auto ROLE_, int oh, int wv) {
             using PR = rollt::Prog<decltype(ROLE_)::value>;
@@ -1642,17 +1644,19 @@ struct Run {
         // transposed 32 / 64 -> 32 / 64 (deconv_1, dres2.conv5 / conv6, dres3.conv5, SPP conv9) on 8 x 8 columns of the input grid: the streaming kernel with the
         // filter split over the waves by output phase; a unit = (column, 32-channel output half)
         if (pc.wrollt && !o.in1 && !sw.on(SW_NO_ROLL) && !sw.on(SW_NO_ROLLT)) {
-            const int cols = ((in0.H + DFFW_ROLLT_TY - 1) / DFFW_ROLLT_TY) * ((in0.W + DFFW_ROLLT_TX - 1) / DFFW_ROLLT_TX);   // (partial columns are predicated in the kernel)
+            int tty, ttx;
+            rollt_tile(L.cout, &tty, &ttx);
+            const int cols = ((in0.H + tty - 1) / tty) * ((in0.W + ttx - 1) / ttx);   // (partial columns are predicated in the kernel)
             ConvArgs ak = a;
             ak.Ng = in0.N; ak.Hg = in0.H; ak.Wg = in0.W;
             ak.M = (int64_t)ak.B * in0.N * in0.H * in0.W;
-            if ((int64_t)in0.B * cols * (L.cout / 32) >= sw.rollt_min_units && rollt_ok(e->prec, ak)) {
+            if ((int64_t)in0.B * cols * std::max(1, L.cout / 32) >= sw.rollt_min_units && rollt_ok(e->prec, ak)) {
                 if (dry) return out;
                 RollArgs t;
                 memset(&t, 0, sizeof t);
                 t.wroll = pc.wrollt;
-                t.tiles_y = (in0.H + DFFW_ROLLT_TY - 1) / DFFW_ROLLT_TY;
-                t.tiles_x = (in0.W + DFFW_ROLLT_TX - 1) / DFFW_ROLLT_TX;
+                t.tiles_y = (in0.H + tty - 1) / tty;
+                t.tiles_x = (in0.W + ttx - 1) / ttx;
                 t.zsplit = 1;
                 t.total_tiles = in0.B * cols;
                 t.wgs = sw.roll_wgs;

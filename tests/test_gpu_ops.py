@@ -326,12 +326,13 @@ ROLLT_SHAPES = [(10, 32, 32, 0, 1, False), (1, 16, 24, 8, 1, True), (7, 24, 16, 
                 (5, 12, 20, 8, 1, True), (2, 60, 80, 0, 1, True), (4, 14, 18, 8, 0, True)]
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64)])
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64), (32, 16)])
 @pytest.mark.parametrize("N,H,W,wgs,relu,residual", ROLLT_SHAPES)
 def test_conv_rollt(eng, cin, cout, N, H, W, wgs, relu, residual, monkeypatch):
     """conv_rollt (dffw_conv_rollt.hip): ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1), 32 / 64 -> 32 / 64 channels (`deconv_1`, `dres2.conv5`, `dres3.conv5`, the
     pyramid's `conv9`; DEN.py:41-42, 194-200, 260-264) as a rolling window over 8 x 8 columns of the input grid with the resident filter split over the
-    waves by output phase (64 inputs: phase (1,1) also over K between a wave pair that exchanges one partial per operand tile): every slice count
+    waves by output phase (64 inputs: phase (1,1) also over K between a wave pair that exchanges one partial per operand tile; 32 -> 16, `deconv_2` / `dres3.conv6`:
+    the wide form, eight waves = two roles x four pixel sub-blocks of an 8 x 16 column, one pass per step, ring of five): every slice count
     incl. 1 and 2, one column per workgroup and long streams, a single column per sample, partial columns at the bottom / right edge (30 x 40 and 60 x 80:
     the 1/16- and 1/8-resolution volumes of a 480 x 640 stack; 12 x 20, 14 x 18), ReLU and residual on and off; against F.conv_transpose3d, bitwise
     repeatable, and against conv_tile on the same input (DFFW_NO_ROLLT)."""
@@ -350,24 +351,25 @@ def test_conv_rollt(eng, cin, cout, N, H, W, wgs, relu, residual, monkeypatch):
         monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
     kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, relu=relu, residual=res.cuda() if residual else None, precision="bf16x3")
     got = eng.op_conv3d(x.cuda(), w, **kw)
-    assert eng.last_conv_kernel() == "dffw::conv_rollt<%d, %d>" % (cin, 1 if residual else 0), eng.last_conv_kernel()
+    assert eng.last_conv_kernel() == "dffw::conv_rollt<%d, %d, %s>" % (cin, 1 if residual else 0, "true" if cout == 16 else "false"), eng.last_conv_kernel()
     assert rel(got, ref) <= TOL["bf16x3"], rel(got, ref)
     again = eng.op_conv3d(x.cuda(), w, **kw)
     assert torch.equal(got, again)                      # the K-split pair adds its two partials in a fixed order
     monkeypatch.setenv("DFFW_NO_ROLLT", "1")
     alt = eng.op_conv3d(x.cuda(), w, **kw)
-    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert eng.last_conv_kernel().startswith(("dffw::conv_tile<", "dffw::conv_roll_t32<")), eng.last_conv_kernel()
     assert rel(got, alt) <= 2e-5, rel(got, alt)
 
 
-@pytest.mark.parametrize("cin", [64, 32])
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (32, 16)])
 @pytest.mark.parametrize("N,H,W,wgs,relu", [(10, 32, 32, 0, 0), (1, 16, 24, 8, 0), (2, 30, 40, 16, 1), (3, 8, 8, 0, 0), (5, 12, 20, 8, 0)])
 @pytest.mark.parametrize("pre,cls", [(True, True), (True, False), (False, True)])
-def test_conv_rollt_second_output_and_classifier(eng, cin, N, H, W, wgs, relu, pre, cls, monkeypatch):
+def test_conv_rollt_second_output_and_classifier(eng, cin, cout, N, H, W, wgs, relu, pre, cls, monkeypatch):
     """conv_rollt<.., 2>: the hourglass's last layer (`dres2.conv6`, DEN.py:96-97, 264: `out = conv6(...)`, `out_in = x + out`, `cost = classif(out_in)`): the
     value before the skip add as a second output and the 1x1x1 32 -> 1 classifier folded into the epilogue -- its dot spans the two 16-channel output tiles
-    of a pixel, i.e. two waves, each adding its partial to the zeroed score volume (two addends: order-independent, so bitwise repeatable)."""
-    B, cout = 2, 32
+    of a pixel, i.e. two waves, each adding its partial to the zeroed score volume (two addends: order-independent, so bitwise repeatable; 16 outputs,
+    `dres3.conv6`: one)."""
+    B = 2
     x = rnd(B, cin, N, H, W, seed=91)
     w = rnd(cin, cout, 3, 3, 3, seed=92, scale=(2.0 / (cin * 27)) ** 0.5 * 3)
     bn = bn_params(cout, 93)
@@ -383,7 +385,7 @@ def test_conv_rollt_second_output_and_classifier(eng, cin, N, H, W, wgs, relu, p
         monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
     kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, relu=relu, residual=res.cuda(), precision="bf16x3", want_pre=pre, cls_weight=cw if cls else None)
     y, yp, sc = eng.op_conv3d(x.cuda(), w, **kw)
-    assert eng.last_conv_kernel() == "dffw::conv_rollt<%d, 2>" % cin, eng.last_conv_kernel()
+    assert eng.last_conv_kernel() == "dffw::conv_rollt<%d, 2, %s>" % (cin, "true" if cout == 16 else "false"), eng.last_conv_kernel()
     assert rel(y, ref) <= TOL["bf16x3"], rel(y, ref)
     if pre:
         assert rel(yp, ref_pre) <= TOL["bf16x3"], rel(yp, ref_pre)
@@ -393,7 +395,7 @@ def test_conv_rollt_second_output_and_classifier(eng, cin, N, H, W, wgs, relu, p
     assert torch.equal(y, y2) and (not pre or torch.equal(yp, yp2)) and (not cls or torch.equal(sc, sc2))
     monkeypatch.setenv("DFFW_NO_ROLLT", "1")
     ya, ypa, sca = eng.op_conv3d(x.cuda(), w, **kw)
-    assert eng.last_conv_kernel().startswith("dffw::conv_tile<"), eng.last_conv_kernel()
+    assert eng.last_conv_kernel().startswith(("dffw::conv_tile<", "dffw::conv_roll_t32<")), eng.last_conv_kernel()
     assert rel(y, ya) <= 2e-5 and (not pre or rel(yp, ypa) <= 2e-5) and (not cls or rel(sc, sca) <= 2e-5)
 
 
@@ -433,6 +435,7 @@ def test_no_lean_roll_switch_reaches_every_rolling_kernel(eng, monkeypatch):
     w = rnd(32, 16, 3, 3, 3, seed=72, scale=0.1)
     bn = bn_params(16, 73)
     kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, relu=1, precision="bf16x3")
+    monkeypatch.setenv("DFFW_NO_ROLLT", "1")             # (round 6: 32 -> 16 channels run on conv_rollt's wide form; conv_roll_t32 keeps the 16-input layers and is the fallback)
     a = eng.op_conv3d(x.cuda(), w, **kw)
     assert eng.last_conv_kernel().startswith("dffw::conv_roll_t32<") and eng.last_conv_kernel().endswith("true>"), eng.last_conv_kernel()
     x2 = rnd(B, 16, N, 128, 256, seed=74)
@@ -464,6 +467,7 @@ def test_conv_roll_transposed_32(eng, N, H, W, residual, wgs, cin, prec, monkeyp
     ref = F.relu(ref + res) if residual else F.relu(ref)
     if wgs:
         monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    monkeypatch.setenv("DFFW_NO_ROLLT", "1")             # (round 6: in split-bf16 the 32 -> 16 layers run on conv_rollt's wide form; this is its fallback and the 16-input kernel)
     kw = dict(transposed=True, stride=(1, 2, 2), pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
     got = eng.op_conv3d(x.cuda(), w, **kw)
     assert eng.last_conv_kernel().startswith("dffw::conv_roll_t32<"), eng.last_conv_kernel()
