@@ -325,6 +325,11 @@ __device__ __forceinline__ void epilogue_quad(const ConvArgs &a, const f32x4 &ac
     }
 }
 
+// the streaming kernels' 16-byte result store.  (Round 6, measured and not kept: as a NON-TEMPORAL store -- a wave's store covers 32-byte pieces of its pixels'
+// 128-byte records, the other pieces follow from the same or a neighbouring wave, and it is the L2 that merges them: with nt the pieces go out one by one,
+// conv_slice32 +31 %, conv_rollt +18 ... 37 %, the K-split kernels -2 %, the forward +1.7 %; profiles/r06_nt_stores.txt)
+__device__ __forceinline__ void dffw_store16(char *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+
 // Lean epilogue of the streaming kernels in split-bf16 storage: the same arithmetic and the same instruction sequence per value
 // as epilogue_quad<PREC, PRE, FAST> (bit-identical results), but straight-line.  The generic routine tests nine ConvArgs fields
 // per call; its ~25 taken branches, SGPR spills and AGPR round trips cost ~1100 cycles per operand tile in the rolling kernels
@@ -347,7 +352,7 @@ __device__ __forceinline__ float epilogue_lean(uint16_t *__restrict__ out, uint1
         Fmt<PREC>::split2(v2, v3, h23, l23);
         swap16(h01, l01);
         swap16(h23, l23);
-        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(base) + (uint32_t)(voff * 2)) = make_uint4(h01, h23, l01, l23);
+        dffw_store16(reinterpret_cast<char *>(base) + (uint32_t)(voff * 2), make_uint4(h01, h23, l01, l23));
     };
     if (out_pre) store(out_pre);
     if constexpr (RES) {
@@ -392,7 +397,7 @@ __device__ __forceinline__ void epilogue_lean_t(uint16_t *__restrict__ out, uint
         Fmt<PREC>::split2(v2, v3, h23, l23);
         swap16(h01, l01);
         swap16(h23, l23);
-        if (pv) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(base) + (uint32_t)(voff * 2)) = make_uint4(h01, h23, l01, l23);
+        if (pv) dffw_store16(reinterpret_cast<char *>(base) + (uint32_t)(voff * 2), make_uint4(h01, h23, l01, l23));
     };
     if (out_pre) store(out_pre);
     if (has_res) {
