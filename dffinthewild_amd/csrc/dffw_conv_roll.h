@@ -119,6 +119,12 @@ constexpr int ROLL_CHUNKS_8 = 9;
 void efd_roll_tile(int *ty, int *tx);
 hipError_t launch_conv_roll_efd(int prec, const ConvArgs &a, const RollArgs &t, hipStream_t s);
 void conv_roll_efd_kernel_name(int prec, const ConvArgs &a, bool dual, char *buf, int n);
+// conv_efd16 (dffw_conv_efd16.hip, round 6): the fused EFD block of the 16-channel stage, 16 -> 32 channels on 8 x 8 columns of the OUTPUT grid: a.in0 = x, a.in1 = its
+// (1,2,2) max-pool; t.wroll / t.wroll2 = the strided / pooled branch's filter in conv_roll_s2's order, a.bias / t.bias2 their BatchNorm shifts
+void efd16_tile(int *ty, int *tx);
+bool efd16_ok(int prec, const ConvArgs &a, const RollArgs &t);
+hipError_t launch_conv_efd16(const ConvArgs &a, const RollArgs &t, hipStream_t s);
+void conv_efd16_kernel_name(char *buf, int n);
 // strided 3x3x3 over 16 (kh = 1) or 32 (kh = 2) input channels: 16 -> 16 (nt = 1: columns of 4 x 16 output pixels), 16 / 32 -> 32
 // (nt = 2: 4 x 8; 64 output channels = two launches with RollArgs::pair = first output tile).  Filter packed per (16-channel output
 // tile, 16-channel input half) as ROLL_CHUNKS chunks [dz][5 chunks of 2 in-slice taps x 16 channels]: [output tile][half][chunk]

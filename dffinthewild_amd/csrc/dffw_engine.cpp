@@ -319,6 +319,7 @@ struct PackedConv {
     uint16_t *wroll_t = nullptr;   // device: the filter in conv_roll_t's order (transposed 3x3x3, 16 -> 8 channels)
     uint16_t *wroll8 = nullptr;    // device: a 3x3x3 8 -> 16 filter (stride 1 or (1,2,2)) in conv_roll_efd's order
     uint16_t *wroll_s2 = nullptr;  // device: a 3x3x3 stride-(1,2,2) 16 -> 16 / 32 filter in conv_roll_s2's order (15 chunks per 16-channel output tile)
+    uint16_t *wroll15 = nullptr;   // device: a 3x3x3 stride-1 16 -> 32 filter in the same order (the pooled branch of the fused 16-channel EFD block, conv_efd16)
     uint16_t *wroll_t32 = nullptr; // device: a transposed 3x3x3 32 -> 16 filter in conv_roll_t32's order (row phase 0: 9 chunks, then phase 1: 18)
     uint16_t *wsrd = nullptr;      // device: a 1x3x3 8 -> 8 filter in srd_roll's order (3 chunks of 4 taps x 8 channels)
     uint16_t *watt = nullptr;      // device: an 8 -> 8 attention conv (3x1x1 or 1x1x1) as srd_roll's stage-C fragments
@@ -368,6 +369,8 @@ static void free_packed(PackedConv &pc) {
     pc.wroll_t32 = nullptr;
     if (pc.wroll_s2) (void)hipFree(pc.wroll_s2);
     pc.wroll_s2 = nullptr;
+    if (pc.wroll15) (void)hipFree(pc.wroll15);
+    pc.wroll15 = nullptr;
     if (pc.wsrd) (void)hipFree(pc.wsrd);
     pc.wsrd = nullptr;
     if (pc.watt) (void)hipFree(pc.watt);
@@ -1128,7 +1131,9 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     }
     // ---- conv_roll_s2: 3x3x3 stride (1,2,2), 16 / 32 -> 16 / 32 / 64 channels: per (16-channel output tile, 16-channel input half) 15 chunks
     // [dz][k5], K octet g = (in-slice tap 2*k5 + (g >> 1), channel octet g & 1 of the half), as conv_roll's plain form
-    if (geo == G3S2 && (cin_pad == 16 || cin_pad == 32) && L.cout % 16 == 0 && L.cout <= 64 && !(cin_pad == 16 && L.cout == 64) && !shortcut_w) {
+    // (the same order for the stride-1 16 -> 32 layer `FM_conv2.0.max_pooling.1`: the pooled branch of conv_efd16)
+    const bool pool15 = geo == G3S1 && cin_pad == 16 && L.cout == 32 && !shortcut_w && !stem;
+    if ((geo == G3S2 && (cin_pad == 16 || cin_pad == 32) && L.cout % 16 == 0 && L.cout <= 64 && !(cin_pad == 16 && L.cout == 64) && !shortcut_w) || pool15) {
         const int ntl = L.cout / 16, khn = cin_pad / 16;
         std::vector<uint16_t> wr((size_t)ntl * khn * ROLL_CHUNKS * parts * 512, 0);
         for (int nt = 0; nt < ntl; ++nt)
@@ -1146,8 +1151,9 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
                             wr[base] = hi;
                             if (parts == 2) wr[base + 512] = lo;
                         }
-        HIPCHK(hipMalloc((void **)&pc.wroll_s2, wr.size() * sizeof(uint16_t)));
-        HIPCHK(hipMemcpy(pc.wroll_s2, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        uint16_t **dst = pool15 ? &pc.wroll15 : &pc.wroll_s2;
+        HIPCHK(hipMalloc((void **)dst, wr.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpy(*dst, wr.data(), wr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     // ---- conv_roll_t32: transposed 3x3x3 s(1,2,2), 32 -> 16 channels, one fragment set per output row phase py.  A chunk = one
     // tap x 32 channels (K octet g = channel octet g).  Enumeration (must match the kernel): x phase 0 first: (window slice d,
@@ -2379,6 +2385,54 @@ static Act efd(Run &r, const std::string &p, const Act &x, Act *pooled = nullptr
             }
             r.drop(*pooled);
             return out;
+        }
+    }
+    // the 16 -> 32 channel block (`FM_conv2.0`): both branches in one streaming kernel, the waves split by branch / output tile / pixel half (conv_efd16)
+    {
+        auto ca = r.e->convs.find(p + ".stride_conv.0"), cb = r.e->convs.find(p + ".max_pooling.1.0");
+        int ty, tx;
+        efd16_tile(&ty, &tx);
+        const int Ho = x.H / 2, Wo = x.W / 2;
+        const auto end = r.e->convs.end();
+        if (x.C == 16 && pooled && pooled->p && ca != end && cb != end && ca->second.wroll_s2 && cb->second.wroll15 && ca->second.def.cout == 32 && x.H % 2 == 0 &&
+            x.W % 2 == 0 && Ho % ty == 0 && Wo % tx == 0 && (int64_t)x.B * (Ho / ty) * (Wo / tx) >= r.sw.roll_min_units && !r.sw.on(SW_NO_ROLL) &&
+            !r.sw.on(SW_NO_FUSED_EFD) && !r.sw.on(SW_NO_TILE)) {
+            ConvArgs a;
+            memset(&a, 0, sizeof a);
+            a.in0 = x.p; a.C0 = 16;
+            a.in1 = pooled->p; a.C1 = 16;
+            a.B = x.B; a.Ni = x.N; a.Hi = x.H; a.Wi = x.W;
+            a.Ng = x.N; a.Hg = Ho; a.Wg = Wo;
+            a.No = x.N; a.Ho = Ho; a.Wo = Wo;
+            a.Cout = 32;
+            a.bias = ca->second.bias;
+            a.relu = 1;
+            a.M = (int64_t)x.B * x.N * Ho * Wo;
+            RollArgs t;
+            memset(&t, 0, sizeof t);
+            t.wroll = ca->second.wroll_s2;
+            t.wroll2 = cb->second.wroll15;
+            t.bias2 = cb->second.bias;
+            t.tiles_y = Ho / ty; t.tiles_x = Wo / tx;
+            t.zsplit = 1;
+            t.total_tiles = x.B * t.tiles_y * t.tiles_x;
+            t.wgs = r.sw.roll_wgs;
+            a.out = (uint16_t *)16;   // (placeholder for the check below: the output is allocated once the kernel is known to serve the shape)
+            if (efd16_ok(r.e->prec, a, t)) {
+                Act out = r.act(x.B, x.N, Ho, Wo, 32);
+                if (r.ok() && !r.dry) {
+                    a.out = out.p;
+                    char kn[64];
+                    conv_efd16_kernel_name(kn, sizeof kn);
+                    g_last_kernel = kn;
+                    const double opx = (double)x.B * x.N * Ho * Wo;
+                    r.prof_begin(kn, p, 2.0 * opx * 27.0 * 16 * 32 * 2, ((double)x.pixels() * 16 + opx * 16 + opx * 32) * r.elem_bytes());
+                    r.check(launch_conv_efd16(a, t, r.s), "conv_efd16");
+                    r.prof_end();
+                }
+                r.drop(*pooled);
+                return out;
+            }
         }
     }
     Act a = r.conv(p + ".stride_conv.0", x);

@@ -274,6 +274,34 @@ def test_fused_efd_block_matches_two_launch_form(lib_built, B, N, H, W, wgs, pre
         assert cpu_ref.rel_l2(outs[3].cpu(), ref[3]) <= 1e-3
 
 
+@pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 1, 64, 128, 0), (3, 2, 96, 160, 8), (2, 3, 128, 64, 16), (4, 10, 128, 128, 24), (1, 15, 32, 64, 0)])
+def test_fused_efd16_block_matches_two_launch_form(lib_built, B, N, H, W, wgs, monkeypatch):
+    """conv_efd16 (dffw_conv_efd16.hip, round 6): the EFD block of the 16-channel stage (DEN.py:306-315, `FM_conv2.0`: relu(BN(conv s(1,2,2)(x)) + BN(conv(maxpool(x)))),
+    16 -> 32 channels) in one streaming kernel whose eight waves are (branch, output tile, pixel half) and exchange one partial tile per step, against the two-launch
+    form (conv_roll_s2, then the pooled conv with the first as a residual): V3 = the following SRD block's output, and the depth maps against the oracle.  Slice counts 1,
+    2, 3, 10, 15, a single 8 x 8 column per sample, non-square maps, one column per workgroup and long streams; repeatable bit for bit (the two partials of a tile
+    are added in a fixed order)."""
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 4, "smooth").items()}
+    model = model_for(sd, (4, "smooth"), "bf16x3")
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=79)).cuda()
+    fd = torch.from_numpy(synth.focus_dists(B, N, 1, 1)).cuda()
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "1")
+    if wgs:
+        monkeypatch.setenv("DFFW_ROLL_WGS", str(wgs))
+    with torch.no_grad():
+        outs, taps = model.forward_with_taps(FS, fd, ["V3"])
+        again, taps_again = model.forward_with_taps(FS, fd, ["V3"])
+        monkeypatch.setenv("DFFW_NO_FUSED_EFD", "1")
+        outs2, taps2 = model.forward_with_taps(FS, fd, ["V3"])
+    assert torch.equal(taps["V3"], taps_again["V3"])
+    err = cpu_ref.rel_l2(taps["V3"].cpu(), taps2["V3"].cpu())
+    assert 0 < err <= 2e-5, err      # 0 would mean both runs took the same path
+    with torch.no_grad():
+        ref = cpu_ref.dff_forward(sd, FS.cpu(), fd.cpu())
+    assert cpu_ref.rel_l2(outs[3].cpu(), ref[3]) <= DRIFT_OUT
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("B,N,H,W", [(1, 10, 256, 256), (2, 1, 64, 128), (1, 2, 64, 64)])
 def test_mfma_attention_of_the_32_channel_block(lib_built, B, N, H, W, prec, monkeypatch):
