@@ -243,9 +243,11 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
     // partial columns at the volume's bottom / right edge (H or W not a multiple of 8: the 1/8-resolution volumes of 480 x 640 stacks): the fill's
     // range check zero-pads them, the epilogue's store (and residual read) is predicated on the lane's pixel lying inside: pv0 / pv1 for the unit
     // this wave owns in half-step 0 / 1 of the current column, ppv1 = pv1 of the step before (another column at a column change)
-    int pv0 = 1, pv1 = 1, ppv1 = 1;
+    int pvm = 7;                          // bit 0: pv0, bit 1: pv1, bit 2: ppv1 (one register for the three flags: the residual instantiations sit at the 256-register cap)
     char *pptr = nullptr;                 // where the previous step's output slice starts (wave-uniform)
-    const char *rptr = nullptr;           // ... and its residual slice
+    // the residual volume has the output's geometry: its slices are addressed through the output pointers + this distance (two fewer loop-carried 64-bit values:
+    // at the 256-register cap the 8-wave residual instantiations spilled 7 VGPRs in their prologue)
+    const int64_t rdelta = RES ? reinterpret_cast<const char *>(a.res0) - reinterpret_cast<const char *>(a.out) : 0;
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -288,8 +290,9 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         f32x4 part[NPA ? NPA : 1];
         u32x4 rq = {0, 0, 0, 0};
         if constexpr (FIN && RES) {
-            const char *rp = rptr_f + (uint32_t)(pv_f ? vob_f * 2 : 0);   // (a lane outside the volume reads the column's first pixel instead: always inside)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq) : "v"(rp) : "memory");
+            // (a lane outside the volume reads the column's first pixel instead: always inside; wave-uniform base in SGPRs + the lane's 32-bit byte offset)
+            const unsigned ro = (unsigned)(pv_f ? vob_f * 2 : 0);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rq) : "v"(ro), "s"(rptr_f) : "memory");
         }
         f32x4 v = zero4;
         auto fin_read = [&](auto B_) {
@@ -463,7 +466,7 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
 
     // One step of the stream.  LIVE: this window produces an output slice (nofront / noback: see half); PEND: the previous one did (its second
     // half-step's units are finished now).
-    auto step = [&](auto LIVE_, auto PEND_, const bool nofront, const bool noback, char *optr, const char *rp) {
+    auto step = [&](auto LIVE_, auto PEND_, const bool nofront, const bool noback, char *optr) {
         constexpr bool LIVE = decltype(LIVE_)::value, PEND = decltype(PEND_)::value;
         using T = std::true_type;
         using F = std::false_type;
@@ -472,26 +475,25 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         f32x4 dummy;
         if constexpr (LIVE) {
             // (a live step behind a live step finds its chunk 0 requested by that step's second half-step)
-            half(I0{}, T{}, std::integral_constant<bool, PEND && OWN1>{}, F{}, std::integral_constant<bool, PEND>{}, nofront, noback, mine1, pptr, rptr, vob1, ppv1, OWN0 ? mine0 : dummy);
-            half(I1{}, T{}, std::integral_constant<bool, OWN0>{}, T{}, T{}, nofront, noback, mine0, optr, rp, vob0, pv0, OWN1 ? mine1 : dummy);
+            half(I0{}, T{}, std::integral_constant<bool, PEND && OWN1>{}, F{}, std::integral_constant<bool, PEND>{}, nofront, noback, mine1, pptr, pptr + rdelta, vob1, pvm & 4, OWN0 ? mine0 : dummy);
+            half(I1{}, T{}, std::integral_constant<bool, OWN0>{}, T{}, T{}, nofront, noback, mine0, optr, optr + rdelta, vob0, pvm & 1, OWN1 ? mine1 : dummy);
         } else {
-            half(I0{}, F{}, std::integral_constant<bool, PEND && OWN1>{}, T{}, F{}, false, false, mine1, pptr, rptr, vob1, ppv1, dummy);
+            half(I0{}, F{}, std::integral_constant<bool, PEND && OWN1>{}, T{}, F{}, false, false, mine1, pptr, pptr + rdelta, vob1, pvm & 4, dummy);
         }
         sidx = (sidx + 1) & (RING - 1);
         advance_fill();
         pptr = optr;
-        rptr = rp;
-        ppv1 = pv1;
+        pvm = (pvm & 3) | ((pvm & 2) << 1);
     };
-    auto dispatch = [&](bool live, bool pend, bool nofront, bool noback, char *optr, const char *rp) {
+    auto dispatch = [&](bool live, bool pend, bool nofront, bool noback, char *optr) {
         using T = std::true_type;
         using F = std::false_type;
         if (live) {
-            if (pend) step(T{}, T{}, nofront, noback, optr, rp);
-            else step(T{}, F{}, nofront, noback, optr, rp);
+            if (pend) step(T{}, T{}, nofront, noback, optr);
+            else step(T{}, F{}, nofront, noback, optr);
         } else {
-            if (pend) step(F{}, T{}, false, false, optr, rp);
-            else step(F{}, F{}, false, false, optr, rp);
+            if (pend) step(F{}, T{}, false, false, optr);
+            else step(F{}, F{}, false, false, optr);
         }
     };
 
@@ -505,23 +507,20 @@ __device__ __forceinline__ void rollk_body(const ConvArgs &a, const RollArgs &t,
         // reaches the volume's end none -- a unit that covers all slices is ns live steps.
         {
             const int col = U.gx0 + (r & 7), row = U.gy0 + (myu >> 1) + 4 * (r >> 3);
-            pv0 = (col < a.Wo && row < a.Ho) ? 1 : 0;
-            pv1 = (col < a.Wo && row + 2 < a.Ho) ? 1 : 0;
+            pvm = (pvm & 4) | ((col < a.Wo && row < a.Ho) ? 1 : 0) | ((col < a.Wo && row + 2 < a.Ho) ? 2 : 0);
         }
         const int zlo = U.zbeg > 0 ? U.zbeg - 1 : 0, h0 = U.zbeg - zlo;
         const int ns = (U.zbeg + U.nz < a.Ni ? U.zbeg + U.nz : a.Ni - 1) - zlo + 1;
         char *optr = reinterpret_cast<char *>(a.out) + o0 - (int64_t)h0 * ostride;
-        const char *rp = RES ? reinterpret_cast<const char *>(a.res0) + o0 - (int64_t)h0 * ostride : nullptr;
         for (int st = 0; st < ns; ++st) {
             const bool live = st >= h0 && st - h0 < U.nz;
-            dispatch(live, prev_live, st == 0, st == ns - 1, optr, rp);
+            dispatch(live, prev_live, st == 0, st == ns - 1, optr);
             prev_live = live;
             optr += ostride;
-            if (RES) rp += ostride;
         }
     }
     // the last live step's second half-step is finished by the step behind it: past the end of the stream, one more (dead) step
-    if (prev_live) dispatch(false, true, false, false, nullptr, nullptr);
+    if (prev_live) dispatch(false, true, false, false, nullptr);
     // ... and the slices queued past the end of the stream are still in flight: a wave must not retire before its LDS-DMA has landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
