@@ -1269,6 +1269,8 @@ class Arena {
 
 using namespace dffw;
 
+extern "C" char **environ;
+
 // ---- engine ------------------------------------------------------------------------------------
 struct ProfRec {
     std::string kernel, layer;
@@ -1337,6 +1339,32 @@ enum SwitchId {
 #undef X_ID
     SW_COUNT
 };
+// A DFFW_* variable in the environment that nothing reads (a retired switch, a typo) is reported once per process: a retired switch that is silently ignored turns an
+// A/B script into base against base.
+static void warn_unknown_switches() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    static const char *const known[] = {
+#define X_NM(n) "DFFW_" #n,
+        DFFW_SWITCHES(X_NM)
+#undef X_NM
+        "DFFW_ROLL_WGS", "DFFW_SRD_WGS", "DFFW_SMALL_MAX_UNITS", "DFFW_ROLL_ZSPLIT", "DFFW_KSPLIT_TARGET", "DFFW_SPLIT_S64", "DFFW_SPLIT_T64", "DFFW_NARROW_MAX",
+        "DFFW_WARM_MAX_WGS", "DFFW_ROLLK_MERGE_BELOW", "DFFW_ROLLT_MIN_UNITS", "DFFW_ROLL_MIN_UNITS", "DFFW_SPLIT_WG", "DFFW_DEBUG_FLAGS", "DFFW_CONCURRENT_MAX_PIXELS",
+        "DFFW_SRD_PIPE", "DFFW_TRACE_LAYER", "DFFW_TRACE_OUT", "DFFW_NO_STEM_PAIR", "DFFW_RCCL_LIB", "DFFW_LIB_PATH", "DFFW_NO_PROBE", "DFFW_PRECISION",
+        "DFFW_BENCH_ONE_DEVICE", "DFFW_BENCH_TIMEOUT_S",
+        // development builds only (make ABL=1 / TRACE=1)
+        "DFFW_SRD_ABL", "DFFW_ROLLX_ABL", "DFFW_ROLLX_NTS", "DFFW_ROLLK_ABL", "DFFW_ROLLK_SKEW"};
+    for (char **e = ::environ; e && *e; ++e) {
+        if (strncmp(*e, "DFFW_", 5) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        const size_t n = eq ? (size_t)(eq - *e) : strlen(*e);
+        bool ok = false;
+        for (const char *k : known) ok = ok || (strlen(k) == n && strncmp(k, *e, n) == 0);
+        if (!ok) fprintf(stderr, "libdffw: environment variable %.*s is not a switch this library reads (retired or misspelt?) -- ignored\n", (int)n, *e);
+    }
+}
+
 struct Switches {
     bool f[SW_COUNT];
     int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 192, rollk_merge_below = 1 << 30, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
@@ -1381,6 +1409,7 @@ struct Switches {
         { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
         { const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS"); s.concurrent_max_pixels = z ? atoll(z) : -1; }
         s.srd_pipe = getenv_flag("DFFW_SRD_PIPE");
+        warn_unknown_switches();
         s.trace_layer = getenv("DFFW_TRACE_LAYER");
         s.trace_out = getenv("DFFW_TRACE_OUT");
         return s;
