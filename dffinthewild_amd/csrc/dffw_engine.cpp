@@ -1367,7 +1367,7 @@ static void warn_unknown_switches() {
 
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 192, rollk_merge_below = 1 << 30, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, rollk_merge_below = 1 << 30, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
     bool srd_pipe = false;   // DFFW_SRD_PIPE=1: the 16-channel SRD block on srd_pipe16 (one barrier per step) instead of srd_roll16
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     const char *trace_layer = nullptr, *trace_out = nullptr;
@@ -1401,7 +1401,7 @@ struct Switches {
         // tables at batch 32: the 16 x 16-grid layers (128 columns: one unit per CU) 0.058 -> 0.050-0.054 ms against conv_tile, dres0.0 0.099 -> 0.090, dres0.2 /
         // dres2.conv2 -1..2 % against two launches
         s.rollk_merge_below = geti("DFFW_ROLLK_MERGE_BELOW", 0, 1 << 30);
-        s.rollt_min_units = geti("DFFW_ROLLT_MIN_UNITS", 1, 192);   // (column, output half) units the transposed streaming kernel conv_rollt needs in its 8-wave forms, twice that in the 4-wave form (DFFW_ROLL_MIN_UNITS lowers it too)
+        s.rollt_min_units = geti("DFFW_ROLLT_MIN_UNITS", 1, 128);   // (column, output half) units the transposed streaming kernel conv_rollt needs in its 8-wave forms, 1.5x that in the 4-wave form (DFFW_ROLL_MIN_UNITS lowers it too)
         s.roll_min_units = geti("DFFW_ROLL_MIN_UNITS", 1, 192);   // columns a layer needs for its persistent streaming kernel (measured 16 ... 256
                                                                   // at batch 1 and 4: 192 is 3.6 % faster than 256 on one 5x224x224 stack, level elsewhere; <= 32 slower)
         s.rollt_min_units = std::min(s.rollt_min_units, s.roll_min_units);
@@ -1685,11 +1685,11 @@ struct Run {
             ConvArgs ak = a;
             ak.Ng = in0.N; ak.Hg = in0.H; ak.Wg = in0.W;
             ak.M = (int64_t)ak.B * in0.N * in0.H * in0.W;
-            // enough (column, output half) units to fill the chip: one 8-wave workgroup per CU, two of the 4-wave form (32 -> 32 / 64) -- at batch 8 (128 units) the kernel
-            // ran deconv_1 / dres2.conv6 / dres3.conv5 1.3x-1.9x slower than conv_tile on its idle half of the chip (gpurun layer tables, round 6)
+            // (column, output half) units from which the kernel beats conv_tile / conv_roll_t32, measured at batch 8 / 16 / 32 (profiles/r06_rollt_thresholds.txt): 128 for the
+            // 8-wave forms -- half the CUs busy, and still 0.046 vs 0.058 ms on deconv_1 at batch 8, 0.052 vs 0.072 on SPP conv9 at batch 32; 64 units lose --, 192 for the 4-wave form
             const int64_t rt_units = (int64_t)in0.B * cols * std::max(1, L.cout / 32);
             const bool rt_four = cin_pad == 32 && L.cout != 16;
-            if (rt_units >= (int64_t)sw.rollt_min_units * (rt_four ? 2 : 1) && rollt_ok(e->prec, ak)) {
+            if (rt_units >= (int64_t)sw.rollt_min_units * (rt_four ? 3 : 2) / 2 && rollt_ok(e->prec, ak)) {
                 if (dry) return out;
                 RollArgs t;
                 memset(&t, 0, sizeof t);
