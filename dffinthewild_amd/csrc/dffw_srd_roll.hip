@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
 #define DFFW_SRD_READ(k)                                                                                                                  \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xh[k]) : "v"(base), "n"(k * rowB));                                               \
     if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(base), "n"(k * rowB + loB));               \
-    else xl[k] = xh[k];
+    else xl[k] = short8{0, 0, 0, 0, 0, 0, 0, 0};   /* (single-part storage: never contracted; NOT a copy of the in-flight hi fragment, tools/isa_wait_lint.py) */
         DFFW_SRD_READ(0)
         DFFW_SRD_READ(1)
         DFFW_SRD_READ(2)
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void of_roll8_kernel(const SrdArgs a) {
 #define DFFW_SRD_READ(k)                                                                                                                  \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xh[k]) : "v"(base), "n"(k * rowB));                                               \
     if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(base), "n"(k * rowB + loB));               \
-    else xl[k] = xh[k];
+    else xl[k] = short8{0, 0, 0, 0, 0, 0, 0, 0};   /* (single-part storage: never contracted; NOT a copy of the in-flight hi fragment, tools/isa_wait_lint.py) */
         DFFW_SRD_READ(0)
         DFFW_SRD_READ(1)
         DFFW_SRD_READ(2)
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             const unsigned ad = base + tapo[k];
             asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
             if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(ad), "n"(loB));
-            else xl[k] = xh[k];
+            else xl[k] = short8{0, 0, 0, 0, 0, 0, 0, 0};   /* (single-part storage: never contracted; NOT a copy of the in-flight hi fragment, tools/isa_wait_lint.py) */
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             const unsigned ad = base + tapo[k];
             asm volatile("ds_read_b128 %0, %1" : "=v"(xh[k]) : "v"(ad));
             if constexpr (PARTS == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xl[k]) : "v"(ad), "n"(loB));
-            else xl[k] = xh[k];
+            else xl[k] = short8{0, 0, 0, 0, 0, 0, 0, 0};   /* (single-part storage: never contracted; NOT a copy of the in-flight hi fragment, tools/isa_wait_lint.py) */
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {

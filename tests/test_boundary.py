@@ -162,3 +162,20 @@ def test_comm_entry_points_fail_cleanly_without_gpu(eng):
     if not torch.cuda.is_available():
         rc = lib.dffw_comm_init_rank(0, 1, 0, b"\0" * eng.COMM_ID_BYTES, ctypes.byref(h))
         assert rc < 0 and not h.value and lib.dffw_last_error()
+
+
+def test_isa_wait_lint_finds_the_round6_hazard_and_nothing_else():
+    """tools/isa_wait_lint.py (round 6): no instruction hipcc places between an inline-asm load and the wait that covers it may read the load's destination registers.
+    The shipped conv_slice kernels are clean; the development build without the scheduling barrier between wait and tie (-DDFFW_SLICE_HAZARD=2) reproduces the copies that made
+    conv_slice64_head wrong by 2e-3 (profiles/r06_wait_tie_hazard.txt).  (hipcc cross-compiles gfx950 without a GPU; two compilations of one source, ~1 min.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    src = os.path.join(root, "dffinthewild_amd", "csrc", "dffw_conv_slice.hip")
+    tool = os.path.join(root, "tools", "isa_wait_lint.py")
+    clean = subprocess.run([sys.executable, tool, src], capture_output=True, text=True)
+    assert clean.returncode == 0, clean.stdout
+    bad = subprocess.run([sys.executable, tool, src], capture_output=True, text=True, env=dict(os.environ, LINT_DEFS="-DDFFW_SLICE_HAZARD=2"))
+    assert bad.returncode == 1 and "conv_slice64_head" in bad.stdout, bad.stdout
