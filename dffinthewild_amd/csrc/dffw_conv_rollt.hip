@@ -42,7 +42,7 @@ struct Lay {
     static constexpr int ROWP = 2 * (TX + 2);     // row pitch in entries: [pixel TX + 1 (+ 1 pad)][octet]
     static constexpr int RING = WIDE ? 5 : 4;
     static constexpr int NW = WIDE ? 8 : CIN / 8; // waves per workgroup
-    static constexpr int NG = CIN / 16;           // 16-channel groups of the input
+    static constexpr int NG = CIN / 16;           // 16-channel groups of the input (16 channels: one group, read by both K octet pairs)
     static constexpr int PARTE = FY * ROWP;       // entries of one part of a group: [row][pixel][octet]
     static constexpr int CQE = 2 * PARTE;         // ... of a group: [part][row][pixel][octet]
     static constexpr int SLOTE = NG * CQE;
@@ -54,7 +54,8 @@ struct Lay {
     static constexpr int LDSB = XCH_OFF + 2 * XCHB;
     static_assert(DFFW_ROLLT_TY == 8 && DFFW_ROLLT_TX == 8 && (4 * ROWP) % 16 == 0, "operand tiles are rows (j, j + 4) x 8 columns, a multiple of 256 bytes apart");
     static_assert(SLOTB % 256 == 0 && LDSB <= 160 * 1024, "LDS layout");
-    static_assert(!WIDE || CIN == 32, "the wide form is built for 32 input channels");
+    static_assert(!WIDE || CIN == 32 || CIN == 16, "the wide form is built for 32 input channels (16: `dres4.conv5`, the upper K octets carry zero weights)");
+    static_assert(CIN == 16 ? WIDE : true, "16 input channels: wide form only");
 };
 // orders every later use of p[] behind the (volatile) asm statements before this point: the counted waits that cover their ds_reads
 template <int N>
@@ -166,7 +167,7 @@ __device__ __forceinline__ void rollt_body(const ConvArgs &a, const RollArgs &t,
     // ---- operand addressing: K octet g of a chunk = channels 32 chunk + 8 g .. = (group 2 chunk + (g >> 1), octet g & 1) of the set's tap; lane r of
     // operand tile j = input pixel (row j + 4 (r >> 3), column r & 7): window slice -> one of three address registers, everything else an immediate
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned abase = lds0 + (unsigned)(((g >> 1) * L::CQE + (4 * (r >> 3) + 2 * psw) * ROWP + (8 * hw + (r & 7)) * 2 + (g & 1)) * 16);
+    const unsigned abase = lds0 + (unsigned)(((CIN >= 32 ? (g >> 1) : 0) * L::CQE + (4 * (r >> 3) + 2 * psw) * ROWP + (8 * hw + (r & 7)) * 2 + (g & 1)) * 16);
     // output: own slot k = phase (py, px): the lane's 16-byte piece (part g & 1 of channel octet 2 ntg + (g >> 1)) of output pixel (2 row + py, 2 col + px)
     // of operand tile 0; tile j adds 2 j output rows (wave-uniform).  vcls: the pixel's position in the fp32 score volume
     int vob[NOWN], vcls[NOWN];
@@ -443,8 +444,8 @@ void rollt_tile(int cout, int *ty, int *tx) {
 
 bool rollt_ok(int prec, const ConvArgs &a) {
     if (prec != P_BF16X3 || (a.dbg & DFFW_ARGS_NO_ROLLT)) return false;
-    if (a.outf || a.res1 || a.res_bcast || a.relu == 2 || a.C1 != 0 || (a.C0 != 32 && a.C0 != 64)) return false;
-    if (!(a.Cout == 32 || a.Cout == 64 || (a.Cout == 16 && a.C0 == 32))) return false;
+    if (a.outf || a.res1 || a.res_bcast || a.relu == 2 || a.C1 != 0 || (a.C0 != 16 && a.C0 != 32 && a.C0 != 64)) return false;
+    if (!(((a.Cout == 32 || a.Cout == 64) && a.C0 >= 32) || (a.Cout == 16 && a.C0 <= 32))) return false;
     if (a.No != a.Ni || a.Ho != 2 * a.Hi || a.Wo != 2 * a.Wi) return false;
     const int mode = rollt_mode(a);
     // (the classifier's partial dots are ADDED to the zeroed score volume: one or two addends, so the sum does not depend on their order)
@@ -462,7 +463,11 @@ hipError_t launch_conv_rollt(const ConvArgs &a, const RollArgs &t, hipStream_t s
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8))), (unsigned)ny), block(nw * 64);
     const int mode = rollt_mode(a);
 #define DFFW_ROLLT_LAUNCH(CI, MD, WD) hipLaunchKernelGGL((conv_rollt<CI, MD, WD>), grid, block, 0, s, a, t)
-    if (wide) {
+    if (wide && a.C0 == 16) {
+        if (mode == 2) DFFW_ROLLT_LAUNCH(16, 2, true);
+        else if (mode == 1) DFFW_ROLLT_LAUNCH(16, 1, true);
+        else DFFW_ROLLT_LAUNCH(16, 0, true);
+    } else if (wide) {
         if (mode == 2) DFFW_ROLLT_LAUNCH(32, 2, true);
         else if (mode == 1) DFFW_ROLLT_LAUNCH(32, 1, true);
         else DFFW_ROLLT_LAUNCH(32, 0, true);

@@ -807,8 +807,8 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
     // ---- conv_rollt (dffw_conv_rollt.hip): transposed 3x3x3 s(1,2,2), 32 / 64 -> 32 / 64 channels, the filter split over the workgroup's waves by output phase
     // and 16-channel output tile (rollt::Prog<role>: the wave's operand fragment sets and the accumulator slots = output phases each feeds).  A weight unit =
     // one tap x 32 channels (K octet g = channels 32 chunk + 8 g ..) x 16 outputs; units in the wave's set order, one per fed slot
-    if (geo == G3T && (cin_pad == 32 || cin_pad == 64) && L.cin == cin_pad && ((L.cout % 32 == 0 && L.cout <= 64) || (L.cout == 16 && cin_pad == 32)) && !shortcut_w &&
-        prec == P_BF16X3) {
+    if (geo == G3T && (cin_pad == 32 || cin_pad == 64 || (cin_pad == 16 && L.cout == 16)) && L.cin == cin_pad &&
+        ((L.cout % 32 == 0 && L.cout <= 64) || (L.cout == 16 && cin_pad <= 32)) && !shortcut_w && prec == P_BF16X3) {
         // (16 output channels, the wide form: the shares of the roles A32 / C32 once -- "waves" 0, 1 of one "half")
         const int nw = L.cout == 16 ? 2 : cin_pad / 8, nhalf = L.cout == 16 ? 1 : L.cout / 32;
         std::vector<uint16_t> wr((size_t)nhalf * nw * rollt::MAXU * parts * 512, 0);
@@ -836,7 +836,7 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
         };
         for (int oh = 0; oh < nhalf; ++oh)
             for (int wv = 0; wv < nw; ++wv)
-                switch (rollt_role(cin_pad, wv)) {
+                switch (rollt_role(cin_pad == 16 ? 32 : cin_pad, wv)) {
                     case rollt::R_A: pack_role(std::integral_constant<int, rollt::R_A>{}, oh, wv); break;
                     case rollt::R_B: pack_role(std::integral_constant<int, rollt::R_B>{}, oh, wv); break;
                     case rollt::R_C: pack_role(std::integral_constant<int, rollt::R_C>{}, oh, wv); break;

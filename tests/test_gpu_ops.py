@@ -326,13 +326,14 @@ ROLLT_SHAPES = [(10, 32, 32, 0, 1, False), (1, 16, 24, 8, 1, True), (7, 24, 16, 
                 (5, 12, 20, 8, 1, True), (2, 60, 80, 0, 1, True), (4, 14, 18, 8, 0, True)]
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64), (32, 16)])
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (32, 64), (32, 16), (16, 16)])
 @pytest.mark.parametrize("N,H,W,wgs,relu,residual", ROLLT_SHAPES)
 def test_conv_rollt(eng, cin, cout, N, H, W, wgs, relu, residual, monkeypatch):
     """conv_rollt (dffw_conv_rollt.hip): ConvTranspose3d k3 s(1,2,2) p1 op(0,1,1), 32 / 64 -> 32 / 64 channels (`deconv_1`, `dres2.conv5`, `dres3.conv5`, the
     pyramid's `conv9`; DEN.py:41-42, 194-200, 260-264) as a rolling window over 8 x 8 columns of the input grid with the resident filter split over the
     waves by output phase (64 inputs: phase (1,1) also over K between a wave pair that exchanges one partial per operand tile; 32 -> 16, `deconv_2` / `dres3.conv6`:
-    the wide form, eight waves = two roles x four pixel sub-blocks of an 8 x 16 column, one pass per step, ring of five): every slice count
+    the wide form, eight waves = two roles x four pixel sub-blocks of an 8 x 16 column, one pass per step, ring of five; 16 -> 16, `dres4.conv5`: the same with the upper K
+    octets on zero weights): every slice count
     incl. 1 and 2, one column per workgroup and long streams, a single column per sample, partial columns at the bottom / right edge (30 x 40 and 60 x 80:
     the 1/16- and 1/8-resolution volumes of a 480 x 640 stack; 12 x 20, 14 x 18), ReLU and residual on and off; against F.conv_transpose3d, bitwise
     repeatable, and against conv_tile on the same input (DFFW_NO_ROLLT)."""
@@ -361,7 +362,7 @@ def test_conv_rollt(eng, cin, cout, N, H, W, wgs, relu, residual, monkeypatch):
     assert rel(got, alt) <= 2e-5, rel(got, alt)
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (32, 16)])
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (32, 16), (16, 16)])
 @pytest.mark.parametrize("N,H,W,wgs,relu", [(10, 32, 32, 0, 0), (1, 16, 24, 8, 0), (2, 30, 40, 16, 1), (3, 8, 8, 0, 0), (5, 12, 20, 8, 0)])
 @pytest.mark.parametrize("pre,cls", [(True, True), (True, False), (False, True)])
 def test_conv_rollt_second_output_and_classifier(eng, cin, cout, N, H, W, wgs, relu, pre, cls, monkeypatch):
