@@ -407,7 +407,7 @@ def test_config3_batch32_two_goldens_and_properties(lib_built, monkeypatch):
             assert torch.equal(a, b), env              # same kernels, only their stream placement differs
 
 
-@pytest.mark.parametrize("which", ["batch2_bcast", "full_10x256"])
+@pytest.mark.parametrize("which", ["batch2_bcast", "full_10x256", "n15_wide", "ddff_5x224", "one_slice"])
 def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monkeypatch):
     """conv_tile's LEAN instantiations (straight-line epilogue) run the same arithmetic in the same order as the generic
     epilogue_quad, the four regression heads in one launch the same as one launch each, and the few-tile launches' weight warm-up
