@@ -8,6 +8,7 @@ scheduled in front of the wait.  This script compiles a source to gfx950 assembl
   * an s_waitcnt (inline or hipcc's own) retires all but the newest N entries of the queue it names (DS operations retire in order; VMEM: vmcnt(0) retires everything; a
     COUNTED vmcnt moves the older VMEM loads to an "assumed" list -- VGPR loads, LDS-DMA loads and stores do not retire in one order, so a counted wait is an assumption
     the stress tests pin, tests/test_gpu_forward.py::test_streaming_kernels_long_streams_repeat_bit_for_bit, not a guarantee);
+  * the walk is linear in the TEXT: behind an unconditional branch the in-flight state is reset (hazards across such an edge are missed, not invented);
   * any instruction OUTSIDE inline asm that reads a register still in flight is reported as a HAZARD (exit code 1); reads behind a counted vmcnt are listed as ASSUMED
     (the residual variants of conv_roll / conv_roll_t / conv_roll_t32, whose deep prefetch rules a drain out).
 usage: python tools/isa_wait_lint.py dffinthewild_amd/csrc/dffw_conv_slice.hip [more sources]      (exit code 1 when something is reported; extra compiler
@@ -56,6 +57,11 @@ def lint(src):
         if s.startswith(".") or s.startswith(";"):
             continue
         op = s.split()[0]
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            # the textual successor of an unconditional branch is not its successor in execution: what is in flight there is unknown (taken as nothing --
+            # a hazard across such an edge is missed rather than invented)
+            ds, vm, vma = [], [], []
+            continue
         if op == "s_waitcnt":
             m = re.search(r"lgkmcnt\((\d+)\)", s)
             if m:
