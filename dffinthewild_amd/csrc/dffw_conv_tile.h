@@ -44,7 +44,8 @@ struct TileCfg {
     // derived LDS image constants (host needs them to precompute tap offsets)
     int fz, fy, fx, fxl;
     int pipe;            // 1: software-pipelined MFMA loop (compute-bound layers), 0: lean loop (bandwidth-bound)
-    int nw;              // waves per workgroup (4, or 8 for the wide tiles)
+    int nw;              // waves per workgroup (4, or 8 for the wide tiles) -- per TEAM for the team configurations
+    int kt = 1;          // teams per workgroup (> 1: the contraction depth split inside the workgroup, see conv_tile's header; nw * kt waves)
 };
 
 struct TileArgs {
@@ -72,6 +73,9 @@ const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide = false);
 const TileCfg *tile_cfg_find_shape(int geo, int nt, int cg, int tz, int ty, int tx);
 // configuration with the same geometry, channel group and TILE SHAPE as `base` but `nt` output tiles (for splits)
 const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt);
+// the team configuration that replaces a split-K launch of `base` (same pack) over `nstage` stages -- one stage per team -- with `nt` output tiles per
+// workgroup, or nullptr
+const TileCfg *tile_cfg_find_team(const TileCfg *base, int nstage, int nt);
 bool tile_cfg_has_splitk(const TileCfg *c);   // a split-K instantiation of this configuration exists
 bool tile_cfg_has_sums(const TileCfg *c);     // a row-sums instantiation (DFFW_ARGS_SUMS: per-row sums through ConvArgs::outf, nothing stored) exists
 int tile_cfg_count();

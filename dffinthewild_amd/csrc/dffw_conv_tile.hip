@@ -36,8 +36,13 @@ namespace dffw {
 // LEAN: the launch's epilogue is one the straight-line routine covers (tile_lean(): split-bf16 storage, out / out_pre / fused
 // classifier, at most one residual in the output's geometry, ReLU after it): epilogue_lean_t instead of epilogue_quad's run-time
 // option tree (which costs ~1000 cycles per operand tile and 16-channel group)
-template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4, bool SPLITK = false, bool LEAN = false>
-__global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const TileArgs t) {
+// KT (round 6, "teams"): the split of the contraction depth INSIDE the workgroup -- KT teams of NWAVES waves, team z owns the channel-group stages
+// [z nstage / KT, (z + 1) nstage / KT) (the split-K partition) and its own LDS image; the teams' accumulators meet in LDS (team 0 adds them in team
+// order and runs the epilogue): no fp32 partials through memory and no splitk_finish launch behind the kernel, which is what the few-tile layers of a
+// batch-1 forward pay for split-K (28 of its 89 launches, 5-6 us each on a chain of dependent 11 us launches).  nstage % KT == 0 (the teams meet at
+// the same workgroup barriers), single-pass geometries only.
+template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4, bool SPLITK = false, bool LEAN = false, int KT = 1>
+__global__ __launch_bounds__(NWAVES * KT * 64) void conv_tile(const ConvArgs a, const TileArgs t) {
     using T = TileT<GEO, TZ, TY, TX, CG>;
     using G = GeoT<GEO>;
     constexpr int PARTS = Fmt<PREC>::PARTS;
@@ -64,9 +69,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     constexpr int PLANEB = (T::FPIX * PIXB + 1023) / 1024 * 1024;
     constexpr int LDSB = PARTS * PLANEB;
     static_assert(PLANEB < 65536, "lo-plane offset must fit the ds_read immediate");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
+    static_assert(KT == 1 || (!SPLITK && GEO != G2D && GEO != G2P), "teams: conv geometries (the transposed conv only with its passes split over grid.z), no split-K / raw variants");
+    static_assert(KT * LDSB <= 160 * 1024, "the teams' LDS images must fit one CU");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem_all[KT * LDSB];
 
-    const int tid = threadIdx.x;
+    const int team = KT > 1 ? (int)threadIdx.x / (NWAVES * 64) : 0;       // (wave-uniform)
+    unsigned char *const smem = smem_all + team * LDSB;                   // this team's image
+    const int tid = KT > 1 ? (int)threadIdx.x % (NWAVES * 64) : (int)threadIdx.x;   // thread, wave within the team
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     // (compiled in only with -DDFFW_TRACE_BUILD: the checks cost a few percent on the large layers)
     auto stamp = [&](int k) {
 #ifdef DFFW_TRACE_BUILD
-        if (a.trace && tid == 0) a.trace[(int64_t)tile * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (a.trace && tid == 0 && team == 0) a.trace[(int64_t)tile * 8 + k] = __builtin_amdgcn_s_memtime();
 #else
         (void)k;
 #endif
@@ -209,8 +218,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     // split-K (few-tile layers with a deep contraction, see Run::conv): blockIdx.z owns a contiguous range of the
     // channel-group stages and writes raw fp32 partial sums; splitk_finish adds them up and runs the epilogue
     const bool splitk = SPLITK && !STEM && !SUMS && t.ksplit > 1;
-    const int st_lo = splitk ? (int)blockIdx.z * t.nstage / t.ksplit : 0;
-    const int st_hi = splitk ? ((int)blockIdx.z + 1) * t.nstage / t.ksplit : t.nstage;
+    const int st_lo = KT > 1 ? team * t.nstage / KT : splitk ? (int)blockIdx.z * t.nstage / t.ksplit : 0;
+    const int st_hi = KT > 1 ? (team + 1) * t.nstage / KT : splitk ? ((int)blockIdx.z + 1) * t.nstage / t.ksplit : t.nstage;
     // pass split (transposed conv, few tiles): the 4 sub-pixel passes write disjoint output phases, so they can be
     // 4 workgroups instead of a 4x longer chain in one
     const int pass_lo = (G::NPASS > 1 && t.pass_split) ? (int)blockIdx.z : 0;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < MTW; ++j) acc[nt][j] = (BIAS_IN_ACC && !splitk) ? bias4[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < MTW; ++j) acc[nt][j] = (BIAS_IN_ACC && !splitk && team == 0) ? bias4[nt] : f32x4{0.f, 0.f, 0.f, 0.f};
 
             const int KC = t.KC[pass];
             const int *tab = t.tab[pass] + g;
@@ -373,6 +382,23 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
 #pragma unroll
                     for (int pt = 0; pt < PARTS; ++pt) wfirst[nt][pt] = wp[(nt * PARTS + pt) * 64];
                 const int tfirst = tab[0];
+                // team configurations: weight fragments and tap offsets WD chunks ahead (a ring of WD register sets, requested in front of the wait for the image).
+                // These launches run one or two workgroups per CU on a mostly idle chip: one chunk ahead, every chunk of 6-12 MFMAs waited ~600 cycles
+                // for its fragments' L2 round trip -- 6.1k cycles for a 14-chunk stage (phase timeline of dres8_1.0 at batch 1).
+                constexpr int WD = KT > 1 ? 4 : 1;
+                short8 wr[WD][NT][PARTS];
+                int tr[WD];
+                if constexpr (KT > 1) {
+#pragma unroll
+                    for (int q = 0; q < WD; ++q) {
+                        const int kq = q < KC ? q : KC - 1;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int pt = 0; pt < PARTS; ++pt) wr[q][nt][pt] = wp[(int64_t)kq * wstride + (nt * PARTS + pt) * 64];
+                        tr[q] = tab[kq * 4];
+                    }
+                }
                 if ((pass == pass_lo || st_hi - st_lo > 1) && !resident && !(a.dbg & 1)) {
                     if (!prefilled) {
                         __syncthreads();  // everyone is done reading the previous image
@@ -421,6 +447,53 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     #pragma unroll
                             for (int pt = 0; pt < PARTS; ++pt) wf[nt][pt] = wn[nt][pt];
                         toff = tn;
+                    }
+                } else if constexpr (KT > 1) {
+                    // team loop: the operands of chunk k + 1 are read while chunk k is contracted, the fragments of chunk k + WD requested behind it
+                    short8 xc[MTW][PARTS], xn[MTW][PARTS];
+#pragma unroll
+                    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PARTS; ++pt) xc[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tr[0] + pt * PLANEB);
+                    for (int kc0 = 0; kc0 < ((a.dbg & 2) ? 1 : KC); kc0 += WD) {
+#pragma unroll
+                        for (int q = 0; q < WD; ++q) {
+                            const int kc = kc0 + q;
+                            if (kc < KC) {
+                                if (kc + 1 < KC) {
+#pragma unroll
+                                    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                                        for (int pt = 0; pt < PARTS; ++pt)
+                                            xn[j][pt] = *reinterpret_cast<const short8 *>(smem + pofs[j] + tr[(q + 1) % WD] + pt * PLANEB);
+                                }
+                                if constexpr (PARTS == 2) {
+#pragma unroll
+                                    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                                        for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wr[q][nt][1], xc[j][0], acc[nt][j]);
+#pragma unroll
+                                    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                                        for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wr[q][nt][0], xc[j][1], acc[nt][j]);
+                                }
+#pragma unroll
+                                for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt) acc[nt][j] = mma<F16>(wr[q][nt][0], xc[j][0], acc[nt][j]);
+                                if (kc + WD < KC) {
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                        for (int pt = 0; pt < PARTS; ++pt) wr[q][nt][pt] = wp[(int64_t)(kc + WD) * wstride + (nt * PARTS + pt) * 64];
+                                    tr[q] = tab[(kc + WD) * 4];
+                                }
+#pragma unroll
+                                for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                                    for (int pt = 0; pt < PARTS; ++pt) xc[j][pt] = xn[j][pt];
+                            }
+                        }
                     }
                 } else {
                     // Software pipeline: the wave's MTW operand tiles are split into two groups; while the matrix
@@ -506,6 +579,28 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
                 }
             }
 
+            if constexpr (KT > 1) {
+                // ---- the teams' partial sums meet in LDS: [team - 1][wave][output tile][operand tile][64 lanes] x 16 bytes over the images, which
+                // nobody reads any more behind the first barrier; team 0 adds them in team order (fixed order: run-to-run identical) ----
+                static_assert((KT - 1) * NWAVES * NT * MTW * 1024 <= KT * LDSB, "reduction area");
+                __syncthreads();
+                if (team > 0) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j)
+                            *reinterpret_cast<f32x4 *>(smem_all + ((((team - 1) * NWAVES + wave) * NT + nt) * MTW + j) * 1024 + lane * 16) = acc[nt][j];
+                }
+                __syncthreads();
+                if (team > 0) return;
+#pragma unroll
+                for (int z = 1; z < KT; ++z)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < MTW; ++j)
+                            acc[nt][j] += *reinterpret_cast<const f32x4 *>(smem_all + ((((z - 1) * NWAVES + wave) * NT + nt) * MTW + j) * 1024 + lane * 16);
+            }
             // ---- epilogue of this pass (shared with conv_igemm, see dffw_device.h) ---------------------------
             if (pass == G::NPASS - 1) stamp(3);
             const int ooy = t.ooy[pass], oox = t.oox[pass];
@@ -780,7 +875,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     if (a.trace) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of this wave issued AND acknowledged
         stamp(4);
-        if (tid == 0) {
+        if (tid == 0 && team == 0) {
             unsigned hwid;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             unsigned xcc;
@@ -858,6 +953,23 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_tile(const ConvArgs a, const
     X(38, G3S2, 2, 4, 4, 8, 16, 1)   \
     X(39, G3S2, 1, 4, 4, 8, 16, 1)
 
+// "team" configurations (KT teams of NW waves per workgroup, see the kernel header): what a few-tile layer runs on INSTEAD of a split-K launch + splitk_finish.
+// Same (geo, NT, TY, TX, CG) as a split-K configuration -- the packs and tap tables do not depend on TZ.  Small blocks (64 grid points, two waves per team):
+// a team launch has 1 / KT of the split-K launch's workgroups, and these layers are latency chains on a mostly idle chip -- first measured with the split-K
+// blocks (320 points, four waves per team): the teams of a workgroup share their SIMDs' matrix pipes, 14.1 us against 11.5 + the finish launch.
+//        id  geo   NT  TZ TY  TX  CG  PIPE NW KT
+#define DFFW_TILE_CONFIGS_TEAM(X)           \
+    X(50, G3S1, 1, 1, 4, 16, 16, 1, 2, 2)   \
+    X(51, G3S1, 1, 1, 4, 16, 16, 1, 2, 4)   \
+    X(52, G3S2, 1, 1, 4, 16, 8, 1, 2, 2)    \
+    X(53, G3S2, 1, 1, 4, 16, 8, 1, 2, 4)    \
+    X(58, G3T, 1, 1, 4, 16, 32, 1, 2, 2)    \
+    X(59, G3T, 1, 1, 4, 16, 32, 1, 2, 4)    \
+    X(60, G3T, 2, 1, 4, 16, 32, 1, 2, 2)    \
+    X(61, G3T, 2, 1, 4, 16, 32, 1, 2, 4)
+// (built and dropped, batch 1 / 2 layer tables in profiles/r06_batch1_teams.txt: the 2 x 4 x 8 blocks of the 8 x 8-grid layers with 128-192 input channels, 4 and 8
+// teams of two or three stages each -- 40-96 workgroups walk what split-K spreads over 192: combine2 27.9 against 24.1 us, conv4 21-41 against 19-22)
+
 #if DFFW_TILE_PREC == 0 && !defined(DFFW_TILE_LEAN)   // configuration table and look-ups live in one of the per-precision objects
 bool tile_cfg_has_sums(const TileCfg *c) { return c && c->geo == G2S1 && c->nw == 4 && (c->id == 34 || c->id == 19); }
 bool tile_cfg_has_splitk(const TileCfg *c) {
@@ -876,30 +988,43 @@ bool tile_cfg_has_splitk(const TileCfg *c) {
 #define X_CFG8(ID, GEO, NT, TZ, TY, TX, CG, PIPE)                                                            \
     TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
             TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL, PIPE, 8},
-static const TileCfg g_cfgs[] = {DFFW_TILE_CONFIGS(X_CFG) DFFW_TILE_CONFIGS_W8(X_CFG8)};
+#define X_CFGT(ID, GEO, NT, TZ, TY, TX, CG, PIPE, NW, KT)                                                    \
+    TileCfg{ID, GEO, NT, CG, TZ, TY, TX, TileT<GEO, TZ, TY, TX, CG>::FZ, TileT<GEO, TZ, TY, TX, CG>::FY, \
+            TileT<GEO, TZ, TY, TX, CG>::FX, TileT<GEO, TZ, TY, TX, CG>::FXL, PIPE, NW, KT},
+static const TileCfg g_cfgs[] = {DFFW_TILE_CONFIGS(X_CFG) DFFW_TILE_CONFIGS_W8(X_CFG8) DFFW_TILE_CONFIGS_TEAM(X_CFGT)};
 #undef X_CFG
 #undef X_CFG8
+#undef X_CFGT
 
 int tile_cfg_count() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
 const TileCfg *tile_cfg_at(int i) { return (i >= 0 && i < tile_cfg_count()) ? &g_cfgs[i] : nullptr; }
 const TileCfg *tile_cfg_find(int geo, int nt, int cg, bool wide) {
     if (wide)
         for (const TileCfg &c : g_cfgs)
-            if (c.nw == 8 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
+            if (c.nw == 8 && c.kt <= 1 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
     for (const TileCfg &c : g_cfgs)
-        if (c.nw == 4 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
+        if (c.nw == 4 && c.kt <= 1 && c.geo == geo && c.nt == nt && c.cg == cg) return &c;
     return nullptr;
 }
 
 const TileCfg *tile_cfg_find_shape(int geo, int nt, int cg, int tz, int ty, int tx) {
     for (const TileCfg &c : g_cfgs)
-        if (c.nw == 4 && c.geo == geo && c.nt == nt && c.cg == cg && c.tz == tz && c.ty == ty && c.tx == tx) return &c;
+        if (c.nw == 4 && c.kt <= 1 && c.geo == geo && c.nt == nt && c.cg == cg && c.tz == tz && c.ty == ty && c.tx == tx) return &c;
     return nullptr;
 }
 
 const TileCfg *tile_cfg_find_like(const TileCfg *base, int nt) {
     for (const TileCfg &c : g_cfgs)
-        if (c.geo == base->geo && c.cg == base->cg && c.nt == nt && c.tz == base->tz && c.ty == base->ty && c.tx == base->tx && c.nw == base->nw) return &c;
+        if (c.kt <= 1 && c.geo == base->geo && c.cg == base->cg && c.nt == nt && c.tz == base->tz && c.ty == base->ty && c.tx == base->tx && c.nw == base->nw) return &c;
+    return nullptr;
+}
+
+// the team configuration that replaces a split-K launch of `base` over `nstage` channel-group stages: same geometry, channel group, output tiles per workgroup
+// and TY x TX (the pack and its tap offsets are those of `base`), ONE stage per team (a team that walks several stages re-fills its image between them, and every
+// such layer measured slower than its split-K launch pair); nullptr: none
+const TileCfg *tile_cfg_find_team(const TileCfg *base, int nstage, int nt) {
+    for (const TileCfg &c : g_cfgs)
+        if (c.kt == nstage && c.kt > 1 && c.geo == base->geo && c.cg == base->cg && c.nt == nt && c.ty == base->ty && c.tx == base->tx) return &c;
     return nullptr;
 }
 
@@ -914,9 +1039,9 @@ bool tile_lean(int prec, const TileCfg *c, const ConvArgs &a, const TileArgs &t)
 }
 
 void conv_tile_kernel_name(int prec, const TileCfg *c, bool splitk, bool lean, char *buf, int n) {
-    // exactly as rocprofv3 --kernel-trace prints the instantiation (all eleven template arguments)
-    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw,
-             splitk ? "true" : "false", lean ? "true" : "false");
+    // exactly as rocprofv3 --kernel-trace prints the instantiation (all twelve template arguments)
+    snprintf(buf, n, "dffw::conv_tile<%d, %d, %d, %d, %d, %d, %d, %d, %d, %s, %s, %d>", prec, c->geo, c->nt, c->tz, c->ty, c->tx, c->cg, c->pipe, c->nw,
+             splitk ? "true" : "false", lean ? "true" : "false", c->kt > 1 ? c->kt : 1);
 }
 
 #endif
@@ -937,6 +1062,12 @@ hipError_t launch_conv_tile_lean0(const TileCfg *cfg, const ConvArgs &a, const T
         break;
         DFFW_TILE_CONFIGS_W8(X_LAUNCH8)
 #undef X_LAUNCH8
+#define X_LAUNCHT(ID, GEO, NT, TZ, TY, TX, CG, PIPE, NW, KT)                                                              \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((conv_tile<P_BF16X3, GEO, NT, TZ, TY, TX, CG, PIPE, NW, false, true, KT>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.pass_split ? 4 : 1)), dim3(64 * NW * KT), 0, s, a, t); \
+        break;
+        DFFW_TILE_CONFIGS_TEAM(X_LAUNCHT)
+#undef X_LAUNCHT
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -963,6 +1094,12 @@ static hipError_t launch_conv_tile_p(const TileCfg *cfg, const ConvArgs &a, cons
         break;
         DFFW_TILE_CONFIGS_SPLITK(X_LAUNCHK)
 #undef X_LAUNCHK
+#define X_LAUNCHT(ID, GEO, NT, TZ, TY, TX, CG, PIPE, NW, KT)                                                              \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((conv_tile<PREC, GEO, NT, TZ, TY, TX, CG, PIPE, NW, false, false, KT>), dim3((unsigned)t.grid, (unsigned)t.nsplit, (unsigned)(t.pass_split ? 4 : 1)), dim3(64 * NW * KT), 0, s, a, t); \
+        break;
+        DFFW_TILE_CONFIGS_TEAM(X_LAUNCHT)
+#undef X_LAUNCHT
         // the row-sums variant of the per-slice 1x3x3 configurations the alignment heads' third conv runs on
         case 3000 + 34:
             hipLaunchKernelGGL((conv_tile<PREC, G2S1, 2, 5, 4, 16, 32, 1, 4, true>), dim3((unsigned)t.grid, 1, 1), dim3(256), 0, s, a, t);

@@ -1332,7 +1332,7 @@ static bool getenv_flag(const char *name) {
     X(NO_CONCURRENT) X(NO_CONF_FORK) X(NO_FUSED_ATTENTION) X(NO_FUSED_EFD) X(NO_FUSED_OF) X(NO_FUSED_POOL) X(NO_FUSED_SRD) \
     X(NO_FUSED_STEM) X(NO_HEAD_SPLIT) X(NO_ROLL) X(NO_ROLL_S2) X(NO_SPLIT) X(NO_SPLITK)  \
     X(NO_STEM_PAIR) X(NO_TILE) X(NO_SMALL) X(NO_ROLL_S2_WIDE) X(NO_HEAD_SUMS) X(NO_HEAD_SUMS_FUSED) X(NO_HEAD_WARP) X(NO_OF_FIRST) \
-    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_ROLLK) X(NO_ROLLT) X(NO_SLICE32) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
+    X(NO_LEAN_TILE) X(NO_LEAN_ROLL) X(NO_ROLLX) X(NO_ROLLK) X(NO_ROLLT) X(NO_TEAMS) X(NO_SLICE32) X(NO_REGRESS_FUSED) X(NO_STEM_PIPE) X(NO_POOL3) X(NO_NARROW)
 enum SwitchId {
 #define X_ID(n) SW_##n,
     DFFW_SWITCHES(X_ID)
@@ -1351,7 +1351,7 @@ static void warn_unknown_switches() {
 #undef X_NM
         "DFFW_ROLL_WGS", "DFFW_SRD_WGS", "DFFW_SMALL_MAX_UNITS", "DFFW_ROLL_ZSPLIT", "DFFW_KSPLIT_TARGET", "DFFW_SPLIT_S64", "DFFW_SPLIT_T64", "DFFW_NARROW_MAX",
         "DFFW_WARM_MAX_WGS", "DFFW_ROLLK_MERGE_BELOW", "DFFW_ROLLT_MIN_UNITS", "DFFW_ROLL_MIN_UNITS", "DFFW_SPLIT_WG", "DFFW_DEBUG_FLAGS", "DFFW_CONCURRENT_MAX_PIXELS",
-        "DFFW_SRD_PIPE", "DFFW_TRACE_LAYER", "DFFW_TRACE_OUT", "DFFW_NO_STEM_PAIR", "DFFW_RCCL_LIB", "DFFW_LIB_PATH", "DFFW_NO_PROBE", "DFFW_PRECISION",
+        "DFFW_SRD_PIPE", "DFFW_REDIR_SIDE", "DFFW_TEAM_MIN_WGS", "DFFW_TEAM_MAX_WGS", "DFFW_CONCURRENT_MIN_PIXELS", "DFFW_TRACE_LAYER", "DFFW_TRACE_OUT", "DFFW_NO_STEM_PAIR", "DFFW_RCCL_LIB", "DFFW_LIB_PATH", "DFFW_NO_PROBE", "DFFW_PRECISION",
         "DFFW_BENCH_ONE_DEVICE", "DFFW_BENCH_TIMEOUT_S",
         // development builds only (make ABL=1 / TRACE=1)
         "DFFW_SRD_ABL", "DFFW_ROLLX_ABL", "DFFW_ROLLX_NTS", "DFFW_ROLLK_ABL", "DFFW_ROLLK_SKEW"};
@@ -1367,9 +1367,10 @@ static void warn_unknown_switches() {
 
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, rollk_merge_below = 1 << 30, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, rollk_merge_below = 1 << 30, redir_side = 1, team_min_wgs = 0, team_max_wgs = 320, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
     bool srd_pipe = false;   // DFFW_SRD_PIPE=1: the 16-channel SRD block on srd_pipe16 (one barrier per step) instead of srd_roll16
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
+    int64_t concurrent_min_pixels = 400000;   // below: one stream (a 5x224x224 stack, 0.25M: 0.799 -> 0.785 ms on one stream; 10x256x256, 0.66M: 0.915 -> 0.905 on three)
     const char *trace_layer = nullptr, *trace_out = nullptr;
     bool on(int id) const { return f[id]; }
     // the switches the kernel launchers consult, as ConvArgs::dbg bits (so that no launcher calls getenv)
@@ -1390,6 +1391,9 @@ struct Switches {
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
+        s.redir_side = geti("DFFW_REDIR_SIDE", 0, 1);
+        s.team_min_wgs = geti("DFFW_TEAM_MIN_WGS", 0, 0);
+        s.team_max_wgs = geti("DFFW_TEAM_MAX_WGS", 1, 320);
         s.split_s64 = geti("DFFW_SPLIT_S64", 1, 1025);   // ... and a stride-1 3x3x3 layer with 64 outputs (End_to_End dres16_* at batch 8: 0.093 -> 0.076 ms on two 2-tile workgroups per tile; 257 = round 4)
         s.split_t64 = geti("DFFW_SPLIT_T64", 1, 1025);   // tile count below which a transposed layer with 64 outputs splits its output channels (257 = round 4)
         s.narrow_max = geti("DFFW_NARROW_MAX", 1, 40);   // widest grid that may take the 5 x 8 x 8 block when its own block leaves the chip short of workgroups (8 = round 4)
@@ -1408,6 +1412,7 @@ struct Switches {
         { const char *z = getenv("DFFW_SPLIT_WG"); s.split_wg = z ? atoi(z) : 256; }   // measured best of 64/128/256/512 at batch 1, 4, 8
         { const char *z = getenv("DFFW_DEBUG_FLAGS"); s.debug_flags = z ? atoi(z) : 0; }
         { const char *z = getenv("DFFW_CONCURRENT_MAX_PIXELS"); s.concurrent_max_pixels = z ? atoll(z) : -1; }
+        { const char *z = getenv("DFFW_CONCURRENT_MIN_PIXELS"); if (z) s.concurrent_min_pixels = atoll(z); }
         s.srd_pipe = getenv_flag("DFFW_SRD_PIPE");
         warn_unknown_switches();
         s.trace_layer = getenv("DFFW_TRACE_LAYER");
@@ -2119,12 +2124,50 @@ struct Run {
             // transposed conv on few tiles: its 4 sub-pixel passes as 4 workgroups (no reduction, any epilogue)
             const int thr = sw.split_wg;
             t.pass_split = (L.transposed && t.total_tiles * t.nsplit <= thr && !sw.on(SW_NO_SPLITK)) ? 1 : 0;
+            if (t.pass_split && tp.nstage >= 2 && !sw.on(SW_NO_TEAMS)) {
+                // a transposed layer whose passes are workgroups of their own walks its 2-4 channel-group stages one after the other (SPP conv8 at batch 1:
+                // 30 us): one stage per team instead, with as few output-channel workgroups per tile as keep the launch to one round of workgroups
+                for (int nts = cfg->nt; nts <= pc.nt && nts <= 2; nts *= 2) {
+                    const TileCfg *team = tile_cfg_find_team(cfg, tp.nstage, nts);
+                    if (!team) continue;
+                    const int tz_t = (a.Ng + team->tz - 1) / team->tz, ty_t = (a.Hg + team->ty - 1) / team->ty, tx_t = (a.Wg + team->tx - 1) / team->tx;
+                    const int64_t wgs = (int64_t)a.B * tz_t * ty_t * tx_t * (pc.nt / nts) * 4;
+                    if (wgs > sw.team_max_wgs) continue;
+                    cfg = team;
+                    t.nsplit = pc.nt / nts;
+                    t.tiles_z = tz_t; t.tiles_y = ty_t; t.tiles_x = tx_t;
+                    t.total_tiles = a.B * tz_t * ty_t * tx_t;
+                    t.grid = 8 * ((t.total_tiles + 7) / 8);
+                    t.warm = (t.total_tiles * t.nsplit <= sw.warm_max_wgs) ? 1 : 0;
+                    break;
+                }
+            }
             if (!t.pass_split && tile_cfg_has_splitk(cfg) && t.total_tiles * t.nsplit <= thr * 3 / 4 && tp.nstage >= 2 && !o.cls && !o.out_pre && !o.outf && !o.discard && !o.res_bcast && L.cout % 4 == 0 &&
                 !sw.on(SW_NO_SPLITK)) {
                 // enough splits for ~two workgroups per CU (measured 256 ... 768 at batch 1 / 4 and on one End_to_End stack: 512 is 3-4 %
                 // faster than the earlier floor(256 / n), which left 129 ... 192-workgroup launches unsplit)
                 const int want = (sw.ksplit_target + t.total_tiles * t.nsplit - 1) / (t.total_tiles * t.nsplit);
                 t.ksplit = std::max(1, std::min(std::min(tp.nstage, want), 8));
+                // the same split INSIDE the workgroup where a team configuration covers it (round 6): the teams' partial sums meet in LDS, no partials through
+                // memory and no splitk_finish launch (5-6 us each behind 28 of a batch-1 forward's 89 launches)
+                const TileCfg *team = (t.ksplit > 1 && !sw.on(SW_NO_TEAMS)) ? tile_cfg_find_team(cfg, tp.nstage, cfg->nt) : nullptr;
+                if (team) {
+                    // ... unless the team launch needs several rounds of workgroups (their LDS images allow one or two per CU, and next to the other streams'
+                    // kernels they take whole CUs): measured per layer at batch 1 / 2 / 4, profiles/r06_batch1_teams.txt
+                    const int tz_t = (a.Ng + team->tz - 1) / team->tz;
+                    const int64_t wgs = (int64_t)a.B * tz_t * ((a.Hg + team->ty - 1) / team->ty) * ((a.Wg + team->tx - 1) / team->tx) * t.nsplit;
+                    if (wgs < sw.team_min_wgs || wgs > sw.team_max_wgs) team = nullptr;
+                }
+                if (team) {
+                    cfg = team;
+                    t.ksplit = 1;
+                    t.tiles_z = (a.Ng + cfg->tz - 1) / cfg->tz;
+                    t.tiles_y = (a.Hg + cfg->ty - 1) / cfg->ty;
+                    t.tiles_x = (a.Wg + cfg->tx - 1) / cfg->tx;
+                    t.total_tiles = a.B * t.tiles_z * t.tiles_y * t.tiles_x;
+                    t.grid = 8 * ((t.total_tiles + 7) / 8);
+                    t.warm = (t.total_tiles * t.nsplit <= sw.warm_max_wgs) ? 1 : 0;
+                }
                 if (t.ksplit > 1) {
                     t.partial_stride = M_out * (int64_t)pc.nt * 16;
                     partial = (float *)raw(t.ksplit * t.partial_stride * (int64_t)sizeof(float));
@@ -2172,8 +2215,10 @@ struct Run {
             if (t.ksplit > 1) {
                 prof_begin("dffw::splitk_finish_kernel", name + " (split-K finish)", 0.0,
                            (double)M_out * L.cout * (4.0 * t.ksplit + elem_bytes() * (o.res0 ? 2 : 1)));
+#ifndef DFFW_EXP_SKIP_FINISH   // (dev-only timing bound, tools/build_variant_lib.sh: what a split-K without its finish launch could save at most; results are garbage)
                 check(launch_splitk_finish(e->prec, partial, t.ksplit, t.partial_stride, M_out, pc.nt * 16, L.cout, pc.bias, a.res0,
                                            o.relu, out.p, s), "splitk_finish");
+#endif
                 prof_end();
                 drop_raw(partial);
             }
@@ -2527,9 +2572,12 @@ static Act pyramid(Run &r, const std::string &S, const Act &v3) {
     r.release_deferred();
     // redir1 / redir2 (1x1x1 conv + BN of x_8 / of conv2's output, DEN.py:209-210,234-237) only feed the residual inputs of conv9 / conv8: they run on the
     // side streams next to the chain conv1 ... conv4 instead of between its launches (two small gather-GEMM launches off the critical path)
-    r.forked = r.concurrent;
-    r.fork(0);
-    r.on(0);
+    const bool redir_side = r.concurrent && r.sw.redir_side != 0;
+    r.forked = redir_side;
+    if (redir_side) {
+        r.fork(0);
+        r.on(0);
+    }
     Act rd1 = r.conv(S + ".redir1.0", s8);
     r.on(-1);
     Act d1 = r.conv(S + ".conv1", s8);
@@ -2539,8 +2587,10 @@ static Act pyramid(Run &r, const std::string &S, const Act &v3) {
     r.drop(d1); r.drop(s16);
     Act c2 = r.conv(S + ".conv2.0.0", m1, rl);
     r.drop(m1);
-    r.fork(1);
-    r.on(1);
+    if (redir_side) {
+        r.fork(1);
+        r.on(1);
+    }
     Act rd2 = r.conv(S + ".redir2.0", c2);
     r.on(-1);
     Act d2 = r.conv(S + ".conv3", c2);
@@ -2550,11 +2600,11 @@ static Act pyramid(Run &r, const std::string &S, const Act &v3) {
     r.drop(d2); r.drop(s32);
     Act c4 = r.conv(S + ".conv4.0.0", m2, rl);
     r.drop(m2);
-    r.join(1);
+    if (redir_side) r.join(1);
     ConvOpt u8o = rl; u8o.res0 = &rd2;
     Act u8 = r.conv(S + ".conv8.0", c4, u8o);
     r.drop(c4); r.drop(rd2);
-    r.join(0);
+    if (redir_side) r.join(0);
     ConvOpt u9o = rl; u9o.res0 = &rd1;
     Act u9 = r.conv(S + ".conv9.0", u8, u9o);
     r.drop(u8); r.drop(rd1);
@@ -2646,7 +2696,8 @@ static int run_depth(Run &r, const float *FS, const float *fd, const int64_t fst
     {
         const int64_t z = r.sw.concurrent_max_pixels;
         // (not in profiling mode: the per-launch event durations are meant to be each kernel's own)
-        if ((z < 0 || (int64_t)B * N * H * W < z) && !r.sw.on(SW_NO_CONCURRENT) && !r.e->profiling) r.enable_concurrency();
+        const int64_t px = (int64_t)B * N * H * W;
+        if ((z < 0 || px < z) && px >= r.sw.concurrent_min_pixels && !r.sw.on(SW_NO_CONCURRENT) && !r.e->profiling) r.enable_concurrency();
     }
 
     // feature extraction: V1 (8ch, full), V2 (16ch, 1/2), V3 (32ch, 1/4)            DEN.py:77-80

@@ -1948,6 +1948,9 @@ __global__ __launch_bounds__(256) void of_roll_kernel(const SrdArgs a) {
 // w = output rows 2w, 2w+1; CF = 16: 8 waves, wave w = row w, two 16-channel output tiles; K octet g of chunk k = o = 4k + g ->
 // (tap o / OCT, channel octet o % OCT), OCT = CF / 8 + 1; filter resident in LDS) and the epilogue (+ ref, held in registers for all
 // slices of the column, ReLU, split, 16-byte stores) follow after one barrier.  Plain loads only (no LDS-DMA): hipcc counts every wait.
+#ifndef DFFW_HW_ABL
+#define DFFW_HW_ABL 0   // dev-only ablations (tools/build_variant_lib.sh): 1 no corner loads, 2 no output stores, 4 no MFMAs, 8 no blend
+#endif
 template <int PREC, int CF>
 __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_per_eu(4))) void head_warp_kernel(const HeadWarpArgs a) {
     constexpr int PARTS = Fmt<PREC>::PARTS;
@@ -2015,14 +2018,17 @@ __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_pe
             wgt[k] = ok ? wx[k & 1] * wy[k >> 1] : 0.f;
             const uint16_t *rp = slice + (ok ? (yc * a.W + xc) * frec : 0);
 #pragma unroll
-            for (int i = 0; i < PARTS; ++i) q[k][i] = *reinterpret_cast<const uint4 *>(rp + i * CF);
+            for (int i = 0; i < PARTS; ++i) {
+                if constexpr (DFFW_HW_ABL & 1) q[k][i] = make_uint4(ix, iy, n, k);
+                else q[k][i] = *reinterpret_cast<const uint4 *>(rp + i * CF);
+            }
         }
     };
     auto land = [&](int slot) {     // blend the corners requested by the last issue(), write the octet (octet-0 threads: also the flow record)
         if (!gth) return;
         unsigned char *dst = smem + slot * SLOTB + gp * PIXB;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (pin) {
+        if (pin && !(DFFW_HW_ABL & 8)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (wgt[k] == 0.f) continue;      // corner outside the image (or weight exactly 0): skipped, as warp_octet skips it
@@ -2108,6 +2114,10 @@ __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_pe
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const short8 wh = *reinterpret_cast<const short8 *>(wl + ((k * NT + nt) * PARTS) * 1024);
+                        if constexpr (DFFW_HW_ABL & 4) {
+                            acc[nt][0] += __builtin_bit_cast(float, (int)xh[0] + (int)xl[1] + (int)wh[0]);
+                            continue;
+                        }
                         if constexpr (PARTS == 2) {
                             const short8 wlo = *reinterpret_cast<const short8 *>(wl + ((k * NT + nt) * PARTS + 1) * 1024);
                             acc[nt] = mma<F16>(wlo, xh, acc[nt]);
@@ -2123,6 +2133,7 @@ __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_pe
                     uint32_t h01, h23, l01, l23;
                     Fmt<PREC>::split2(relu_bits(acc[nt][0]), relu_bits(acc[nt][1]), h01, l01);
                     Fmt<PREC>::split2(relu_bits(acc[nt][2]), relu_bits(acc[nt][3]), h23, l23);
+                    if ((DFFW_HW_ABL & 2) && h01 != 0x12345u) continue;
                     if constexpr (PARTS == 2) {
                         swap16(h01, l01);
                         swap16(h23, l23);

@@ -159,6 +159,79 @@ def test_conv_small_grids(eng, case, prec, monkeypatch):
     assert rel(got, alt) <= TOL[prec] * 0.2
 
 
+TEAM_CASES = [
+    # name, Cin, Cout, stride, B, N, H, W, residual, teams
+    ("dres8_32_32", 32, 32, 1, 1, 10, 32, 32, False, 2),        # two 16-channel stages, one per team
+    ("dres8_32_32_res_n5", 32, 32, 1, 1, 5, 28, 28, True, 2),   # BASELINE config 2's grid: edge tiles in y and x
+    ("dres16_64_64", 64, 64, 1, 1, 10, 16, 16, True, 4),        # four stages, four teams
+    ("dres32_64_64_b2_n3", 64, 64, 1, 2, 3, 8, 8, False, 4),    # an 8 x 8 grid: half of every operand tile outside it
+    ("dres0_32_64", 32, 64, 1, 1, 10, 32, 32, False, 2),        # 64 outputs: four output-channel workgroups per tile
+    ("conv1_s2_32_64", 32, 64, 2, 1, 10, 32, 32, False, 4),     # stride (1,2,2): four 8-channel stages
+    ("conv_s2_16_32_b2_n3", 16, 32, 2, 2, 3, 32, 64, False, 2),
+    ("conv_s2_16_16_res", 16, 16, 2, 1, 5, 56, 56, True, 2),
+]
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("case", TEAM_CASES, ids=lambda c: c[0])
+def test_conv_tile_teams(eng, case, prec, monkeypatch):
+    """conv_tile's team configurations (round 6; dffw_conv_tile.hip, template argument KT): the few-tile layers of a batch-1 forward -- the 1/8 ... 1/32-resolution
+    pyramid and hourglass layers (DEN.py:212-238, 265-284) -- split their contraction depth over KT teams of four waves INSIDE the workgroup and add the teams'
+    accumulators up in LDS, instead of a split-K launch that leaves fp32 partials in memory for a splitk_finish launch.  3x3x3 at stride 1 and (1,2,2), 32 ... 128
+    channels, whole and edge tiles, slice counts 3 / 5 / 10, residual + ReLU; against F.conv3d, against the split-K launch pair (DFFW_NO_TEAMS: only the order of
+    the fp32 sums differs) and bitwise against a second run."""
+    name, cin, cout, stride, B, N, H, W, residual, kt = case
+    x = rnd(B, cin, N, H, W, seed=61)
+    w = rnd(cout, cin, 3, 3, 3, seed=62, scale=(2.0 / (cin * 27)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 63)
+    ref = ref_bn(F.conv3d(x, w, None, (1, stride, stride), 1), bn)
+    res = rnd(*ref.shape, seed=64) if residual else None
+    ref = F.relu(ref + res) if residual else F.relu(ref)
+    kw = dict(stride=(1, stride, stride), pad=1, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "100000")   # (the rolling kernels take some of these shapes at this size: not under test here)
+    monkeypatch.setenv("DFFW_TEAM_MAX_WGS", "100000")     # (the engine keeps split-K for launches of more than 320 team workgroups)
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    kn = eng.last_conv_kernel()
+    assert kn.startswith("dffw::conv_tile<") and kn.endswith(", %d>" % kt), kn   # (last template argument: teams per workgroup)
+    assert rel(got, ref) <= TOL[prec], (name, rel(got, ref))
+    again = eng.op_conv3d(x.cuda(), w, **kw)
+    assert torch.equal(got, again)
+    monkeypatch.setenv("DFFW_NO_TEAMS", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    kn = eng.last_conv_kernel()
+    assert kn.startswith("dffw::conv_tile<") and kn.endswith(", true, false, 1>"), kn   # the split-K instantiation
+    assert rel(alt, ref) <= TOL[prec]
+    assert rel(got, alt) <= TOL[prec] * 0.1, rel(got, alt)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
+@pytest.mark.parametrize("cin,cout,B,N,H,W,residual,kt", [(128, 64, 1, 10, 8, 8, True, 4), (64, 32, 1, 10, 16, 16, True, 2), (128, 64, 1, 5, 14, 14, False, 4),
+                                                          (64, 64, 2, 3, 12, 20, False, 2)])
+def test_conv_tile_teams_transposed(eng, cin, cout, B, N, H, W, residual, kt, prec, monkeypatch):
+    """The transposed 3x3x3 convs of the few-tile regime (SPP `conv8` 128 -> 64 on the 8 x 8 grid, `conv9` 64 -> 32 on 16 x 16 at batch 1, DEN.py:228-238): their four
+    sub-pixel passes are workgroups of their own (grid.z) and each workgroup's 32-channel stages one team each (conv_tile's KT, round 6) instead of a walk over
+    the stages.  Against F.conv_transpose3d, against the walk (DFFW_NO_TEAMS), and bitwise against a second run."""
+    x = rnd(B, cin, N, H, W, seed=71)
+    w = rnd(cin, cout, 3, 3, 3, seed=72, scale=(2.0 / (cin * 27 / 4)) ** 0.5 * 1.7)
+    bn = bn_params(cout, 73)
+    ref = ref_bn(F.conv_transpose3d(x, w, None, (1, 2, 2), 1, (0, 1, 1)), bn)
+    res = rnd(*ref.shape, seed=74) if residual else None
+    ref = F.relu(ref + res) if residual else F.relu(ref)
+    kw = dict(stride=(1, 2, 2), pad=1, transposed=True, bn=bn, residual=res.cuda() if residual else None, relu=1, precision=prec)
+    monkeypatch.setenv("DFFW_ROLL_MIN_UNITS", "100000")
+    monkeypatch.setenv("DFFW_ROLLT_MIN_UNITS", "100000")
+    got = eng.op_conv3d(x.cuda(), w, **kw)
+    kn = eng.last_conv_kernel()
+    assert kn.startswith("dffw::conv_tile<0, 2," if prec == "bf16x3" else "dffw::conv_tile<") and kn.endswith(", %d>" % kt), kn
+    assert rel(got, ref) <= TOL[prec], rel(got, ref)
+    assert torch.equal(got, eng.op_conv3d(x.cuda(), w, **kw))
+    monkeypatch.setenv("DFFW_NO_TEAMS", "1")
+    alt = eng.op_conv3d(x.cuda(), w, **kw)
+    assert eng.last_conv_kernel().endswith(", 1>"), eng.last_conv_kernel()
+    assert rel(alt, ref) <= TOL[prec]
+    assert rel(got, alt) <= TOL[prec] * 0.1, rel(got, alt)
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("cout,N,H,W,zsplit,residual,wgs", [(8, 10, 128, 128, 1, True, 0), (16, 5, 128, 128, 1, False, 24), (8, 1, 64, 256, 1, False, 8),
                                                              (16, 10, 64, 256, 2, True, 40), (16, 7, 128, 128, 3, False, 0), (8, 2, 128, 128, 2, True, 16),
