@@ -1367,7 +1367,7 @@ static void warn_unknown_switches() {
 
 struct Switches {
     bool f[SW_COUNT];
-    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, rollk_merge_below = 1 << 30, redir_side = 1, team_min_wgs = 0, team_max_wgs = 320, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
+    int roll_wgs = 0, roll_zsplit = 0, srd_wgs = 0, split_wg = 256, debug_flags = 0, small_max_units = 0, roll_min_units = 192, rollt_min_units = 128, rollk_merge_below = 1 << 30, redir_side = -1, team_min_wgs = 0, team_max_wgs = 320, ksplit_target = 512, warm_max_wgs = 1024, narrow_max = 40, split_t64 = 1025, split_s64 = 1025;
     bool srd_pipe = false;   // DFFW_SRD_PIPE=1: the 16-channel SRD block on srd_pipe16 (one barrier per step) instead of srd_roll16
     int64_t concurrent_max_pixels = -1;   // < 0: no limit
     int64_t concurrent_min_pixels = 400000;   // below: one stream (a 5x224x224 stack, 0.25M: 0.799 -> 0.785 ms on one stream; 10x256x256, 0.66M: 0.915 -> 0.905 on three)
@@ -1391,7 +1391,7 @@ struct Switches {
                                                                   // batch-1 call then differs from the same stack inside a batch by 1.5e-5: off)
         s.roll_zsplit = geti("DFFW_ROLL_ZSPLIT", 1, 0);
         s.ksplit_target = geti("DFFW_KSPLIT_TARGET", 1, 512);
-        s.redir_side = geti("DFFW_REDIR_SIDE", 0, 1);
+        s.redir_side = geti("DFFW_REDIR_SIDE", 0, -1);   // redir1 / redir2 on the side streams: 1 always, 0 never, unset: from 2M stack pixels
         s.team_min_wgs = geti("DFFW_TEAM_MIN_WGS", 0, 0);
         s.team_max_wgs = geti("DFFW_TEAM_MAX_WGS", 1, 320);
         s.split_s64 = geti("DFFW_SPLIT_S64", 1, 1025);   // ... and a stride-1 3x3x3 layer with 64 outputs (End_to_End dres16_* at batch 8: 0.093 -> 0.076 ms on two 2-tile workgroups per tile; 257 = round 4)
@@ -2555,6 +2555,8 @@ static Act pyramid(Run &r, const std::string &S, const Act &v3) {
     }
     // the three scales are independent chains of 4 convs (DEN.py:216-223): side by side when concurrency is on
     r.forked = r.concurrent;
+    // (one hipEventRecord per side stream: with ONE event that both side streams wait for the batch-1 forward is 80 us SLOWER, 0.877 -> 0.958 ms; and
+    // chaining the joins -- side 1 waits for side 0, the main stream for side 1 -- costs as much: profiles/r06_batch1_teams.txt)
     r.fork(0);
     r.fork(1);
     Act s8 = pyramid_scale(r, S, "8", p8);
@@ -2572,7 +2574,9 @@ static Act pyramid(Run &r, const std::string &S, const Act &v3) {
     r.release_deferred();
     // redir1 / redir2 (1x1x1 conv + BN of x_8 / of conv2's output, DEN.py:209-210,234-237) only feed the residual inputs of conv9 / conv8: they run on the
     // side streams next to the chain conv1 ... conv4 instead of between its launches (two small gather-GEMM launches off the critical path)
-    const bool redir_side = r.concurrent && r.sw.redir_side != 0;
+    // (below 2M stack pixels -- batch 1 and 2 of 10x256x256 -- in line: a fork and a join hold the main queue for ~6 us each, the launch itself is 7-9 us:
+    // 0.877 -> 0.870 ms at batch 1, 1.122 -> 1.118 at batch 2; from batch 4 up the side streams win by 0.3-0.7 %)
+    const bool redir_side = r.concurrent && (r.sw.redir_side == 1 || (r.sw.redir_side < 0 && (int64_t)v3.B * v3.N * v3.H * v3.W * 16 >= (2 << 20)));
     r.forked = redir_side;
     if (redir_side) {
         r.fork(0);
