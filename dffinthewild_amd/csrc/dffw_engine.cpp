@@ -2989,7 +2989,7 @@ static int run_e2e(Run &r, const float *FS, const float *fd, const int64_t fst[4
             auto ccur = r.e->convs.find(hp + ".0.0#cur");
             const bool roll = (fe.C == 8 || fe.C == 16) && ccur != r.e->convs.end() && ccur->second.wsrd && ccur->second.def.cin == fe.C + 2 &&
                               ccur->second.def.cout == 2 * fe.C && fe.H % 8 == 0 &&
-                              fe.W % 16 == 0 && (int64_t)B * (fe.H / 8) * (fe.W / 16) >= r.sw.roll_min_units && !r.sw.on(SW_NO_HEAD_WARP) && !r.sw.on(SW_NO_TILE);
+                              fe.W % 16 == 0 && (int64_t)B * (fe.H / 8) * (fe.W / 16) >= r.sw.roll_min_units && (int64_t)B * N <= head_warp_max_planes() && !r.sw.on(SW_NO_HEAD_WARP) && !r.sw.on(SW_NO_TILE);
             Act vol;
             if (!roll) vol = r.act(B, N, fe.H, fe.W, fe.C + 8);
             if (r.ok() && !r.dry) {

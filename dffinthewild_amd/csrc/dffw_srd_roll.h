@@ -67,6 +67,7 @@ struct HeadWarpArgs {
     int wgs;                  // workgroups to launch (0: default)
 };
 constexpr int head_warp_chunks(int cf) { return (9 * (cf / 8 + 1) + 3) / 4; }
+constexpr int head_warp_max_planes() { return 320; }   // B N: the kernel keeps every plane's three warp parameters in LDS (launch_head_warp rejects more)
 hipError_t launch_head_warp(int prec, int cf, const HeadWarpArgs &a, hipStream_t s);
 void head_warp_kernel_name(int prec, int cf, char *buf, int n);
 // ... and the 8 -> 8 channel blocks (pixel-pair form): a.w0 = conv.0 as 3 pair-form chunks, a.w2 = conv.2 as 3 chunks + 1 shortcut chunk

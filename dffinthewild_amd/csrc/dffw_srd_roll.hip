@@ -1961,8 +1961,13 @@ __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_pe
     constexpr int PIXB = OCT * 16, PLANEB = XPIX * PIXB, SLOTB = PARTS * PLANEB;
     constexpr int NCH = (9 * OCT + 3) / 4, TB = TY / NWAVES;
     constexpr int W_OFF = 2 * SLOTB, WB = NCH * NT * PARTS * 1024;   // the filter: [chunk][output tile][part][64 lanes][16 bytes]
+    // the warp parameters of every (sample, slice): (alpha0 + fov, alpha1, alpha2), read from LDS in issue().  As global loads (wave-uniform addresses, but
+    // hipcc issues vector loads for them) every step waited vmcnt(0) for them -- with the previous step's result stores in the same queue: a store
+    // acknowledgement per step on the critical path (with every load, store, MFMA and blend taken out the kernel still ran 0.51 of its 0.73 ms:
+    // profiles/r06_head_warp.txt).  B N <= head_warp_max_planes(); the engine keeps the two-launch form beyond.
+    constexpr int PRM_OFF = W_OFF + WB, PRM_MAX = head_warp_max_planes();
     static_assert(XPIX * GO <= NTHR, "one gather item per thread");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[W_OFF + WB];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PRM_OFF + PRM_MAX * 12];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r = lane & 15;
@@ -1989,6 +1994,14 @@ __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_pe
     };
     const int rec = PARTS * C, frec = PARTS * CF;
     for (int i = tid; i < WB / 16; i += NTHR) reinterpret_cast<uint4 *>(smem + W_OFF)[i] = reinterpret_cast<const uint4 *>(a.w)[i];
+    float *prm = reinterpret_cast<float *>(smem + PRM_OFF);
+    for (int i = tid; i < a.B * a.N; i += NTHR) {
+        const int b = i / a.N, n = i - b * a.N;
+        prm[i * 3 + 0] = a.alpha[b * 3 * a.N + n] + a.fov[i];
+        prm[i * 3 + 1] = a.alpha[b * 3 * a.N + a.N + n];
+        prm[i * 3 + 2] = a.alpha[b * 3 * a.N + 2 * a.N + n];
+    }
+    __syncthreads();
 
     // ---- gather side: thread t < 180 * GO owns channel octet t / 180 of footprint pixel t % 180 ---------------------
     const bool gth = tid < XPIX * GO;
@@ -2001,9 +2014,8 @@ __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_pe
         const int iy = U.gy0 - 1 + fy, ix = U.gx0 - 1 + fx;
         pin = gth && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         if (!pin) return;
-        const int ai = U.b * 3 * a.N + n;
-        const float f = a.alpha[ai] + a.fov[U.b * a.N + n];
-        const WarpPoint wp = warp_point(ix, iy, a.H, a.W, f, a.alpha[ai + a.N], a.alpha[ai + 2 * a.N]);
+        const int pi = (U.b * a.N + n) * 3;
+        const WarpPoint wp = warp_point(ix, iy, a.H, a.W, prm[pi], prm[pi + 1], prm[pi + 2]);
         flx = wp.fx;
         fly = wp.fy;
         const float x0f = floorf(wp.sx), y0f = floorf(wp.sy);
@@ -2152,6 +2164,7 @@ __global__ __launch_bounds__(CF == 8 ? 256 : 512) __attribute__((amdgpu_waves_pe
 void head_warp_kernel_name(int prec, int cf, char *buf, int n) { snprintf(buf, n, "dffw::head_warp_kernel<%d, %d>", prec, cf); }
 
 hipError_t launch_head_warp(int prec, int cf, const HeadWarpArgs &a, hipStream_t s) {
+    if ((int64_t)a.B * a.N > head_warp_max_planes()) return hipErrorInvalidValue;
     const int want = a.wgs > 0 ? a.wgs : (cf == 8 ? 1024 : 512);
     const int per_xcd = (a.total_tiles + 7) / 8;
     const dim3 grid((unsigned)(8 * std::min(per_xcd, std::max(1, want / 8))));

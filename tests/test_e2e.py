@@ -234,7 +234,7 @@ def test_hip_e2e_batch_is_per_sample(lib_built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_HEAD_SUMS_FUSED", "DFFW_NO_HEAD_WARP", "DFFW_NO_SLICE32"])
+@pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_HEAD_SPLIT", "DFFW_NO_SPLITK", "DFFW_NO_HEAD_SUMS", "DFFW_NO_HEAD_SUMS_FUSED", "DFFW_NO_HEAD_WARP", "DFFW_NO_SLICE32", "DFFW_NO_TEAMS"])
 def test_hip_e2e_fallback_kernels_keep_parity(lib_built, monkeypatch, env):
     """The gather kernel (no LDS tiles), the unsplit alignment heads (reference slice carried in every slice's volume
     instead of entering as a slice-broadcast residual), the unsplit few-tile launches and the heads' last conv + plane mean as

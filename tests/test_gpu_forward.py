@@ -428,14 +428,14 @@ def test_lean_epilogue_and_merged_heads_are_bit_identical(lib_built, which, monk
 
 @pytest.mark.parametrize("env", ["DFFW_NO_TILE", "DFFW_NO_CONCURRENT", "DFFW_NO_CONF_FORK", "DFFW_NO_SMALL", "DFFW_NO_SPLIT", "DFFW_NO_FUSED_ATTENTION", "DFFW_NO_FUSED_POOL",
                                  "DFFW_NO_FUSED_STEM", "DFFW_NO_SPLITK", "DFFW_NO_ROLL", "DFFW_NO_FUSED_SRD", "DFFW_NO_FUSED_EFD", "DFFW_NO_STEM_PAIR",
-                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_ROLLT", "DFFW_SRD_PIPE", "DFFW_NO_SLICE32", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE",
+                                 "DFFW_NO_LEAN_TILE", "DFFW_NO_LEAN_ROLL", "DFFW_NO_ROLLX", "DFFW_NO_ROLLK", "DFFW_NO_ROLLT", "DFFW_NO_TEAMS", "DFFW_SRD_PIPE", "DFFW_NO_SLICE32", "DFFW_NO_NARROW", "DFFW_NO_ROLL_S2_WIDE",
                                  "DFFW_ROLLK_MERGE_BELOW"])
 @pytest.mark.parametrize("which", ["batch2_bcast", "he_n10_64", "full_10x256"])
 def test_alternative_kernel_paths_keep_parity(lib_built, env, which, monkeypatch):
     """Every kernel path that can serve a layer must give the reference's answer: the gather fallback
     (conv_igemm, DFFW_NO_TILE), the un-split
     few-tile launches, the unfused attention convs / pooling, conv_tile on its generic epilogue (DFFW_NO_LEAN_TILE), conv_tile instead of
-    the K-split rolling window (DFFW_NO_ROLLK).  (Round 5 retired the switches whose alternative had lost every A/B for two rounds or more:
+    the K-split rolling window (DFFW_NO_ROLLK), split-K launch pairs instead of conv_tile's teams (DFFW_NO_TEAMS).  (Round 5 retired the switches whose alternative had lost every A/B for two rounds or more:
     DFFW_NO_CG32, DFFW_NO_WIDE, DFFW_NO_REGRESS_MERGE and the untested pack-time ones.)"""
     path = [p for p in GOLDEN if which in p][0]
     g, meta, FS, fd, sd = case(path)
