@@ -190,6 +190,28 @@ def test_oracle_parity_fresh_inputs_and_batch_independence(lib_built):
     assert cpu_ref.rel_l2(single[3].cpu(), got[3][2:].cpu()) <= 1e-6     # batch independent (bitwise in practice)
 
 
+@pytest.mark.parametrize("B,N,H,W,seed", [(1, 7, 96, 160, 11), (2, 3, 192, 128, 12), (5, 4, 64, 96, 13), (3, 10, 160, 96, 14), (1, 2, 288, 352, 15), (7, 1, 64, 64, 16)])
+def test_oracle_parity_at_shapes_outside_the_fixtures(lib_built, B, N, H, W, seed):
+    """Round 6: the kernel choice now depends on the shape in more places (conv_tile teams below 320 team workgroups, one stage per team; conv_rollt / conv_rollk /
+    conv_efd16 from their unit thresholds; one stream below 400k stack pixels; redir in line below 2M) -- so the whole forward against the CPU oracle at shapes no
+    fixture has: odd slice counts incl. 1 and 2, non-square maps whose 1/8 ... 1/32 grids are not multiples of the 4 x 16 / 8 x 8 blocks (edge tiles in every team
+    launch), batch sizes 1 ... 7.  Gate 1e-3 on every output, pred3 inside the drift guard; the batch's last stack alone agrees with it inside the batch to 1e-4."""
+    entries = list(graph.param_entries(graph.dff_net_convs()))
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict_numpy(entries, 7, "smooth").items()}
+    FS = torch.from_numpy(synth.focal_stack(B, N, H, W, seed=seed))
+    fd = torch.from_numpy(synth.focus_dists(B, N, H, W)) * (1.0 + 0.1 * torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(seed)))
+    with torch.no_grad():
+        ref = cpu_ref.dff_forward(sd, FS, fd)
+    model = model_for(sd, (7, "smooth"))
+    with torch.no_grad():
+        got = model(FS.cuda(), fd.cuda())
+        single = model(FS[B - 1:].cuda(), fd[B - 1:].cuda())
+    for name, r, o in zip(("mid_out", "pred1", "pred2", "pred3"), ref, got):
+        assert cpu_ref.rel_l2(o.cpu(), r) <= OUT_TOL["bf16x3"], name
+    assert cpu_ref.rel_l2(got[3].cpu(), ref[3]) <= DRIFT_OUT
+    assert cpu_ref.rel_l2(single[3].cpu(), got[3][B - 1:].cpu()) <= 1e-4
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("B,N,H,W,wgs", [(1, 10, 256, 256, 0), (2, 3, 128, 256, 16), (3, 1, 128, 128, 0), (2, 2, 96, 288, 8), (3, 2, 352, 96, 0), (4, 10, 128, 128, 24),
                                          (2, 15, 64, 96, 8)])
