@@ -40,7 +40,8 @@ namespace dffw {
 // [z nstage / KT, (z + 1) nstage / KT) (the split-K partition) and its own LDS image; the teams' accumulators meet in LDS (team 0 adds them in team
 // order and runs the epilogue): no fp32 partials through memory and no splitk_finish launch behind the kernel, which is what the few-tile layers of a
 // batch-1 forward pay for split-K (28 of its 89 launches, 5-6 us each on a chain of dependent 11 us launches).  nstage % KT == 0 (the teams meet at
-// the same workgroup barriers), single-pass geometries only.
+// the same workgroup barriers; the engine launches one stage per team), ONE pass per workgroup: the transposed conv only with its passes split over grid.z
+// (TileArgs::pass_split), where a team per 32-channel stage replaces the walk over the stages.
 template <int PREC, int GEO, int NT, int TZ, int TY, int TX, int CG, int PIPE, int NWAVES = 4, bool SPLITK = false, bool LEAN = false, int KT = 1>
 __global__ __launch_bounds__(NWAVES * KT * 64) void conv_tile(const ConvArgs a, const TileArgs t) {
     using T = TileT<GEO, TZ, TY, TX, CG>;
