@@ -568,7 +568,16 @@ static int pack_conv(const LayerDef &L, int prec, const float *weight, const flo
             tp.npass = (int)tapsets.size();
             const int cg8 = cg / 8;
             for (int ps = 0; ps < tp.npass; ++ps) {
-                const auto &taps = tapsets[ps];
+                // pair form (round 6): chunks 0-8 = filter row ky with the pair columns jx = 0, 2, 4, 6 as its four K octets, chunks 9-11 = the last pair column
+                // (jx = 8) of rows 0-3, 4-7, 8.  Output rows y and y + 2 then read the SAME operand fragment for (y + 2, ky) and (y, ky + 1) -- the dilation is 2 --,
+                // which stem_pipe loads once (its LDS port is the kernel's busiest unit: 0.65); conv_tile's pair-form kernel just follows the table
+                std::vector<Tap> ptaps;
+                if (pair && tapsets[ps].size() == 45) {
+                    for (int ky = 0; ky < 9; ++ky)
+                        for (int ji = 0; ji < 4; ++ji) ptaps.push_back(tapsets[ps][ky * 5 + ji]);
+                    for (int ky = 0; ky < 9; ++ky) ptaps.push_back(tapsets[ps][ky * 5 + 4]);
+                }
+                const auto &taps = ptaps.empty() ? tapsets[ps] : ptaps;
                 const int K8 = (int)taps.size() * cg8;
                 const int KC = (K8 + 3) / 4;
                 tp.KC[ps] = KC;

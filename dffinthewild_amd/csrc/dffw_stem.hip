@@ -166,11 +166,47 @@ __global__ __launch_bounds__(512) void stem_pipe(const ConvArgs a, const TileArg
             load_tile(cn);   // in flight under this tile's contraction
         }
         // ---- contraction: 12 chunks x 4 operand tiles, filter fragments from LDS ----
+        // Chunks 0-8 are the filter rows ky (K octet g = pair column 2g), chunks 9-11 the last pair column (the engine's pair-form pack).  The wave's operand
+        // tiles are the rows ty .. ty + 3 of one 16-pair column block, and the dilation is 2: the fragment of (row ty + 2, chunk ky) IS the fragment of
+        // (row ty, chunk ky + 1), so rows j and j + 2 share their loads -- 10 instead of 18 per row pair, 88 instead of 120 ds_read_b128 per wave and tile on a
+        // kernel whose busiest unit is the LDS port (0.65; matrix pipe 0.59).  Every accumulator still takes its chunks in the order 0 ... 11 and the three
+        // products of a chunk in conv_tile's order: bit-identical to the table walk.
         f32x4 acc[MTW];
 #pragma unroll
         for (int j = 0; j < MTW; ++j) acc[j] = bias4;
+        static_assert(MTW == 4 && KC == 12, "row pairs (j, j + 2), nine filter rows + three chunks of the last pair column");
+        {
+            short8 wph = short8{0, 0, 0, 0, 0, 0, 0, 0}, wpl = wph;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
+            for (int ky = 0; ky <= 9; ++ky) {
+                short8 whi = wph, wlo = wpl;
+                if (ky < 9) {
+                    whi = *reinterpret_cast<const short8 *>(wlds + (ky * 2 + 0) * 1024 + lane * 16);
+                    wlo = *reinterpret_cast<const short8 *>(wlds + (ky * 2 + 1) * 1024 + lane * 16);
+                }
+                const int tofs = ky < 9 ? toff[ky] : toff[8] + 2 * T::FXL * PIXB;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const unsigned char *lp = smem + pofs[jj] + tofs;
+                    const short8 xh = *reinterpret_cast<const short8 *>(lp);
+                    const short8 xl = *reinterpret_cast<const short8 *>(lp + PLANEB);
+                    if (ky < 9) {
+                        acc[jj] = mma<false>(wlo, xh, acc[jj]);
+                        acc[jj] = mma<false>(whi, xl, acc[jj]);
+                        acc[jj] = mma<false>(whi, xh, acc[jj]);
+                    }
+                    if (ky > 0) {
+                        acc[jj + 2] = mma<false>(wpl, xh, acc[jj + 2]);
+                        acc[jj + 2] = mma<false>(wph, xl, acc[jj + 2]);
+                        acc[jj + 2] = mma<false>(wph, xh, acc[jj + 2]);
+                    }
+                }
+                wph = whi;
+                wpl = wlo;
+            }
+        }
+#pragma unroll
+        for (int kc = 9; kc < KC; ++kc) {
             const short8 whi = *reinterpret_cast<const short8 *>(wlds + (kc * 2 + 0) * 1024 + lane * 16);
             const short8 wlo = *reinterpret_cast<const short8 *>(wlds + (kc * 2 + 1) * 1024 + lane * 16);
 #pragma unroll
