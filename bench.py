@@ -105,6 +105,11 @@ def roofline_from_profile(model, inputs, device, precision="bf16x3"):
         "all_conv_kernels": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                              "frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4),
                              "share_of_forward_time": round(conv_ms / total_ms, 3)},
+        # the dominant kernel's launches one by one (since round 6 one instantiation serves layers of 8x different size: `frac` above is their total
+        # work over their total time)
+        "launches_of_kernel": [{"layer": lname, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+                                "frac_mfma": round(fl / (ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)}
+                               for k, lname, fl, _, ms in rows if k == dom_name and ms > 0],
         "profiled_forward_ms": round(total_ms, 3), "n_launches": len(rows),
         "durations": "HIP events around every launch of one extra forward after the timed region, on the launch stream; in this "
                      "profiling mode the engine runs the pyramid's three scales one after the other (side by side, as in the timed "
